@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by RUNNING THE
+REFERENCE (its ``models``/``modules`` packages, imported on CPU).
+
+Runs only in the build container, where /root/reference exists; the reference
+never travels to the GPU box -- only the .npz vectors do.  The reference's
+``utils.py``/``data.py`` need torchvision and do not import here, so the cfg
+keys that ``process_control`` would derive (utils.py:104-192) are set by hand
+and the train loop body (train_gan.py:139-176) is driven around the imported
+model with explicitly injected latents.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--only NAME]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('MC_REFERENCE', '/root/reference/src')
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+os.chdir(REF)                     # config.py opens config.yml relatively (config.py:4)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from config import cfg  # noqa: E402
+
+import golden_util as gu  # noqa: E402
+
+torch.set_num_threads(8)
+OUT = gu.GOLDEN_DIR
+
+
+def set_gan_cfg(g_hidden, d_hidden, classes, data_name='CIFAR10'):
+    cfg['model_name'] = 'mcgan'
+    cfg['data_name'] = data_name
+    cfg['device'] = 'cpu'
+    cfg['classes_size'] = classes
+    cfg['controller_rate'] = 0.5
+    cfg['data_shape'] = [3, 32, 32]
+    cfg['gan'] = {'latent_size': 128, 'generator_hidden_size': list(g_hidden),
+                  'discriminator_hidden_size': list(d_hidden), 'embedding_size': 32}
+
+
+def np_state(sd, prefix='sd/'):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f'wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+# --------------------------------------------------------------------------- #
+def fx_mc_unit():
+    """MultimodalController forward/backward, 4-D and 2-D inputs (modules.py:71-76)."""
+    from modules import MultimodalController
+    torch.manual_seed(0)
+    mc = MultimodalController(32, 10, 0.5)
+    x4 = torch.randn(4, 32, 4, 4, requires_grad=True)
+    x2 = torch.randn(4, 32, requires_grad=True)
+    lab = torch.tensor([3, 0, 9, 3])
+    ind = F.one_hot(lab, 10).float()
+    g4, g2 = torch.randn(4, 32, 4, 4), torch.randn(4, 32)
+    o4 = mc([x4, ind])[0]; o4.backward(g4)
+    o2 = mc([x2, ind])[0]; o2.backward(g2)
+    soft = torch.softmax(torch.randn(4, 10), -1)         # non one-hot indicator
+    os_ = mc([x4.detach(), soft])[0]
+    ones = MultimodalController(32, 10, 1)                # rate 1 -> identity
+    save('mc_unit.npz', codebook=mc.codebook.numpy(), x4=x4.detach().numpy(), x2=x2.detach().numpy(),
+         label=lab.numpy(), g4=g4.numpy(), g2=g2.numpy(), out4=o4.detach().numpy(), out2=o2.detach().numpy(),
+         dx4=x4.grad.numpy(), dx2=x2.grad.numpy(), soft=soft.numpy(), out_soft=os_.numpy(),
+         ones_codebook=ones.codebook.numpy())
+
+
+def fx_blocks():
+    """Single residual blocks of the reference: outputs, input/param grads,
+    BN running stats and SN u/v after one and two training forwards."""
+    import importlib
+    import models  # noqa: F401
+    M = sys.modules.get('models.mcgan') or importlib.import_module('models.mcgan')
+    from models.utils import make_SpectralNormalization
+    set_gan_cfg([16] * 4, [16] * 4, 10)
+    torch.manual_seed(3)
+    lab = torch.tensor([1, 7, 7, 0, 4, 9])
+    ind = F.one_hot(lab, 10).float()
+    arrays = {'label': lab.numpy()}
+
+    def run(tag, blk, x):
+        for p in blk.parameters():
+            torch.nn.init.normal_(p, 0.0, 0.2) if p.dim() > 1 else torch.nn.init.uniform_(p, 0.5, 1.5)
+        blk.train(True)
+        arrays.update(np_state(blk.state_dict(), f'{tag}/sd0/'))
+        x = x.clone().requires_grad_(True)
+        out = blk([x, ind])[0]
+        g = torch.randn_like(out)
+        out.backward(g)
+        arrays[f'{tag}/x'] = x.detach().numpy(); arrays[f'{tag}/g'] = g.numpy()
+        arrays[f'{tag}/out'] = out.detach().numpy(); arrays[f'{tag}/dx'] = x.grad.numpy()
+        for n, p in blk.named_parameters():
+            arrays[f'{tag}/grad/{n}'] = p.grad.numpy().copy()
+        arrays.update(np_state(blk.state_dict(), f'{tag}/sd1/'))
+        out2 = blk([x.detach(), ind])[0]                   # second forward: SN/BN state advances again
+        arrays[f'{tag}/out_second'] = out2.detach().numpy()
+        arrays.update(np_state(blk.state_dict(), f'{tag}/sd2/'))
+        blk.train(False)
+        arrays[f'{tag}/out_eval'] = blk([x.detach(), ind])[0].detach().numpy()
+
+    run('gen', M.GenResBlock(16, 16, 10, 0.5, 2), torch.randn(6, 16, 4, 4))
+    run('dis_first', M.FirstDisResBlock(3, 16, 10, 0.5).apply(make_SpectralNormalization), torch.randn(6, 3, 8, 8))
+    run('dis_s2', M.DisResBlock(16, 16, 10, 0.5, 2).apply(make_SpectralNormalization), torch.randn(6, 16, 8, 8))
+    run('dis_s1', M.DisResBlock(16, 16, 10, 0.5, 1).apply(make_SpectralNormalization), torch.randn(6, 16, 4, 4))
+    save('mcgan_blocks.npz', **arrays)
+
+
+def ref_train_iteration(model, opt, img, label, zs, d_iters=5, g_iters=1):
+    """train_gan.py:139-176 around the imported model, latents injected."""
+    zi = iter(zs)
+    for _ in range(d_iters):
+        opt['discriminator'].zero_grad(); opt['generator'].zero_grad()
+        d_x = model.discriminate(img, label)
+        generated = model.generate(label, next(zi))
+        d_gz = model.discriminate(generated.detach(), label)
+        d_loss = F.relu(1.0 - d_x).mean() + F.relu(1.0 + d_gz).mean()
+        d_loss.backward()
+        opt['discriminator'].step()
+    for _ in range(g_iters):
+        opt['discriminator'].zero_grad(); opt['generator'].zero_grad()
+        generated = model.generate(label, next(zi))
+        g_loss = -model.discriminate(generated, label).mean()
+        g_loss.backward()
+        opt['generator'].step()
+    return d_loss.item(), g_loss.item()
+
+
+def make_opt(model):
+    return {'generator': torch.optim.Adam(model.generator.parameters(), lr=2e-4, betas=(0.5, 0.999)),
+            'discriminator': torch.optim.Adam(model.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999))}
+
+
+def fx_mcgan_small():
+    """Reduced-width MCGAN, reference init (seed 0), 3 train iterations, B=8."""
+    import models
+    set_gan_cfg([32] * 4, [16] * 4, 10)
+    torch.manual_seed(0)
+    model = models.mcgan()
+    model.train(True)
+    arrays = np_state(model.state_dict(), 'sd/')
+    B, iters = 8, 3
+    img, lab = gu.synthetic_batch(B, 10, seed=1)
+    zs = gu.latent_batches(6 * iters + 1, B, 128, seed=2)
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy()
+    arrays['z'] = torch.stack(zs).numpy()
+    # single forward/backward probes before any update
+    probe = model.generate(lab, zs[-1])
+    d_probe = model.discriminate(img, lab)
+    arrays['probe_generated'] = probe.detach().numpy()
+    arrays['probe_d_real'] = d_probe.detach().numpy()
+    arrays.update(np_state(model.state_dict(), 'sd_after_probe/'))
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in arrays.items() if k.startswith('sd/')})
+    opt = make_opt(model)
+    losses = []
+    for it in range(iters):
+        losses.append(ref_train_iteration(model, opt, img, lab, zs[6 * it:6 * it + 6]))
+    arrays['losses'] = np.array(losses, dtype=np.float64)
+    arrays.update(np_state(model.state_dict(), 'sd_final/'))
+    model.train(False)
+    with torch.no_grad():
+        arrays['final_generated_eval'] = model.generate(lab, zs[-1]).numpy()
+        arrays['final_d_eval'] = model.discriminate(img, lab).numpy()
+    save('mcgan_small.npz', **arrays)
+
+
+def fx_mcgan_full():
+    """Full-size MCGAN (utils.py:156-162) with procedural weights: only inputs
+    that cannot be regenerated, losses and digests are stored."""
+    import models
+    g_hidden, d_hidden = [256] * 4, [128] * 4
+    set_gan_cfg(g_hidden, d_hidden, 10)
+    torch.manual_seed(0)
+    model = models.mcgan()
+    shapes = gu.mcgan_shapes(g_hidden, d_hidden, 10)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes == ref_shapes, set(shapes.items()) ^ set(ref_shapes.items())
+    sd = gu.procedural_state(shapes, seed=1234, num_mode=10)
+    model.load_state_dict(sd)
+    model.train(True)
+    B = 16
+    img, lab = gu.synthetic_batch(B, 10, seed=1)
+    zs = gu.latent_batches(6 * 2, B, 128, seed=2)
+    arrays = {}
+    gen0 = model.generate(lab, zs[0])
+    d0 = model.discriminate(img, lab)
+    arrays['probe_generated'] = gen0.detach().numpy()[:, :, ::4, ::4].copy()   # strided sample
+    arrays['probe_generated_digest'] = gu.checksum(gen0)
+    arrays['probe_d_real'] = d0.detach().numpy()
+    model.load_state_dict(sd)
+    opt = make_opt(model)
+    losses = [ref_train_iteration(model, opt, img, lab, zs[0:6]),
+              ref_train_iteration(model, opt, img, lab, zs[6:12])]
+    arrays['losses'] = np.array(losses, dtype=np.float64)
+    fin = model.state_dict()
+    for k in ['generator.blocks.2.conv.8.module.weight', 'generator.linear.module.bias',
+              'discriminator.blocks.1.conv.2.module.weight_orig', 'discriminator.blocks.4.conv.5.module.weight_u'
+              if 'discriminator.blocks.4.conv.5.module.weight_u' in fin else 'discriminator.blocks.3.conv.5.module.weight_u',
+              'generator.blocks.3.module.running_var', 'discriminator.blocks.7.module.weight_orig']:
+        arrays['digest/' + k] = gu.checksum(fin[k])
+    save('mcgan_full_digest.npz', **arrays)
+
+
+def fx_mcgan_coil():
+    """Non-CIFAR block schedule (models/mcgan.py:166-175): G [64,32,16,8],
+    D [8,16,32,64], 20 modes -- exercises channel-changing blocks and the
+    stride-1 block with a 1x1 shortcut."""
+    import models
+    set_gan_cfg([64, 32, 16, 8], [8, 16, 32, 64], 20, data_name='COIL100')
+    torch.manual_seed(5)
+    model = models.mcgan()
+    model.train(True)
+    arrays = np_state(model.state_dict(), 'sd/')
+    B = 4
+    img, lab = gu.synthetic_batch(B, 20, seed=11)
+    zs = gu.latent_batches(6, B, 128, seed=12)
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy(); arrays['z'] = torch.stack(zs).numpy()
+    opt = make_opt(model)
+    arrays['losses'] = np.array([ref_train_iteration(model, opt, img, lab, zs)], dtype=np.float64)
+    arrays.update(np_state(model.state_dict(), 'sd_final/'))
+    save('mcgan_coil_small.npz', **arrays)
+
+
+FIXTURES = {'mc_unit': fx_mc_unit, 'blocks': fx_blocks, 'mcgan_small': fx_mcgan_small,
+            'mcgan_full': fx_mcgan_full, 'mcgan_coil': fx_mcgan_coil}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in FIXTURES.items():
+        if a.only in (None, name):
+            fn()
