@@ -1,0 +1,197 @@
+/*
+ * mcgen_hip.h -- C ABI of libmcgen_hip.so: the MI355X (gfx950) kernels behind the
+ * MultimodalController training hot path.
+ *
+ * The reference (diaoenmao/Multimodal-Controller-for-Generative-Models) is pure
+ * Python on stock PyTorch: its "operator API" for this path is the nn.Module
+ * surface of src/modules/modules.py and src/models/mcgan.py, and every entry
+ * point below replaces a chain of ATen calls those modules make.  Each
+ * declaration cites the reference lines whose arithmetic it implements.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are NHWC ("channels last"), element type selected by `dtype`
+ *     (MCGEN_F32 = float, MCGEN_BF16 = bfloat16), channel pitch a multiple of 8;
+ *   - parameters, statistics, codes and gradients of parameters are float32;
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises, nothing
+ *     allocates: the caller owns every buffer (workspace sizes are queryable);
+ *   - return value 0 = launched, non-zero = rejected before launch
+ *     (mcgen_last_error() holds the reason).  Device-side faults surface through
+ *     the HIP runtime on the caller's next synchronisation, as for any kernel.
+ */
+#ifndef MCGEN_HIP_H
+#define MCGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
+
+const char* mcgen_last_error(void);
+int mcgen_abi_version(void);
+
+/* One K-segment of a fused convolution: the input tensor and the prologue that
+ * is applied while the tile is staged into LDS:
+ *     a = x[n, h>>ups, w>>ups, c]                 nn.Upsample(2,'nearest')   mcgan.py:17,27
+ *     a = a * scale[c] + shift[c]    (if scale)   nn.BatchNorm2d apply       mcgan.py:15,20,55
+ *     a = max(a, 0)                  (if relu)    nn.ReLU                    mcgan.py:16,21,56,79,102,105
+ *     a = a * code[n, c]             (if code)    MultimodalController.forward  modules.py:71-76
+ */
+typedef struct {
+    const void*  x;       /* [N, H>>ups, W>>ups, C]                                   */
+    const float* scale;   /* [C] or NULL                                              */
+    const float* shift;   /* [C] (read only when scale != NULL)                       */
+    const float* code;    /* [N, C] = indicator @ codebook, or NULL                   */
+    int32_t C;            /* channels of x (multiple of 8)                            */
+    int32_t ups;          /* 1: x is at half the convolution's resolution             */
+    int32_t relu;
+    int32_t ksize;        /* 3 (padding 1) or 1 (padding 0); stride is always 1       */
+} mcgen_seg_t;
+
+/* Fused convolution  y = epilogue( sum_seg conv(prologue_seg(x_seg), W_seg) ).
+ * Replaces, per call, one of the op chains of GenResBlock / FirstDisResBlock /
+ * DisResBlock (mcgan.py:9-44, 72-138) in the forward direction, and the matching
+ * autograd input-gradient chain in the backward direction (the same kernel run on
+ * flipped/transposed weights prepared by mcgen_prep_weight).
+ *
+ * Epilogue, in this order, on v = alpha * acc (acc summed over 2x2 windows when pool):
+ *     v += bias[co]                                   conv bias
+ *     v *= ocode[n, co]              (if ocode)       d(MC mask)             modules.py:75
+ *     v *= (z > 0), z = gate_x*gscale+gshift (if gate_x)  d(ReLU) [after BN when gscale]
+ *     stats_mode 2: partial sums of v and v*xhat, xhat = (gate_x-gmean)*grstd   (BN backward)
+ *     v += res[n, ho, wo, co]        (if res)         residual / shortcut add   mcgan.py:42,91,136
+ *     v  = tanh(v)                   (if tanh_out)    nn.Tanh                   mcgan.py:60
+ *     stats_mode 1: partial sums of v and v*v          (next BatchNorm's batch statistics)
+ * pool=1 with alpha=0.25 is nn.AvgPool2d(2) (mcgan.py:82,85,110,114); with alpha=1
+ * it is the adjoint of the nearest x2 upsample.
+ */
+typedef struct {
+    mcgen_seg_t  seg[2];
+    int32_t      nseg;
+    const void*  w;        /* weight image from mcgen_prep_weight (all segments, in order) */
+    const float* bias;     /* [Cout] or NULL                                               */
+    void*        y;        /* [N, Ho, Wo, Cy]  (Ho = H>>pool)                              */
+    int32_t N, H, W;       /* convolution (pre-pool) resolution; H, W powers of two        */
+    int32_t Cout;          /* logical output channels                                      */
+    int32_t Cout_w;        /* rows per block of the weight image (Cout rounded up to 16)   */
+    int32_t Cy;            /* channel pitch of y / res / gate_x (multiple of 8, >= Cout)   */
+    int32_t pool;
+    float   alpha;
+    const void*  res;
+    const float* ocode;    /* [N, Cout]                                                    */
+    const void*  gate_x;
+    const float* gscale; const float* gshift; const float* gmean; const float* grstd;
+    int32_t tanh_out;
+    float*  stats;         /* [m_tiles][2][Cy] partial sums, or NULL                       */
+    int32_t stats_mode;
+} mcgen_conv_t;
+
+/* number of M tiles (rows of `stats`) the launch of `p` will use */
+int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream);
+
+/* Weight gradient of the same fused convolution for ONE segment:
+ *     dW[co, ci, kh, kw] = alpha * sum_{n,h,w} dy[n, (h,w)>>dy_ups, co] * prologue(x)[n, h+kh-1, w+kw-1, ci]
+ * (autograd of nn.Conv2d / nn.Linear weights, mcgan.py:19,23,29,51,59,77,80,84,...).
+ * Partial sums over pixel groups go to `slabs` [splits][weight-image of the segment];
+ * mcgen_wgrad_reduce sums them in a fixed order into the fp32 master-layout gradient.
+ */
+typedef struct {
+    mcgen_seg_t  seg;
+    const void*  dy;       /* [N, H>>dy_ups, W>>dy_ups, Cdy]                                */
+    int32_t N, H, W;
+    int32_t Cout, Cout_w, Cdy;
+    int32_t dy_ups;        /* 1: dy is the gradient of a 2x2-pooled output                  */
+    float*  slabs;
+    int32_t splits;
+} mcgen_wgrad_t;
+
+int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p);          /* floats per split */
+int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
+/* grad[master layout] (+)= alpha * sum_s slabs[s]; master layout = [Cout][Cin][k][k] with
+ * row co stored at (co % rows_inner) * row_perm + co / rows_inner when row_perm > 1
+ * (the generator's Linear(128 -> C*4*4) viewed as NHWC, mcgan.py:51,67).
+ * transpose=0 only (weight gradients are always produced in forward orientation). */
+int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
+                       int Cout_w, int row_perm, float alpha, int accumulate, void* stream);
+
+/* Build the kernel-side weight image from fp32 master weights [Cout][Cin][k][k]:
+ *   image[q][tap][co_w][32] (q = input-channel chunk of 32), element type `dtype`,
+ *   multiplied by wscale / (*sigma if sigma != NULL)   -- spectral norm's W / sigma,
+ *   torch.nn.utils.spectral_norm as applied by models/utils.py:17-21;
+ *   transpose=1 builds the image of the transposed, spatially flipped filter used for
+ *   input gradients (rows = Cin, K = Cout).
+ * Returns the number of elements written through *elems_out (may be NULL). */
+int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int transpose);
+int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                      int transpose, int row_perm, const float* sigma, float wscale, void* stream);
+
+/* layout / dtype conversion at the module boundary (the reference works on NCHW fp32) */
+int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+
+/* code[N, C] = indicator[N, M] @ codebook[M, C]      MultimodalController.forward, modules.py:73 */
+int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream);
+/* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers; NHWC */
+int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, void* stream);
+
+/* BatchNorm2d training statistics from per-tile partial sums (mcgan.py:15,20,55):
+ * mean/var over `count` elements per channel, scale = gamma*rstd, shift = beta-mean*scale,
+ * running stats updated with momentum (unbiased variance), all in one launch.
+ * `fold` > 1: partial column j belongs to channel j % C (Linear output viewed as [C*4*4]). */
+int mcgen_bn_finalize(const float* partials, int tiles, int pitch, int fold, int C, double count,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                      void* stream);
+/* eval mode: scale/shift from the running statistics */
+int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* BatchNorm backward: reduce partial (sum dz, sum dz*xhat) -> dgamma, dbeta (+= when accumulate),
+ * then dx = scale * (dz - dbeta/count - xhat * dgamma/count) (+ add), xhat = (x-mean)*rstd */
+int mcgen_bn_bwd_finalize(const float* partials, int tiles, int pitch, int C,
+                          float* dgamma, float* dbeta, float* sums, int accumulate, void* stream);
+int mcgen_bn_bwd_apply(const void* dz, const void* x, const void* add, void* dx, int dtype,
+                       int64_t pixels, int C, const float* sums, double count,
+                       const float* scale, const float* mean, const float* rstd, void* stream);
+
+/* column sums: out[c] (+)= alpha * sum_p x[p, c]   (bias gradients) */
+int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int row_perm,
+                 float alpha, int accumulate, float* workspace, void* stream);
+
+/* Spectral norm (torch.nn.utils.spectral_norm via models/utils.py:17-21), all layers of a
+ * network in one launch.  Per layer l: W = w + off[l] viewed [rows[l]][cols[l]];
+ * if do_iter: v = normalize(W^T u), u = normalize(W v) (eps 1e-12, in place); sigma[l] = u.(W v). */
+typedef struct { int64_t w_off, u_off, v_off; int32_t rows, cols; } mcgen_sn_layer_t;
+int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                        int do_iter, float* sigma, void* stream);
+/* gradient through W/sigma:  g = (g - <g, W/sigma> u v^T) / sigma, in place per layer */
+int mcgen_sn_grad_fix(float* g_base, const float* w_base, const float* uv_base,
+                      const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, void* stream);
+
+/* Discriminator tail (mcgan.py:158-165): logit[n] = b + sum_c (w[c]/sigma) * sum_hw relu(x)*code */
+int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b,
+                    const float* sigma, float* pooled, float* logit, int N, int HW, int C, void* stream);
+int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, const float* code, const float* w,
+                    const float* sigma, const float* pooled, void* dx, float* dw, float* db,
+                    int N, int HW, int C, int accumulate, void* stream);
+
+/* Hinge losses (train_gan.py:154,172).  d: loss = mean relu(1-real) + mean relu(1+fake);
+ * g: loss = -mean(fake).  Writes the loss and d(loss)/d(logit). */
+int mcgen_hinge_d(const float* real, const float* fake, int N, float* loss, float* dreal, float* dfake, void* stream);
+int mcgen_hinge_g(const float* fake, int N, float* loss, float* dfake, void* stream);
+
+/* dx = dy * (1 - y*y)      (nn.Tanh backward, mcgan.py:60) */
+int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, void* stream);
+
+/* Adam over one flat fp32 buffer (torch.optim.Adam as configured at train_gan.py:43-47,231):
+ * step is a device counter incremented by the call. */
+int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int64_t* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGEN_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmcgen_hip.so (the C ABI in include/mcgen_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmcgen_hip.so')
+
+F32, BF16 = 0, 1
+
+
+class Seg(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('code', C.c_void_p),
+                ('C', C.c_int32), ('ups', C.c_int32), ('relu', C.c_int32), ('ksize', C.c_int32)]
+
+
+class Conv(C.Structure):
+    _fields_ = [('seg', Seg * 2), ('nseg', C.c_int32),
+                ('w', C.c_void_p), ('bias', C.c_void_p), ('y', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Cout', C.c_int32), ('Cout_w', C.c_int32), ('Cy', C.c_int32),
+                ('pool', C.c_int32), ('alpha', C.c_float),
+                ('res', C.c_void_p), ('ocode', C.c_void_p), ('gate_x', C.c_void_p),
+                ('gscale', C.c_void_p), ('gshift', C.c_void_p), ('gmean', C.c_void_p), ('grstd', C.c_void_p),
+                ('tanh_out', C.c_int32), ('stats', C.c_void_p), ('stats_mode', C.c_int32)]
+
+
+class Wgrad(C.Structure):
+    _fields_ = [('seg', Seg), ('dy', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Cout', C.c_int32), ('Cout_w', C.c_int32), ('Cdy', C.c_int32),
+                ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32)]
+
+
+class SnLayer(C.Structure):
+    _fields_ = [('w_off', C.c_int64), ('u_off', C.c_int64), ('v_off', C.c_int64),
+                ('rows', C.c_int32), ('cols', C.c_int32)]
+
+
+# every symbol include/mcgen_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _d, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+SYMBOLS = {
+    'mcgen_last_error': (C.c_char_p, []),
+    'mcgen_abi_version': (_i, []),
+    'mcgen_conv_m_tiles': (_i, [C.POINTER(Conv), _i]),
+    'mcgen_conv_fused': (_i, [C.POINTER(Conv), _i, _vp]),
+    'mcgen_wgrad_slab_elems': (_i64, [C.POINTER(Wgrad)]),
+    'mcgen_wgrad': (_i, [C.POINTER(Wgrad), _i, _vp]),
+    'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
+    'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_bn_eval_affine': (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    'mcgen_bn_bwd_finalize': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),
+    'mcgen_colsum': (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
+    'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'mcgen_hinge_g': (_i, [_vp, _i, _vp, _vp, _vp]),
+    'mcgen_tanh_bwd': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    'mcgen_adam': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+class McgenError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise McgenError(f'{LIB_PATH} is missing: run __graft_entry__.build() '
+                             f'(or csrc/build.sh); there is no CPU fallback')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        raise McgenError(f'{what}: {load().mcgen_last_error().decode()}')

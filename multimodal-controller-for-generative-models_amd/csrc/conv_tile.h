@@ -1,0 +1,121 @@
+// Tile geometry and the prologue-applying LDS window stager shared by the fused convolution
+// (conv_fused.hip) and its weight-gradient kernel (wgrad.hip).
+#pragma once
+#include "mcgen_common.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ void run(const frag& w, const frag& a, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x8 frag;
+    static __device__ __forceinline__ void run(const frag& w, const frag& a, f32x4& acc) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], a[i], acc, 0, 0, 0);
+    }
+};
+
+// A tile is BM consecutive pixels of the flattened (n, h, w) grid: either TH whole rows of one
+// image, or TI whole images.  H, W and BM are powers of two.
+struct Geo {
+    int n0, h0;             // first image / first row of the tile
+    int TI, TH;             // images and rows per tile
+    int lgW, lgTHW;         // log2(W), log2(TH*W)
+};
+
+static __device__ __forceinline__ Geo make_geo(int BM, int tile_m, int H, int W) {
+    Geo g;
+    const int HW = H * W;
+    g.lgW = 31 - __builtin_clz(W);
+    if (BM <= HW) {
+        g.TI = 1; g.TH = BM / W;
+        const int pix0 = tile_m * BM;
+        g.n0 = pix0 / HW; g.h0 = (pix0 % HW) / W;
+    } else {
+        g.TI = BM / HW; g.TH = H;
+        g.n0 = tile_m * g.TI; g.h0 = 0;
+    }
+    g.lgTHW = 31 - __builtin_clz(g.TH * W);
+    return g;
+}
+
+// Stages the tile's input window (tile + halo) for one chunk of 32 channels into LDS as
+// [window pixel][32 channels] with pitch APITCH, applying the segment's prologue:
+// nearest-x2 upsample by index, BatchNorm scale/shift, ReLU, MultimodalController code.
+// Out-of-image pixels and channels beyond C are written as zeros (the conv's zero padding).
+template <typename T, int NT, int NI, int APITCH>
+struct PatchStager {
+    using E = Elem<T>;
+    int it_src[NI];      // element offset of the source pixel (+ sub-chunk), -1 = zero fill
+    int it_n[NI];        // image index (row of the code table)
+    int it_lds[NI];      // byte offset in the LDS window, -1 = no item
+    int it_sub[NI];      // channel offset inside the chunk: 0, 8, 16, 24
+
+    __device__ __forceinline__ void setup(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W, int tid) {
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        const int PP = g.TI * PR * PC;
+        const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tid + k * NT;
+            it_src[k] = -1; it_lds[k] = -1; it_n[k] = 0; it_sub[k] = 0;
+            if (it < PP * 4) {
+                const int sub = it & 3, pp = it >> 2;
+                const int pc = pp % PC, t2 = pp / PC;
+                const int pr = t2 % PR, ti = t2 / PR;
+                const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;
+                it_lds[k] = pp * APITCH + sub * 8 * E::BYTES;
+                it_sub[k] = sub * 8;
+                it_n[k] = n;
+                if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                    const int hs = sg.ups ? (h >> 1) : h, ws = sg.ups ? (w >> 1) : w;
+                    it_src[k] = ((n * Hs + hs) * Ws + ws) * sg.C + sub * 8;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void stage(const mcgen_seg_t& sg, int c0, char* ldsA) const {
+        const T* xs = reinterpret_cast<const T*>(sg.x);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (it_lds[k] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            const int c = c0 + it_sub[k];
+            if (it_src[k] >= 0 && c < sg.C) {
+                E::load8(xs + (size_t)it_src[k] + c0, v);
+                if (sg.scale) {
+                    float sc[8], sh[8];
+                    load8f(sg.scale + c, sc); load8f(sg.shift + c, sh);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (sg.code) {
+                    float cd[8];
+                    load8f(sg.code + (size_t)it_n[k] * sg.C + c, cd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd[i];
+                }
+            }
+            E::store8(reinterpret_cast<T*>(ldsA + it_lds[k]), v);
+        }
+    }
+};
+
+static inline int mcgen_patch_pixels(int BM, int H, int W, int ksize) {
+    const int HW = H * W;
+    int TI = 1, TH;
+    if (BM <= HW) TH = BM / W; else { TI = BM / HW; TH = H; }
+    const int halo = ksize >> 1;
+    return TI * (TH + 2 * halo) * (W + 2 * halo);
+}

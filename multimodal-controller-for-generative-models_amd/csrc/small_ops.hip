@@ -1,0 +1,519 @@
+// Memory-bound helpers around the fused convolutions (gfx950): layout conversion, weight-image
+// construction, MultimodalController code lookup, BatchNorm statistics finalisation and backward,
+// spectral-norm power iteration, discriminator tail, hinge losses, tanh backward, Adam.
+#include "mcgen_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+int mcgen_fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return 1;
+}
+extern "C" const char* mcgen_last_error(void) { return g_err; }
+extern "C" int mcgen_abi_version(void) { return 1; }
+
+namespace {
+
+inline int grid_for(size_t n, int block = 256, int cap = 4096) {
+    size_t b = (n + block - 1) / block; if (b < 1) b = 1; if (b > (size_t)cap) b = cap; return (int)b;
+}
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Elem<T>::to_f(*p); }
+
+// ---- layout conversion --------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int HW, int Cp) {
+    const size_t total = (size_t)N * HW * Cp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp); const size_t pix = i / Cp;
+        const int hw = (int)(pix % HW); const int n = (int)(pix / HW);
+        dst[i] = Elem<T>::from_f(c < C ? src[((size_t)n * C + c) * HW + hw] : 0.f);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int Cp) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW); const size_t t = i / HW;
+        const int c = (int)(t % C); const int n = (int)(t / C);
+        dst[i] = Elem<T>::to_f(src[((size_t)n * HW + hw) * Cp + c]);
+    }
+}
+
+// ---- weight image ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ img, int Cout, int Cin, int KS,
+                                   int transpose, int row_perm, const float* __restrict__ sigma, float wscale) {
+    const int ntap = KS * KS;
+    const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
+    const int rows_w = (rows + 15) / 16 * 16;
+    const int nchunk = (((kdim + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t total = (size_t)nchunk * ntap * rows_w * MCGEN_CK;
+    const float sc = sigma ? wscale / sigma[0] : wscale;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % MCGEN_CK); size_t t = i / MCGEN_CK;
+        const int row = (int)(t % rows_w); t /= rows_w;
+        const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
+        const int k = q * MCGEN_CK + col;
+        float v = 0.f;
+        if (row < rows && k < kdim) {
+            int co = transpose ? k : row;
+            const int ci = transpose ? row : k;
+            if (row_perm > 1) { const int Cc = Cout / row_perm; co = (co % Cc) * row_perm + co / Cc; }
+            const int kh = tap / KS, kw = tap % KS;
+            const int mtap = transpose ? ((KS - 1 - kh) * KS + (KS - 1 - kw)) : tap;
+            v = w[((size_t)co * Cin + ci) * ntap + mtap] * sc;
+        }
+        img[i] = Elem<T>::from_f(v);
+    }
+}
+
+// ---- MultimodalController ---------------------------------------------------------------------------
+__global__ void mc_code_kernel(const float* __restrict__ ind, const float* __restrict__ cb, float* __restrict__ code,
+                               int N, int M, int C) {
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), n = (int)(i / C);
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s = fmaf(ind[(size_t)n * M + m], cb[(size_t)m * C + c], s);
+        code[i] = s;
+    }
+}
+template <typename T>
+__global__ void mc_apply_kernel(const T* __restrict__ x, const float* __restrict__ code, T* __restrict__ y,
+                                int N, int HW, int C) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const int n = (int)(i / ((size_t)HW * C));
+        y[i] = Elem<T>::from_f(Elem<T>::to_f(x[i]) * code[(size_t)n * C + c]);
+    }
+}
+
+// ---- BatchNorm ------------------------------------------------------------------------------------
+// one thread per channel; partial sums are added in tile order in fp64 (deterministic)
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* rmean, float* rvar, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_o, float* rstd_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t)
+        for (int f = 0; f < fold; ++f) {
+            s1 += (double)part[((size_t)t * 2 + 0) * pitch + f * C + c];
+            s2 += (double)part[((size_t)t * 2 + 1) * pitch + f * C + c];
+        }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
+    mean_o[c] = (float)mean; rstd_o[c] = rstd;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc; shift[c] = beta[c] - rmean[c] * sc;
+}
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int C,
+                                       float* dgamma, float* dbeta, float* sums, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) {
+        s1 += (double)part[((size_t)t * 2 + 0) * pitch + c];
+        s2 += (double)part[((size_t)t * 2 + 1) * pitch + c];
+    }
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+}
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ x, const T* __restrict__ add,
+                                    T* __restrict__ dx, size_t pixels, int C, const float* __restrict__ sums, float inv_count,
+                                    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd) {
+    const int cv = C / 8;
+    const size_t total = pixels * cv;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        float g[8], xv[8], o[8];
+        Elem<T>::load8(dz + i * 8, g); Elem<T>::load8(x + i * 8, xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (xv[k] - mean[c + k]) * rstd[c + k];
+            o[k] = scale[c + k] * (g[k] - sums[c + k] * inv_count - xh * sums[C + c + k] * inv_count);
+        }
+        if (add) {
+            float a[8]; Elem<T>::load8(add + i * 8, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] += a[k];
+        }
+        Elem<T>::store8(dx + i * 8, o);
+    }
+}
+
+// ---- column sums ------------------------------------------------------------------------------------
+// stage 1: block b sums rows [b*rpb, (b+1)*rpb) for every column -> ws[b][C]; stage 2 adds blocks in order
+template <typename T>
+__global__ void colsum_stage1(const T* __restrict__ x, size_t rows, int C, int pitch, float* __restrict__ ws, size_t rpb) {
+    const size_t r0 = blockIdx.x * rpb, r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (size_t r = r0; r < r1; ++r) s += Elem<T>::to_f(x[r * pitch + c]);
+        ws[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void colsum_stage2(const float* __restrict__ ws, int blocks, int C, float* out, int row_perm, float alpha, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += (double)ws[(size_t)b * C + c];
+    int o = c;
+    if (row_perm > 1) { const int Cc = C / row_perm; o = (c % Cc) * row_perm + c / Cc; }
+    const float v = alpha * (float)s;
+    out[o] = accumulate ? out[o] + v : v;
+}
+
+// ---- spectral norm ----------------------------------------------------------------------------------
+__device__ float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+// one workgroup per layer
+__global__ void sn_power_iter_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
+                                     int do_iter, float* sigma) {
+    __shared__ float red[32];
+    extern __shared__ float sh[];                  // [rows + cols]
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* W = wb + L.w_off;
+    float* u = uvb + L.u_off; float* v = uvb + L.v_off;
+    float* su = sh; float* sv = sh + L.rows;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < L.rows; i += nt) su[i] = u[i];
+    for (int j = tid; j < L.cols; j += nt) sv[j] = v[j];
+    __syncthreads();
+    if (do_iter) {
+        // v = normalize(W^T u)
+        float nrm = 0.f;
+        for (int j = tid; j < L.cols; j += nt) {
+            float s = 0.f;
+            for (int i = 0; i < L.rows; ++i) s = fmaf(W[(size_t)i * L.cols + j], su[i], s);
+            sv[j] = s; nrm += s * s;
+        }
+        nrm = sqrtf(block_sum(nrm, red));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+        for (int j = tid; j < L.cols; j += nt) sv[j] *= inv;
+        __syncthreads();
+    }
+    // t = W v  (rows); one wave per row stripe
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    float dot_u_wv = 0.f, nrm2 = 0.f;
+    for (int i = wave; i < L.rows; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < L.cols; j += 64) s = fmaf(W[(size_t)i * L.cols + j], sv[j], s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        s = __shfl(s, 0);
+        if (lane == 0) {
+            if (do_iter) { nrm2 += s * s; su[i] = s; }      // su now holds W v (unnormalised)
+            else dot_u_wv += su[i] * s;
+        }
+    }
+    if (do_iter) {
+        nrm2 = block_sum(nrm2, red);                          // also orders the su writes
+        const float n = sqrtf(nrm2);
+        const float inv = 1.f / fmaxf(n, 1e-12f);
+        // u = Wv / max(|Wv|, eps);  sigma = u . (W v) = |Wv|^2 * inv
+        for (int i = tid; i < L.rows; i += nt) u[i] = su[i] * inv;
+        for (int j = tid; j < L.cols; j += nt) v[j] = sv[j];
+        if (tid == 0) sigma[blockIdx.x] = nrm2 * inv;
+    } else {
+        dot_u_wv = block_sum(dot_u_wv, red);
+        if (tid == 0) sigma[blockIdx.x] = dot_u_wv;
+    }
+}
+__global__ void sn_grad_fix_kernel(float* gb, const float* __restrict__ wb, const float* __restrict__ uvb,
+                                   const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma) {
+    __shared__ float red[32];
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    float* G = gb + L.w_off; const float* W = wb + L.w_off;
+    const float* u = uvb + L.u_off; const float* v = uvb + L.v_off;
+    const float sg = sigma[blockIdx.x];
+    const size_t n = (size_t)L.rows * L.cols;
+    float d = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) d = fmaf(G[i], W[i], d);
+    d = block_sum(d, red) / sg;                                // <G, W_orig / sigma>
+    const float inv = 1.f / sg;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = (int)(i / L.cols), c = (int)(i % L.cols);
+        G[i] = (G[i] - d * u[r] * v[c]) * inv;
+    }
+}
+
+// ---- discriminator tail -------------------------------------------------------------------------------
+// one workgroup per sample; thread c handles channel c
+template <typename T>
+__global__ void dtail_fwd_kernel(const T* __restrict__ x, const float* __restrict__ code, const float* __restrict__ w,
+                                 const float* __restrict__ b, const float* __restrict__ sigma, float* pooled, float* logit,
+                                 int HW, int C) {
+    __shared__ float red[32];
+    const int n = blockIdx.x;
+    float part = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += fmaxf(Elem<T>::to_f(x[((size_t)n * HW + p) * C + c]), 0.f);
+        s *= code ? code[(size_t)n * C + c] : 1.f;
+        pooled[(size_t)n * C + c] = s;
+        part = fmaf(s, w[c] / sigma[0], part);
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) logit[n] = part + b[0];
+}
+template <typename T>
+__global__ void dtail_bwd_dx_kernel(const float* __restrict__ dlogit, const T* __restrict__ x, const float* __restrict__ code,
+                                    const float* __restrict__ w, const float* __restrict__ sigma, T* __restrict__ dx,
+                                    int N, int HW, int C) {
+    const size_t total = (size_t)N * HW * C;
+    const float inv = 1.f / sigma[0];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const int n = (int)(i / ((size_t)HW * C));
+        const float g = dlogit[n] * w[c] * inv * (code ? code[(size_t)n * C + c] : 1.f);
+        dx[i] = Elem<T>::from_f(Elem<T>::to_f(x[i]) > 0.f ? g : 0.f);
+    }
+}
+// dw[c] (wrt the NORMALISED weight; mcgen_sn_grad_fix maps it to weight_orig) and db
+__global__ void dtail_bwd_w_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled,
+                                   float* dw, float* db, int N, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s = fmaf(dlogit[n], pooled[(size_t)n * C + c], s);
+        dw[c] = accumulate ? dw[c] + s : s;
+    }
+    if (c == 0) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dlogit[n];
+        db[0] = accumulate ? db[0] + s : s;
+    }
+}
+
+// ---- losses -------------------------------------------------------------------------------------------
+__global__ void hinge_d_kernel(const float* real, const float* fake, int N, float* loss, float* dreal, float* dfake) {
+    __shared__ float red[32];
+    float a = 0.f, b = 0.f;
+    const float inv = 1.f / (float)N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float r = 1.f - real[i], f = 1.f + fake[i];
+        a += fmaxf(r, 0.f); b += fmaxf(f, 0.f);
+        dreal[i] = r > 0.f ? -inv : 0.f;
+        dfake[i] = f > 0.f ? inv : 0.f;
+    }
+    a = block_sum(a, red); b = block_sum(b, red);
+    if (threadIdx.x == 0) loss[0] = a * inv + b * inv;
+}
+__global__ void hinge_g_kernel(const float* fake, int N, float* loss, float* dfake) {
+    __shared__ float red[32];
+    float a = 0.f;
+    const float inv = 1.f / (float)N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) { a += fake[i]; dfake[i] = -inv; }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) loss[0] = -a * inv;
+}
+template <typename T>
+__global__ void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = Elem<T>::to_f(y[i]);
+        dx[i] = Elem<T>::from_f(Elem<T>::to_f(dy[i]) * (1.f - t * t));
+    }
+}
+
+// ---- Adam -----------------------------------------------------------------------------------------------
+// torch.optim.Adam (no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float wd, const int64_t* step) {
+    const double t = (double)(step[0] + 1);
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+}
+__global__ void step_inc_kernel(int64_t* step) { step[0] += 1; }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    if (dtype == MCGEN_F32) { CALL_F32; } else if (dtype == MCGEN_BF16) { CALL_BF16; } \
+    else return mcgen_fail("unknown dtype %d", dtype)
+
+extern "C" int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream) {
+    MCGEN_CHECK(src && dst && Cp >= C && Cp % 8 == 0, "nchw_to_nhwc: bad arguments");
+    const size_t total = (size_t)N * H * W * Cp;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), src, (float*)dst, N, C, H * W, Cp),
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), src, (bf16_t*)dst, N, C, H * W, Cp));
+    MCGEN_LAUNCH_CHECK("nchw_to_nhwc"); return 0;
+}
+extern "C" int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream) {
+    MCGEN_CHECK(src && dst && Cp >= C, "nhwc_to_nchw: bad arguments");
+    const size_t total = (size_t)N * H * W * C;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)src, dst, N, C, H * W, Cp),
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)src, dst, N, C, H * W, Cp));
+    MCGEN_LAUNCH_CHECK("nhwc_to_nchw"); return 0;
+}
+
+extern "C" int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int transpose) {
+    const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
+    const int rows_w = round_up(rows, 16);
+    const int nchunk = (round_up(kdim, 8) + MCGEN_CK - 1) / MCGEN_CK;
+    return (int64_t)nchunk * ksize * ksize * rows_w * MCGEN_CK;
+}
+extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                                 int transpose, int row_perm, const float* sigma, float wscale, void* stream) {
+    MCGEN_CHECK(w && image && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "prep_weight: bad arguments");
+    MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "prep_weight: row_perm must divide Cout");
+    const size_t total = (size_t)mcgen_weight_image_elems(Cout, Cin, ksize, transpose);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale));
+    MCGEN_LAUNCH_CHECK("prep_weight"); return 0;
+}
+
+extern "C" int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream) {
+    MCGEN_CHECK(indicator && codebook && code && N > 0 && M > 0 && C > 0, "mc_code: bad arguments");
+    hipLaunchKernelGGL(mc_code_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, STREAM(stream), indicator, codebook, code, N, M, C);
+    MCGEN_LAUNCH_CHECK("mc_code"); return 0;
+}
+extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, void* stream) {
+    MCGEN_CHECK(x && code && y, "mc_apply: null pointer");
+    const size_t total = (size_t)N * HW * C;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(mc_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, code, (float*)y, N, HW, C),
+        hipLaunchKernelGGL(mc_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, code, (bf16_t*)y, N, HW, C));
+    MCGEN_LAUNCH_CHECK("mc_apply"); return 0;
+}
+
+extern "C" int mcgen_bn_finalize(const float* partials, int tiles, int pitch, int fold, int C, double count,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
+                "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
+}
+extern "C" int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                    float eps, int C, float* scale, float* shift, void* stream) {
+    MCGEN_CHECK(gamma && beta && running_mean && running_var && scale && shift, "bn_eval_affine: null pointer");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), gamma, beta, running_mean, running_var, eps, C, scale, shift);
+    MCGEN_LAUNCH_CHECK("bn_eval_affine"); return 0;
+}
+extern "C" int mcgen_bn_bwd_finalize(const float* partials, int tiles, int pitch, int C, float* dgamma, float* dbeta,
+                                     float* sums, int accumulate, void* stream) {
+    MCGEN_CHECK(partials && sums && tiles > 0 && pitch >= C, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, dgamma, dbeta, sums, accumulate);
+    MCGEN_LAUNCH_CHECK("bn_bwd_finalize"); return 0;
+}
+extern "C" int mcgen_bn_bwd_apply(const void* dz, const void* x, const void* add, void* dx, int dtype, int64_t pixels, int C,
+                                  const float* sums, double count, const float* scale, const float* mean, const float* rstd, void* stream) {
+    MCGEN_CHECK(dz && x && dx && sums && scale && mean && rstd && C % 8 == 0, "bn_bwd_apply: bad arguments");
+    const size_t total = (size_t)pixels * (C / 8);
+    const float inv = (float)(1.0 / count);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)dz, (const float*)x, (const float*)add, (float*)dx, (size_t)pixels, C, sums, inv, scale, mean, rstd),
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)dz, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)dx, (size_t)pixels, C, sums, inv, scale, mean, rstd));
+    MCGEN_LAUNCH_CHECK("bn_bwd_apply"); return 0;
+}
+
+extern "C" int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float* out, int row_perm, float alpha,
+                            int accumulate, float* workspace, void* stream) {
+    MCGEN_CHECK(x && out && workspace && rows > 0 && C > 0 && pitch >= C, "colsum: bad arguments (workspace must hold 256*C floats)");
+    const int blocks = rows < 256 ? (int)rows : 256;
+    const size_t rpb = ((size_t)rows + blocks - 1) / blocks;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(colsum_stage1<float>, dim3(blocks), dim3(256), 0, STREAM(stream), (const float*)x, (size_t)rows, C, pitch, workspace, rpb),
+        hipLaunchKernelGGL(colsum_stage1<bf16_t>, dim3(blocks), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (size_t)rows, C, pitch, workspace, rpb));
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), workspace, blocks, C, out, row_perm, alpha, accumulate);
+    MCGEN_LAUNCH_CHECK("colsum"); return 0;
+}
+
+extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                   int do_iter, float* sigma, void* stream) {
+    MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_power_iter: bad arguments");
+    // rows + cols <= 128 + 9*1024 floats at most for the supported models: 48 KiB of LDS is ample
+    hipLaunchKernelGGL(sn_power_iter_kernel, dim3(nlayers), dim3(512), 48 * 1024, STREAM(stream), w_base, uv_base, layers_dev, do_iter, sigma);
+    MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
+}
+extern "C" int mcgen_sn_grad_fix(float* g_base, const float* w_base, const float* uv_base, const mcgen_sn_layer_t* layers_dev,
+                                 int nlayers, const float* sigma, void* stream) {
+    MCGEN_CHECK(g_base && w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_grad_fix: bad arguments");
+    hipLaunchKernelGGL(sn_grad_fix_kernel, dim3(nlayers), dim3(512), 0, STREAM(stream), g_base, w_base, uv_base, layers_dev, sigma);
+    MCGEN_LAUNCH_CHECK("sn_grad_fix"); return 0;
+}
+
+extern "C" int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b, const float* sigma,
+                               float* pooled, float* logit, int N, int HW, int C, void* stream) {
+    MCGEN_CHECK(x && w && b && sigma && pooled && logit, "dtail_fwd: null pointer");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(dtail_fwd_kernel<float>, dim3(N), dim3(128), 0, STREAM(stream), (const float*)x, code, w, b, sigma, pooled, logit, HW, C),
+        hipLaunchKernelGGL(dtail_fwd_kernel<bf16_t>, dim3(N), dim3(128), 0, STREAM(stream), (const bf16_t*)x, code, w, b, sigma, pooled, logit, HW, C));
+    MCGEN_LAUNCH_CHECK("dtail_fwd"); return 0;
+}
+extern "C" int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, const float* code, const float* w, const float* sigma,
+                               const float* pooled, void* dx, float* dw, float* db, int N, int HW, int C, int accumulate, void* stream) {
+    MCGEN_CHECK(dlogit && x && w && sigma && pooled && dx, "dtail_bwd: null pointer");
+    const size_t total = (size_t)N * HW * C;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(dtail_bwd_dx_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), dlogit, (const float*)x, code, w, sigma, (float*)dx, N, HW, C),
+        hipLaunchKernelGGL(dtail_bwd_dx_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), dlogit, (const bf16_t*)x, code, w, sigma, (bf16_t*)dx, N, HW, C));
+    if (dw && db)
+        hipLaunchKernelGGL(dtail_bwd_w_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), dlogit, pooled, dw, db, N, C, accumulate);
+    MCGEN_LAUNCH_CHECK("dtail_bwd"); return 0;
+}
+
+extern "C" int mcgen_hinge_d(const float* real, const float* fake, int N, float* loss, float* dreal, float* dfake, void* stream) {
+    MCGEN_CHECK(real && fake && loss && dreal && dfake && N > 0, "hinge_d: bad arguments");
+    hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, STREAM(stream), real, fake, N, loss, dreal, dfake);
+    MCGEN_LAUNCH_CHECK("hinge_d"); return 0;
+}
+extern "C" int mcgen_hinge_g(const float* fake, int N, float* loss, float* dfake, void* stream) {
+    MCGEN_CHECK(fake && loss && dfake && N > 0, "hinge_g: bad arguments");
+    hipLaunchKernelGGL(hinge_g_kernel, dim3(1), dim3(256), 0, STREAM(stream), fake, N, loss, dfake);
+    MCGEN_LAUNCH_CHECK("hinge_g"); return 0;
+}
+extern "C" int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, void* stream) {
+    MCGEN_CHECK(dy && y && dx && n > 0, "tanh_bwd: bad arguments");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(tanh_bwd_kernel<float>, dim3(grid_for((size_t)n)), dim3(256), 0, STREAM(stream), (const float*)dy, (const float*)y, (float*)dx, (size_t)n),
+        hipLaunchKernelGGL(tanh_bwd_kernel<bf16_t>, dim3(grid_for((size_t)n)), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, (size_t)n));
+    MCGEN_LAUNCH_CHECK("tanh_bwd"); return 0;
+}
+
+extern "C" int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t* step, void* stream) {
+    MCGEN_CHECK(p && g && m && v && step && n > 0, "adam: bad arguments");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, STREAM(stream), step);
+    MCGEN_LAUNCH_CHECK("adam"); return 0;
+}

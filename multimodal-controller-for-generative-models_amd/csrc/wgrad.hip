@@ -1,0 +1,251 @@
+// Weight gradient of the fused convolution (gfx950 MFMA).
+//
+//   dW[co][tap][ci] = sum over pixels  dy[pixel][co] * prologue(x)[pixel + tap][ci]
+//
+// A workgroup owns 64 output channels x one 32-channel chunk of the input x all taps, and
+// walks pixel tiles of 128 (the K dimension), staging per tile the same prologue-applied
+// input window the forward kernel uses plus the dy tile.  Both MFMA operands are indexed
+// [k = pixel][row/col = channel] in LDS, i.e. k is the slow index: bf16 fragments are read
+// with ds_read_b64_tr_b16 (transposing read, 4 pixels x 16 channels per 16 lanes), fp32
+// fragments with scalar reads.  Pixel groups (blockIdx.z) write separate fp32 slabs in the
+// weight-image layout; mcgen_wgrad_reduce adds the slabs in a fixed order (deterministic).
+#include "conv_tile.h"
+
+namespace {
+
+constexpr int WG_BM = 128;     // pixels per K tile
+constexpr int WG_BCO = 64;     // output channels per workgroup
+constexpr int WG_NT = 256;
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<float> {
+    static constexpr int APITCH = MCGEN_CK * 4 + 16;     // rows stay 16-byte aligned for the staging stores
+    static constexpr int DPITCH = WG_BCO * 4 + 16;
+};
+template <> struct WgTraits<bf16_t> {
+    static constexpr int APITCH = MCGEN_CK * 2 + 16;     // 80 B: rows 8-byte aligned for the tr read
+    static constexpr int DPITCH = WG_BCO * 2 + 16;       // 144 B
+};
+
+// fragment of 8 k-values (pixels) for channel `col16 + lane&15`, rows given by byte offsets
+template <typename T> struct KFrag;
+template <> struct KFrag<float> {
+    // off8[j]: byte offset of pixel j's row; reads one float per pixel
+    static __device__ __forceinline__ f32x8 read(const char* base, const int (&off8)[8], int col_bytes) {
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const float*>(base + off8[j] + col_bytes);
+        return r;
+    }
+};
+
+static __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(WG_NT)
+void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
+    using E = Elem<T>;
+    using M = Mma<T>;
+    using TR = WgTraits<T>;
+    constexpr int ESZ = E::BYTES, APITCH = TR::APITCH, DPITCH = TR::DPITCH;
+    constexpr int NTAP = KS * KS;
+    constexpr int NI = (WG_BM * 9 + WG_NT - 1) / WG_NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsA = smem;
+    char* ldsD = smem + a_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int co0 = blockIdx.x * WG_BCO;
+    const int q = blockIdx.y;                       // input-channel chunk
+    const int c0 = q * MCGEN_CK;
+    const mcgen_seg_t sg = p.seg;
+    const int halo = KS >> 1;
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    const int Hd = p.dy_ups ? (H >> 1) : H, Wd = p.dy_ups ? (W >> 1) : W;
+
+    f32x4 acc[NTAP][2];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int tile = blockIdx.z; tile < m_tiles; tile += gridDim.z) {
+        const Geo g = make_geo(WG_BM, tile, H, W);
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, WG_NT, NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        __syncthreads();                                        // previous tile's reads are done
+        stager.stage(sg, c0, ldsA);
+        // dy tile: [pixel m][64 co]
+        for (int it = tid; it < WG_BM * (WG_BCO / 8); it += WG_NT) {
+            const int sub = it & 7, m = it >> 3;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            const int n = g.n0 + ti, h = g.h0 + r;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            const int co = co0 + sub * 8;
+            if (n < N && co < p.Cdy) {
+                const int hd = p.dy_ups ? (h >> 1) : h, wd = p.dy_ups ? (c >> 1) : c;
+                E::load8(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy + co, v);
+            }
+            E::store8(reinterpret_cast<T*>(ldsD + m * DPITCH + sub * 8 * ESZ), v);
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int ks = 0; ks < WG_BM / 32; ++ks) {
+            if constexpr (sizeof(T) == 4) {
+                // fp32: lane group lg covers pixels ks*32 + 8*lg + j, j = 0..7
+                int offA[8], offD[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int m = ks * 32 + lg * 8 + j;
+                    const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+                    const int r = rem >> g.lgW, c = rem & (W - 1);
+                    offA[j] = ((ti * PR + r) * PC + c) * APITCH;
+                    offD[j] = m * DPITCH;
+                }
+                const f32x8 dfrag = KFrag<float>::read(ldsD, offD, (wave * 16 + l15) * 4);
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) {
+                    const int tapoff = ((tap / KS) * PC + (tap % KS)) * APITCH;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const f32x8 afrag = KFrag<float>::read(ldsA + tapoff, offA, (f * 16 + l15) * 4);
+                        M::run(dfrag, afrag, acc[tap][f]);
+                    }
+                }
+            } else {
+                // bf16: two transposing reads per fragment; lane (q4 = l15>>2, p4 = l15&3) supplies the
+                // address of pixel 8*lg + 4*half + q4, channels 4*p4 .. 4*p4+3 of the 16-channel block
+                const int q4 = l15 >> 2, p4 = l15 & 3;
+                int offA2[2], offD2[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int m = ks * 32 + lg * 8 + hf * 4 + q4;
+                    const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+                    const int r = rem >> g.lgW, c = rem & (W - 1);
+                    offA2[hf] = ((ti * PR + r) * PC + c) * APITCH + p4 * 8;
+                    offD2[hf] = m * DPITCH + p4 * 8;
+                }
+                union { bf16x8 v; s16x4 h[2]; } dfrag;
+                dfrag.h[0] = lds_tr16(ldsD + offD2[0] + wave * 32);
+                dfrag.h[1] = lds_tr16(ldsD + offD2[1] + wave * 32);
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) {
+                    const int tapoff = ((tap / KS) * PC + (tap % KS)) * APITCH;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        union { bf16x8 v; s16x4 h[2]; } afrag;
+                        afrag.h[0] = lds_tr16(ldsA + tapoff + offA2[0] + f * 32);
+                        afrag.h[1] = lds_tr16(ldsA + tapoff + offA2[1] + f * 32);
+                        acc[tap][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag.v, afrag.v, acc[tap][f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15]
+    const size_t slab_elems = (size_t)gridDim.y * NTAP * p.Cout_w * MCGEN_CK;
+    float* out = p.slabs + (size_t)blockIdx.z * slab_elems + (size_t)q * NTAP * p.Cout_w * MCGEN_CK;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wave * 16 + lg * 4 + r;
+                if (co < p.Cout_w)
+                    out[((size_t)tap * p.Cout_w + co) * MCGEN_CK + f * 16 + l15] = acc[tap][f][r];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
+                                    float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
+                                    int row_perm, float alpha, int accumulate) {
+    const int ntap = KS * KS;
+    const size_t total = (size_t)Cout * Cin * ntap;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the master layout [co_master][ci][tap]
+        const int tap = (int)(i % ntap);
+        const int ci = (int)((i / ntap) % Cin);
+        const int com = (int)(i / ((size_t)ntap * Cin));
+        int co = com;
+        if (row_perm > 1) {                       // master row c*P + pos  <->  image row pos*Cc + c
+            const int Cc = Cout / row_perm;
+            co = (com % row_perm) * Cc + com / row_perm;
+        }
+        const int q = ci / MCGEN_CK, cl = ci % MCGEN_CK;
+        const size_t off = (((size_t)q * ntap + tap) * Cout_w + co) * MCGEN_CK + cl;
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_elems + off];
+        s *= alpha;
+        grad[i] = accumulate ? grad[i] + s : s;
+    }
+}
+
+static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
+
+template <typename T, int KS>
+static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
+    using TR = WgTraits<T>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int m_tiles = (int)((Mtot + WG_BM - 1) / WG_BM);
+    const int PP = mcgen_patch_pixels(WG_BM, p->H, p->W, KS);
+    const int a_bytes = round_up(PP * TR::APITCH, 32);
+    const int lds = a_bytes + WG_BM * TR::DPITCH;
+    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    auto kern = wgrad_kernel<T, KS>;
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        raised = true;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, *p, a_bytes, m_tiles);
+    MCGEN_LAUNCH_CHECK("wgrad");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p) {
+    if (!p) return 0;
+    return (int64_t)wgrad_chunks(p) * p->seg.ksize * p->seg.ksize * p->Cout_w * MCGEN_CK;
+}
+
+extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
+    MCGEN_CHECK(p && p->seg.x && p->dy && p->slabs, "wgrad: null pointer");
+    MCGEN_CHECK(p->N > 0 && ilog2_exact(p->H) >= 0 && ilog2_exact(p->W) >= 0 && p->W <= 64, "wgrad: H, W must be powers of two, W <= 64");
+    MCGEN_CHECK(WG_BM >= 2 * p->W || p->H * p->W <= WG_BM, "wgrad: W too large for the pixel tile");
+    MCGEN_CHECK(p->seg.C > 0 && p->seg.C % 8 == 0 && p->Cdy % 8 == 0, "wgrad: channel pitches must be multiples of 8");
+    MCGEN_CHECK(p->seg.ksize == 1 || p->seg.ksize == 3, "wgrad: ksize must be 1 or 3");
+    MCGEN_CHECK(p->Cout > 0 && p->Cout_w == round_up(p->Cout, 16) && p->Cdy >= p->Cout, "wgrad: bad Cout/Cout_w/Cdy");
+    MCGEN_CHECK(p->splits >= 1 && p->splits <= 65535, "wgrad: bad splits");
+    MCGEN_CHECK(!p->dy_ups || (p->H >= 2 && p->W >= 2), "wgrad: dy_ups needs H, W >= 2");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MCGEN_F32) return p->seg.ksize == 3 ? launch<float, 3>(p, st) : launch<float, 1>(p, st);
+    if (dtype == MCGEN_BF16) return p->seg.ksize == 3 ? launch<bf16_t, 3>(p, st) : launch<bf16_t, 1>(p, st);
+    return mcgen_fail("wgrad: unknown dtype %d", dtype);
+}
+
+extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
+                                  int Cout_w, int row_perm, float alpha, int accumulate, void* stream) {
+    MCGEN_CHECK(slabs && grad && splits >= 1, "wgrad_reduce: bad arguments");
+    MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
+    const int nchunk = (round_up(Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
+    const size_t total = (size_t)Cout * Cin * ksize * ksize;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate);
+    MCGEN_LAUNCH_CHECK("wgrad_reduce");
+    return 0;
+}

@@ -1,0 +1,333 @@
+"""Tensor-level wrappers over the C ABI (include/mcgen_hip.h).
+
+Activations are torch tensors of shape [N, H, W, Cp] (channels last, Cp a
+multiple of 8), dtype float32 or bfloat16, on a ROCm device.  All launches go
+to torch's current stream, so they compose with torch.cuda.graphs and streams.
+Nothing here has a CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+def _dt(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return _lib.F32
+    if dtype == torch.bfloat16:
+        return _lib.BF16
+    raise _lib.McgenError(f'unsupported compute dtype {dtype}')
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.McgenError('mcgen_amd has no CPU path: tensor is not on a ROCm device')
+    if not t.is_contiguous():
+        raise _lib.McgenError('mcgen_amd kernels need contiguous tensors')
+    return t.data_ptr()
+
+
+def _f32(t: Optional[Tensor]) -> Optional[int]:
+    if t is not None and t.dtype != torch.float32:
+        raise _lib.McgenError(f'expected float32, got {t.dtype}')
+    return _p(t)
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+@dataclass
+class Seg:
+    """One K-segment of a fused convolution (mcgen_seg_t)."""
+    x: Tensor                       # [N, H>>ups, W>>ups, C]
+    ksize: int = 3
+    scale: Optional[Tensor] = None  # BN affine
+    shift: Optional[Tensor] = None
+    code: Optional[Tensor] = None   # [N, C] MC code
+    ups: bool = False
+    relu: bool = False
+
+    def fill(self, s: _lib.Seg):
+        s.x = _p(self.x)
+        s.scale, s.shift, s.code = _f32(self.scale), _f32(self.shift), _f32(self.code)
+        s.C = self.x.shape[-1]
+        s.ups, s.relu, s.ksize = int(self.ups), int(self.relu), self.ksize
+        if self.code is not None and tuple(self.code.shape) != (self.x.shape[0], self.x.shape[-1]):
+            raise _lib.McgenError(f'code shape {tuple(self.code.shape)} does not match x {tuple(self.x.shape)}')
+
+
+# --------------------------------------------------------------------------- #
+def to_nhwc(x: Tensor, dtype: torch.dtype, cp: Optional[int] = None) -> Tensor:
+    """NCHW fp32 -> NHWC `dtype`, channels zero-padded to a multiple of 8."""
+    n, c, h, w = x.shape
+    cp = cp or pad8(c)
+    y = torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    check(_lib.load().mcgen_nchw_to_nhwc(_f32(x.contiguous()), _p(y), _dt(dtype), n, c, h, w, cp, _stream()), 'nchw_to_nhwc')
+    return y
+
+
+def to_nchw(x: Tensor, c: int) -> Tensor:
+    n, h, w, cp = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().mcgen_nhwc_to_nchw(_p(x), _f32(y), _dt(x.dtype), n, c, h, w, cp, _stream()), 'nhwc_to_nchw')
+    return y
+
+
+def mc_code(indicator: Tensor, codebook: Tensor, cp: Optional[int] = None) -> Tensor:
+    """code = indicator @ codebook  (modules.py:73), zero-padded to `cp` columns."""
+    n, m = indicator.shape
+    c = codebook.shape[1]
+    code = torch.empty((n, c), dtype=torch.float32, device=indicator.device)
+    check(_lib.load().mcgen_mc_code(_f32(indicator.contiguous()), _f32(codebook.contiguous()), _f32(code), n, m, c, _stream()), 'mc_code')
+    if cp is not None and cp != c:
+        code = torch.nn.functional.pad(code, (0, cp - c))
+    return code
+
+
+def mc_apply(x: Tensor, code: Tensor) -> Tensor:
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    check(_lib.load().mcgen_mc_apply(_p(x), _f32(code), _p(y), _dt(x.dtype), n, hw, c, _stream()), 'mc_apply')
+    return y
+
+
+def weight_image_elems(cout: int, cin: int, ksize: int, transpose: bool = False) -> int:
+    return int(_lib.load().mcgen_weight_image_elems(cout, cin, ksize, int(transpose)))
+
+
+def prep_weight(w: Tensor, dtype: torch.dtype, transpose: bool = False, row_perm: int = 1,
+                sigma: Optional[Tensor] = None, wscale: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """Master weights [Cout, Cin, k, k] (or [Cout, Cin]) -> kernel weight image."""
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2] if w.dim() == 4 else 1
+    n = weight_image_elems(cout, cin, ks, transpose)
+    if out is None:
+        out = torch.empty(n, dtype=dtype, device=w.device)
+    assert out.numel() == n and out.dtype == dtype
+    check(_lib.load().mcgen_prep_weight(_f32(w), _p(out), _dt(dtype), cout, cin, ks, int(transpose), row_perm,
+                                        _f32(sigma), float(wscale), _stream()), 'prep_weight')
+    return out
+
+
+def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[Tensor] = None,
+               pool: bool = False, alpha: float = 1.0, res: Optional[Tensor] = None,
+               ocode: Optional[Tensor] = None, gate_x: Optional[Tensor] = None,
+               gscale: Optional[Tensor] = None, gshift: Optional[Tensor] = None,
+               gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
+               tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
+               out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None)."""
+    s0 = segs[0]
+    n = s0.x.shape[0]
+    h = s0.x.shape[1] * (2 if s0.ups else 1)
+    w = s0.x.shape[2] * (2 if s0.ups else 1)
+    dtype = s0.x.dtype
+    cy = cy or pad8(cout)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    p = _lib.Conv()
+    p.nseg = len(segs)
+    for i, s in enumerate(segs):
+        if s.x.dtype != dtype:
+            raise _lib.McgenError('all segments must share the compute dtype')
+        hs = s.x.shape[1] * (2 if s.ups else 1)
+        if hs != h or s.x.shape[0] != n:
+            raise _lib.McgenError('segments disagree on the convolution resolution')
+        s.fill(p.seg[i])
+    if wimg.dtype != dtype:
+        raise _lib.McgenError(f'weight image dtype {wimg.dtype} != activation dtype {dtype}')
+    need = sum(((s.x.shape[-1] + 31) // 32) * s.ksize * s.ksize for s in segs) * pad16(cout) * 32
+    if wimg.numel() != need:
+        raise _lib.McgenError(f'weight image has {wimg.numel()} elements, the segments need {need}')
+    y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=dtype, device=s0.x.device)
+    assert tuple(y.shape) == (n, ho, wo, cy) and y.dtype == dtype
+    p.w, p.bias, p.y = _p(wimg), _f32(bias), _p(y)
+    p.N, p.H, p.W = n, h, w
+    p.Cout, p.Cout_w, p.Cy = cout, pad16(cout), cy
+    p.pool, p.alpha = int(pool), float(alpha)
+    for name, t in (('res', res), ('gate_x', gate_x)):
+        if t is not None and (tuple(t.shape) != (n, ho, wo, cy) or t.dtype != dtype):
+            raise _lib.McgenError(f'{name} must be {(n, ho, wo, cy)} {dtype}, got {tuple(t.shape)} {t.dtype}')
+    if ocode is not None and tuple(ocode.shape) != (n, cout):
+        raise _lib.McgenError(f'ocode must be {(n, cout)}')
+    p.res, p.ocode, p.gate_x = _p(res), _f32(ocode), _p(gate_x)
+    p.gscale, p.gshift, p.gmean, p.grstd = _f32(gscale), _f32(gshift), _f32(gmean), _f32(grstd)
+    p.tanh_out, p.stats_mode = int(tanh), stats_mode
+    stats = None
+    lib = _lib.load()
+    if stats_mode:
+        tiles = lib.mcgen_conv_m_tiles(C.byref(p), _dt(dtype))
+        stats = torch.empty((tiles, 2, cy), dtype=torch.float32, device=y.device)
+        p.stats = _p(stats)
+    check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused')
+    return y, stats
+
+
+def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bool = False,
+          alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None):
+    """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment."""
+    n = seg.x.shape[0]
+    h = seg.x.shape[1] * (2 if seg.ups else 1)
+    w = seg.x.shape[2] * (2 if seg.ups else 1)
+    dtype = seg.x.dtype
+    p = _lib.Wgrad()
+    seg.fill(p.seg)
+    p.dy = _p(dy)
+    p.N, p.H, p.W = n, h, w
+    p.Cout, p.Cout_w, p.Cdy = cout, pad16(cout), dy.shape[-1]
+    p.dy_ups = int(dy_ups)
+    exp = (n, h // 2, w // 2) if dy_ups else (n, h, w)
+    if tuple(dy.shape[:3]) != exp or dy.dtype != dtype:
+        raise _lib.McgenError(f'dy must be {exp}+[C] {dtype}, got {tuple(dy.shape)} {dy.dtype}')
+    m_tiles = (n * h * w + 127) // 128
+    nchunk = (seg.x.shape[-1] + 31) // 32
+    if splits is None:
+        blocks = ((pad16(cout) + 63) // 64) * nchunk
+        splits = max(1, min(m_tiles, (1024 + blocks - 1) // blocks))
+    p.splits = splits
+    lib = _lib.load()
+    elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
+    slabs = torch.empty((splits, elems), dtype=torch.float32, device=dy.device)
+    p.slabs = _p(slabs)
+    check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad')
+    if grad.numel() != cout * cin * seg.ksize * seg.ksize:
+        raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
+    check(lib.mcgen_wgrad_reduce(_p(slabs), splits, _f32(grad), cout, cin, seg.ksize, pad16(cout), row_perm,
+                                 float(alpha), int(accumulate), _stream()), 'wgrad_reduce')
+
+
+def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
+                running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                momentum: float = 0.1, eps: float = 1e-5, fold: int = 1):
+    """-> (scale, shift, mean, rstd), each [C]; running stats updated in place."""
+    tiles, _, pitch = partials.shape
+    c = gamma.numel()
+    out = torch.empty((4, c), dtype=torch.float32, device=partials.device)
+    check(_lib.load().mcgen_bn_finalize(_f32(partials), tiles, pitch, fold, c, float(count), _f32(gamma), _f32(beta),
+                                        _f32(running_mean), _f32(running_var), momentum, eps,
+                                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                        _stream()), 'bn_finalize')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float = 1e-5):
+    c = gamma.numel()
+    out = torch.empty((2, c), dtype=torch.float32, device=gamma.device)
+    check(_lib.load().mcgen_bn_eval_affine(_f32(gamma), _f32(beta), _f32(running_mean), _f32(running_var), eps, c,
+                                           out[0].data_ptr(), out[1].data_ptr(), _stream()), 'bn_eval_affine')
+    return out[0], out[1]
+
+
+def bn_backward(partials: Tensor, dz: Tensor, x: Tensor, count: int, scale, mean, rstd,
+                dgamma: Optional[Tensor], dbeta: Optional[Tensor], add: Optional[Tensor] = None,
+                accumulate: bool = False) -> Tensor:
+    """BN backward from the conv epilogue's (sum dz, sum dz*xhat) partials."""
+    tiles, _, pitch = partials.shape
+    c = scale.numel()
+    sums = torch.empty((2, c), dtype=torch.float32, device=dz.device)
+    lib = _lib.load()
+    check(lib.mcgen_bn_bwd_finalize(_f32(partials), tiles, pitch, c, _f32(dgamma), _f32(dbeta), _f32(sums),
+                                    int(accumulate), _stream()), 'bn_bwd_finalize')
+    dx = torch.empty_like(dz)
+    assert dz.shape[-1] == c and x.shape == dz.shape
+    check(lib.mcgen_bn_bwd_apply(_p(dz), _p(x), _p(add), _p(dx), _dt(dz.dtype), dz.numel() // c, c, _f32(sums),
+                                 float(count), _f32(scale), _f32(mean), _f32(rstd), _stream()), 'bn_bwd_apply')
+    return dx
+
+
+_colsum_ws = {}
+
+
+def colsum(x: Tensor, c: int, out: Tensor, alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1):
+    """out[c] (+)= alpha * sum over all leading dims of x[..., :c]."""
+    pitch = x.shape[-1]
+    rows = x.numel() // pitch
+    ws = torch.empty(256 * c, dtype=torch.float32, device=x.device)
+    check(_lib.load().mcgen_colsum(_p(x), _dt(x.dtype), rows, c, pitch, _f32(out), row_perm, float(alpha),
+                                   int(accumulate), _f32(ws), _stream()), 'colsum')
+
+
+def tanh_bwd(dy: Tensor, y: Tensor) -> Tensor:
+    dx = torch.empty_like(dy)
+    check(_lib.load().mcgen_tanh_bwd(_p(dy), _p(y), _p(dx), _dt(dy.dtype), dy.numel(), _stream()), 'tanh_bwd')
+    return dx
+
+
+def dtail_fwd(x: Tensor, code: Optional[Tensor], w: Tensor, b: Tensor, sigma: Tensor):
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    pooled = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    logit = torch.empty((n,), dtype=torch.float32, device=x.device)
+    check(_lib.load().mcgen_dtail_fwd(_p(x), _dt(x.dtype), _f32(code), _f32(w), _f32(b), _f32(sigma), _f32(pooled),
+                                      _f32(logit), n, hw, c, _stream()), 'dtail_fwd')
+    return logit, pooled
+
+
+def dtail_bwd(dlogit: Tensor, x: Tensor, code, w, sigma, pooled, dw: Optional[Tensor], db: Optional[Tensor],
+              accumulate: bool = False) -> Tensor:
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    check(_lib.load().mcgen_dtail_bwd(_f32(dlogit), _p(x), _dt(x.dtype), _f32(code), _f32(w), _f32(sigma), _f32(pooled),
+                                      _p(dx), _f32(dw), _f32(db), n, hw, c, int(accumulate), _stream()), 'dtail_bwd')
+    return dx
+
+
+def hinge_d(real: Tensor, fake: Tensor):
+    n = real.numel()
+    out = torch.empty(1 + 2 * n, dtype=torch.float32, device=real.device)
+    check(_lib.load().mcgen_hinge_d(_f32(real), _f32(fake), n, out.data_ptr(), out[1:1 + n].data_ptr(),
+                                    out[1 + n:].data_ptr(), _stream()), 'hinge_d')
+    return out[0], out[1:1 + n], out[1 + n:]
+
+
+def hinge_g(fake: Tensor):
+    n = fake.numel()
+    out = torch.empty(1 + n, dtype=torch.float32, device=fake.device)
+    check(_lib.load().mcgen_hinge_g(_f32(fake), n, out.data_ptr(), out[1:].data_ptr(), _stream()), 'hinge_g')
+    return out[0], out[1:]
+
+
+def sn_layers_tensor(layers, device) -> Tensor:
+    """Pack [(w_off, u_off, v_off, rows, cols)] into a device byte tensor of mcgen_sn_layer_t."""
+    arr = (_lib.SnLayer * len(layers))()
+    for i, (wo, uo, vo, r, c) in enumerate(layers):
+        arr[i].w_off, arr[i].u_off, arr[i].v_off, arr[i].rows, arr[i].cols = wo, uo, vo, r, c
+    raw = bytes(arr)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, do_iter: bool, sigma: Tensor):
+    check(_lib.load().mcgen_sn_power_iter(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, int(do_iter),
+                                          _f32(sigma), _stream()), 'sn_power_iter')
+
+
+def sn_grad_fix(g_base: Tensor, w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, sigma: Tensor):
+    check(_lib.load().mcgen_sn_grad_fix(_f32(g_base), _f32(w_base), _f32(uv_base), _p(layers_dev), nlayers,
+                                        _f32(sigma), _stream()), 'sn_grad_fix')
+
+
+def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),
+         eps: float = 1e-8, weight_decay: float = 0.0):
+    assert step.dtype == torch.int64
+    check(_lib.load().mcgen_adam(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, betas[0], betas[1], eps,
+                                 weight_decay, _p(step), _stream()), 'adam')

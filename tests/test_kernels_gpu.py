@@ -1,0 +1,403 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain
+PyTorch fp32 CPU restatements of the same op chains.
+
+fp32 instantiation: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), compared at
+rtol 2e-5 / atol 2e-5 * scale (summation order differs from oneDNN).
+bf16 instantiation: inputs/weights rounded to bf16, fp32 accumulate; compared
+against the fp32 reference at 3e-2 of the output's max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from mcgen_amd import ops
+    return ops
+
+
+def _tol(dtype, ref):
+    scale = float(ref.abs().max()) + 1e-6
+    return (2e-5 * scale + 1e-6, 2e-5) if dtype == torch.float32 else (3e-2 * scale, 3e-2)
+
+
+def _assert_close(got, ref, dtype, what=''):
+    atol, rtol = _tol(dtype, ref)
+    got = got.float().cpu()
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), f'{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.3e} (atol {atol:.2e})'
+
+
+def _rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+def _nhwc(ops, x, dtype):
+    return ops.to_nhwc(x.cuda(), dtype)
+
+
+def _q(x, dtype):
+    """round-trip through the compute dtype (what the kernel will actually read)"""
+    return x.to(dtype).float()
+
+
+def ref_prologue(x, scale, shift, relu, code, ups):
+    if ups:
+        x = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    if scale is not None:
+        x = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if relu:
+        x = torch.relu(x)
+    if code is not None:
+        x = x * code.view(*code.shape, 1, 1)
+    return x
+
+
+CASES = [
+    # N, H, W, Cin, Cout, ksize
+    (3, 8, 8, 16, 24, 3),
+    (2, 32, 32, 40, 130, 3),
+    (5, 4, 4, 8, 3, 3),
+    (6, 16, 16, 32, 64, 1),
+    (2, 32, 32, 128, 128, 3),
+    (9, 4, 4, 64, 48, 3),
+    (5, 1, 1, 128, 64, 1),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CASES)
+def test_conv_plain(case, dtype):
+    ops = _ops()
+    n, h, w, ci, co, ks = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x, wt, b = _rnd(g, n, ci, h, w), _rnd(g, co, ci, ks, ks) * 0.1, _rnd(g, co)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), b, padding=ks // 2)
+    wimg = ops.prep_weight(wt.cuda(), dtype)
+    y, _ = ops.conv_fused([ops.Seg(_nhwc(ops, x, dtype), ksize=ks)], wimg, co, bias=b.cuda())
+    _assert_close(ops.to_nchw(y, co), ref, dtype, 'conv')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('ups', [False, True])
+def test_conv_prologue_stats(dtype, ups):
+    """BN-apply + ReLU + (upsample) + MC code prologue, bias, stats epilogue (G.conv_a, mcgan.py:15-19)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    n, hs, ci, co = 6, 8, 32, 40
+    x = _rnd(g, n, ci, hs, hs)
+    scale, shift = _rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3
+    code = (torch.rand(n, ci, generator=g) < 0.5).float()
+    wt, b = _rnd(g, co, ci, 3, 3) * 0.1, _rnd(g, co)
+    a = ref_prologue(_q(x, dtype), scale, shift, True, code, ups)
+    ref = F.conv2d(_q(a, dtype) if dtype != torch.float32 else a, _q(wt, dtype), b, padding=1)
+    seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=ups, relu=True)
+    y, st = ops.conv_fused([seg], ops.prep_weight(wt.cuda(), dtype), co, bias=b.cuda(), stats_mode=1)
+    _assert_close(ops.to_nchw(y, co), ref, dtype, 'conv_a')
+    s = st.sum(0).cpu()                         # [2, Cy]
+    yq = ops.to_nchw(y, co).cpu()
+    # the kernel sums the fp32 accumulators, yq is the stored (rounded) output
+    tol = dict(rtol=2e-3, atol=2e-2) if dtype == torch.float32 else dict(rtol=2e-2, atol=4.0)
+    np.testing.assert_allclose(s[0, :co], yq.sum((0, 2, 3)), **tol)
+    np.testing.assert_allclose(s[1, :co], (yq * yq).sum((0, 2, 3)), **tol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_two_segments(dtype):
+    """G.conv_b: 3x3 over BN/ReLU/MC'd h  (+)  1x1 shortcut over Up(x)*mc_1  (mcgan.py:20-30,42)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n, hs, c = 4, 8, 32
+    h_in, x = _rnd(g, n, c, 2 * hs, 2 * hs), _rnd(g, n, c, hs, hs)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code1 = (torch.rand(n, c, generator=g) < 0.5).float()
+    code2 = (torch.rand(n, c, generator=g) < 0.5).float()
+    w2, ws, b = _rnd(g, c, c, 3, 3) * 0.1, _rnd(g, c, c, 1, 1) * 0.2, _rnd(g, c)
+    a2 = ref_prologue(_q(h_in, dtype), scale, shift, True, code2, False)
+    a1 = ref_prologue(_q(x, dtype), None, None, False, code1, True)
+    if dtype != torch.float32:
+        a2, a1 = _q(a2, dtype), _q(a1, dtype)
+    ref = F.conv2d(a2, _q(w2, dtype), b, padding=1) + F.conv2d(a1, _q(ws, dtype))
+    img = torch.cat([ops.prep_weight(w2.cuda(), dtype), ops.prep_weight(ws.cuda(), dtype)])
+    segs = [ops.Seg(_nhwc(ops, h_in, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code2.cuda(), relu=True),
+            ops.Seg(_nhwc(ops, x, dtype), ksize=1, code=code1.cuda(), ups=True)]
+    y, _ = ops.conv_fused(segs, img, c, bias=b.cuda())
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'conv_b')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [32, 16, 8, 4])
+def test_conv_pool_residual(dtype, hw):
+    """D.conv_b: ReLU->MC->conv3x3->AvgPool2 + residual (mcgan.py:105-115)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    n, c = 3, 16
+    x, res = _rnd(g, n, c, hw, hw), _rnd(g, n, c, hw // 2, hw // 2)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    wt, b = _rnd(g, c, c, 3, 3) * 0.1, _rnd(g, c)
+    a = ref_prologue(_q(x, dtype), None, None, True, code, False)
+    ref = F.avg_pool2d(F.conv2d(a, _q(wt, dtype), None, padding=1), 2) + b.view(1, -1, 1, 1) + _q(res, dtype)
+    y, _ = ops.conv_fused([ops.Seg(_nhwc(ops, x, dtype), code=code.cuda(), relu=True)], ops.prep_weight(wt.cuda(), dtype), c,
+                          bias=b.cuda(), pool=True, alpha=0.25, res=_nhwc(ops, res, dtype))
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'pool+res')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_dgrad_gate_bnstats(dtype):
+    """Input-gradient form: transposed weights, pooled (upsample-adjoint) output, MC code on the
+    output channels, ReLU-after-BN gate and the two BatchNorm-backward partial sums."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    n, hs, ci, co = 4, 8, 24, 32                 # forward conv: ci -> co at resolution 2*hs
+    dy = _rnd(g, n, co, 2 * hs, 2 * hs)
+    wt = _rnd(g, co, ci, 3, 3) * 0.1
+    xlow = _rnd(g, n, ci, hs, hs)                # the BN input at low resolution
+    mean, rstd = _rnd(g, ci) * 0.2, torch.rand(ci, generator=g) + 0.5
+    gamma, beta = _rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3
+    gscale, gshift = gamma * rstd, beta - mean * gamma * rstd
+    code = (torch.rand(n, ci, generator=g) < 0.5).float()
+    dm = F.conv_transpose2d(_q(dy, dtype), _q(wt, dtype), padding=1)              # [n, ci, 2hs, 2hs]
+    du = dm * code.view(n, ci, 1, 1)
+    da = F.avg_pool2d(du, 2) * 4
+    xq = _q(xlow, dtype)
+    z = xq * gscale.view(1, -1, 1, 1) + gshift.view(1, -1, 1, 1)
+    dz = da * (z > 0)
+    xhat = (xq - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    wimg_t = ops.prep_weight(wt.cuda(), dtype, transpose=True)
+    y, st = ops.conv_fused([ops.Seg(_nhwc(ops, dy, dtype))], wimg_t, ci, pool=True, alpha=1.0,
+                           ocode=code.cuda(), gate_x=_nhwc(ops, xlow, dtype), gscale=gscale.cuda(), gshift=gshift.cuda(),
+                           gmean=mean.cuda(), grstd=rstd.cuda(), stats_mode=2)
+    _assert_close(ops.to_nchw(y, ci), dz, dtype, 'dz')
+    s = st.sum(0).cpu()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=0.5)
+    np.testing.assert_allclose(s[0, :ci], dz.sum((0, 2, 3)), **tol)
+    np.testing.assert_allclose(s[1, :ci], (dz * xhat).sum((0, 2, 3)), **tol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_tanh_small_cout(dtype):
+    """G head: BN->ReLU->MC->conv3x3(C->3)->tanh (mcgan.py:55-60)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(19)
+    n, c = 4, 32
+    x = _rnd(g, n, c, 32, 32)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    wt, b = _rnd(g, 3, c, 3, 3) * 0.1, _rnd(g, 3) * 0.1
+    a = ref_prologue(_q(x, dtype), scale, shift, True, code, False)
+    if dtype != torch.float32:
+        a = _q(a, dtype)
+    ref = torch.tanh(F.conv2d(a, _q(wt, dtype), b, padding=1))
+    y, _ = ops.conv_fused([ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), relu=True)],
+                          ops.prep_weight(wt.cuda(), dtype), 3, bias=b.cuda(), tanh=True)
+    assert y.shape[-1] == 8
+    assert float(y[..., 3:].float().abs().max()) == 0.0          # padded channels stay exactly zero
+    _assert_close(ops.to_nchw(y, 3), ref, dtype, 'head')
+
+
+WG_CASES = [
+    # N, H, Cin, Cout, ksize, ups(x), dy_ups
+    (3, 8, 16, 24, 3, False, False),
+    (2, 32, 40, 72, 3, False, False),
+    (4, 16, 32, 32, 3, True, False),
+    (4, 16, 32, 48, 1, True, False),
+    (4, 16, 16, 16, 3, False, True),
+    (7, 4, 24, 16, 3, False, False),
+    (2, 32, 8, 32, 3, False, False),
+    (16, 1, 128, 64, 1, False, False),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', WG_CASES)
+def test_wgrad(case, dtype):
+    ops = _ops()
+    n, h, ci, co, ks, ups, dy_ups = case
+    g = torch.Generator().manual_seed(23 + h + ci)
+    hs = h // 2 if ups else h
+    x = _rnd(g, n, ci, hs, hs)
+    scale, shift = _rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3
+    code = (torch.rand(n, ci, generator=g) < 0.5).float()
+    dy = _rnd(g, n, co, h // 2 if dy_ups else h, h // 2 if dy_ups else h)
+    a = ref_prologue(_q(x, dtype), scale, shift, True, code, ups)
+    if dtype != torch.float32:
+        a = _q(a, dtype)
+    dyf = _q(dy, dtype)
+    if dy_ups:
+        dyf = dyf.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    wt = torch.zeros(co, ci, ks, ks, requires_grad=True)
+    (F.conv2d(a, wt, padding=ks // 2) * dyf).sum().backward()
+    ref = wt.grad * 0.25
+    grad = torch.full((co, ci, ks, ks), 1.0, device='cuda')
+    seg = ops.Seg(_nhwc(ops, x, dtype), ksize=ks, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=ups, relu=True)
+    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, alpha=0.25, accumulate=True)
+    _assert_close(grad - 1.0, ref, dtype, 'wgrad')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_linear_as_conv_rowperm(dtype):
+    """Generator Linear(128 -> C*16) viewed [N, C, 4, 4] (mcgan.py:51,66-67) as a 1x1 conv whose
+    output rows are permuted so the NHWC result is [N, 4, 4, C]; and its weight/bias gradients."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(29)
+    n, lat, c = 6, 128, 16
+    z, wt, b = _rnd(g, n, lat), _rnd(g, c * 16, lat) * 0.1, _rnd(g, c * 16)
+    ref = F.linear(_q(z, dtype), _q(wt, dtype), b).view(n, c, 4, 4)
+    zt = z.cuda().to(dtype).view(n, 1, 1, lat).contiguous()
+    wimg = ops.prep_weight(wt.cuda(), dtype, row_perm=16)
+    bperm = b.view(c, 16).t().contiguous().view(-1).cuda()
+    y, st = ops.conv_fused([ops.Seg(zt, ksize=1)], wimg, c * 16, bias=bperm, stats_mode=1)
+    x0 = y.view(n, 4, 4, c)
+    _assert_close(ops.to_nchw(x0, c), ref, dtype, 'linear')
+    dy = _rnd(g, n, c, 4, 4)
+    dyt = ops.to_nhwc(dy.cuda(), dtype).view(n, 1, 1, c * 16)
+    gw = torch.zeros(c * 16, lat, device='cuda')
+    ops.wgrad(ops.Seg(zt, ksize=1), dyt, c * 16, lat, gw, row_perm=16)
+    refw = _q(dy, dtype).reshape(n, -1).t() @ _q(z, dtype)
+    _assert_close(gw, refw, dtype, 'linear wgrad')
+    gb = torch.zeros(c * 16, device='cuda')
+    ops.colsum(dyt, c * 16, gb, row_perm=16)
+    _assert_close(gb, _q(dy, dtype).reshape(n, -1).sum(0), dtype, 'linear bias grad')
+
+
+def test_mc_code_and_apply():
+    import golden_util as gu
+    ops = _ops()
+    d = gu.load_npz('mc_unit.npz')
+    cb = torch.from_numpy(d['codebook']).cuda()
+    ind = F.one_hot(torch.from_numpy(d['label']), 10).float().cuda()
+    code = ops.mc_code(ind, cb)
+    assert torch.equal(code.cpu(), torch.from_numpy(d['codebook'])[torch.from_numpy(d['label'])])
+    x = ops.to_nhwc(torch.from_numpy(d['x4']).cuda(), torch.float32)
+    out = ops.to_nchw(ops.mc_apply(x, code), 32)
+    assert np.array_equal(out.cpu().numpy(), d['out4'])                    # bit exact (one multiply)
+    soft = ops.mc_code(torch.from_numpy(d['soft']).cuda(), cb)
+    np.testing.assert_allclose(ops.to_nchw(ops.mc_apply(x, soft), 32).cpu().numpy(), d['out_soft'], rtol=1e-6, atol=1e-6)
+
+
+def test_bn_finalize_and_backward():
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    n, c, h = 8, 16, 8
+    x = (_rnd(g, n, c, h, h) * 2 + 0.5).requires_grad_(True)
+    gamma, beta = (_rnd(g, c) * 0.2 + 1).requires_grad_(True), (_rnd(g, c) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    dzr = _rnd(g, n, c, h, h)
+    y.backward(dzr)
+    xt = ops.to_nhwc(x.detach().cuda(), torch.float32)
+    xf = xt.view(-1, c)
+    part = torch.stack([xf.sum(0), (xf * xf).sum(0)]).view(1, 2, c).contiguous()
+    rmg, rvg = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    scale, shift, mean, rstd = ops.bn_finalize(part, n * h * h, gamma.detach().cuda(), beta.detach().cuda(), rmg, rvg)
+    np.testing.assert_allclose(rmg.cpu(), rm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvg.cpu(), rv, rtol=1e-5, atol=1e-6)
+    yk = xt * scale + shift
+    np.testing.assert_allclose(ops.to_nchw(yk, c).cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    dz = ops.to_nhwc(dzr.cuda(), torch.float32)
+    xhat = (xt - mean) * rstd
+    bpart = torch.stack([dz.view(-1, c).sum(0), (dz * xhat).view(-1, c).sum(0)]).view(1, 2, c).contiguous()
+    dg, db = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    dx = ops.bn_backward(bpart, dz, xt, n * h * h, scale, mean, rstd, dg, db)
+    np.testing.assert_allclose(ops.to_nchw(dx, c).cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dg.cpu(), gamma.grad, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu(), beta.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_spectral_norm_kernels():
+    """mcgen_sn_power_iter / mcgen_sn_grad_fix vs torch.nn.utils.spectral_norm on CPU."""
+    ops = _ops()
+    torch.manual_seed(5)
+    convs = [torch.nn.Conv2d(3, 16, 3), torch.nn.Conv2d(16, 16, 3), torch.nn.Linear(16, 1), torch.nn.Conv2d(16, 24, 1)]
+    sn = [torch.nn.utils.spectral_norm(m) for m in convs]
+    flat_w, flat_uv, layers = [], [], []
+    wo = uo = 0
+    for m in sn:
+        w = m.weight_orig.detach()
+        rows, cols = w.shape[0], w[0].numel()
+        layers.append((wo, uo, uo + rows, rows, cols))
+        flat_w.append(w.reshape(-1)); flat_uv += [m.weight_u.detach().clone(), m.weight_v.detach().clone()]
+        wo += w.numel(); uo += rows + cols
+    W = torch.cat(flat_w).cuda(); UV = torch.cat(flat_uv).cuda()
+    ld = ops.sn_layers_tensor(layers, 'cuda')
+    sigma = torch.zeros(len(sn), device='cuda')
+    for m in sn:
+        m.train()
+    # one training forward on CPU advances u, v and defines weight = W / sigma
+    xs = [torch.randn(2, 3, 8, 8), torch.randn(2, 16, 8, 8), torch.randn(2, 16), torch.randn(2, 16, 4, 4)]
+    outs = [m(x) for m, x in zip(sn, xs)]
+    ops.sn_power_iter(W, UV, ld, len(sn), True, sigma)
+    for i, m in enumerate(sn):
+        wo_, uo_, vo_, r, c = layers[i]
+        np.testing.assert_allclose(UV[uo_:uo_ + r].cpu(), m.weight_u.detach(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(UV[vo_:vo_ + c].cpu(), m.weight_v.detach(), rtol=1e-4, atol=1e-6)
+        ref_sigma = (m.weight_orig.detach().reshape(r, c) / m.weight.detach().reshape(r, c)).flatten()
+        ref_sigma = ref_sigma[torch.isfinite(ref_sigma)].median()
+        np.testing.assert_allclose(float(sigma[i]), float(ref_sigma), rtol=1e-4)
+    # gradient through W / sigma
+    gs = [torch.randn_like(m.weight) for m in sn]
+    for m, o, x, gw in zip(sn, outs, xs, gs):
+        m.zero_grad()
+        (m.weight * gw).sum().backward()
+    G = torch.cat([g.reshape(-1) for g in gs]).cuda()
+    ops.sn_grad_fix(G, W, UV, ld, len(sn), sigma)
+    off = 0
+    for m in sn:
+        k = m.weight_orig.numel()
+        np.testing.assert_allclose(G[off:off + k].cpu(), m.weight_orig.grad.reshape(-1), rtol=2e-4, atol=2e-5)
+        off += k
+    # eval mode: no iteration, same sigma formula
+    sig2 = torch.zeros_like(sigma)
+    UV2 = UV.clone()
+    ops.sn_power_iter(W, UV2, ld, len(sn), False, sig2)
+    assert torch.equal(UV, UV2)
+    np.testing.assert_allclose(sig2.cpu(), sigma.cpu(), rtol=1e-4)
+
+
+def test_dtail_hinge_tanh_adam():
+    ops = _ops()
+    g = torch.Generator().manual_seed(37)
+    n, c, h = 6, 16, 4
+    x = _rnd(g, n, c, h, h).requires_grad_(True)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    w, b = _rnd(g, 1, c).requires_grad_(True), _rnd(g, 1).requires_grad_(True)
+    sigma = torch.tensor([1.7])
+    pooled_ref = (torch.relu(x) * code.view(n, c, 1, 1)).sum((2, 3))
+    logit_ref = F.linear(pooled_ref, w / sigma, b).view(-1)
+    fake_ref = (logit_ref * 0.5 - 1.2).detach()
+    loss_ref = torch.relu(1 - logit_ref).mean() + torch.relu(1 + fake_ref).mean()
+    loss_ref.backward()
+    xt = ops.to_nhwc(x.detach().cuda(), torch.float32)
+    sg = sigma.cuda()
+    logit, pooled = ops.dtail_fwd(xt, code.cuda(), w.detach().view(-1).cuda(), b.detach().cuda(), sg)
+    np.testing.assert_allclose(logit.cpu(), logit_ref.detach(), rtol=1e-5, atol=1e-5)
+    loss, dreal, dfake = ops.hinge_d(logit, fake_ref.cuda())
+    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=1e-6)
+    dw, db = torch.zeros(c, device='cuda'), torch.zeros(1, device='cuda')
+    dx = ops.dtail_bwd(dreal, xt, code.cuda(), w.detach().view(-1).cuda(), sg, pooled, dw, db)
+    np.testing.assert_allclose(ops.to_nchw(dx, c).cpu(), x.grad, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dw.cpu() / 1.7, w.grad.view(-1), rtol=1e-5, atol=1e-6)   # dw is wrt W/sigma
+    np.testing.assert_allclose(db.cpu(), b.grad, rtol=1e-5, atol=1e-6)
+    lg, dfg = ops.hinge_g(logit)
+    np.testing.assert_allclose(float(lg), float(-logit_ref.mean()), rtol=1e-6)
+    assert torch.allclose(dfg.cpu(), torch.full((n,), -1.0 / n))
+    # tanh backward
+    t = torch.tanh(_rnd(g, 4, 8, 8, 8)); dy = _rnd(g, 4, 8, 8, 8)
+    np.testing.assert_allclose(ops.tanh_bwd(dy.cuda(), t.cuda()).cpu(), dy * (1 - t * t), rtol=1e-6, atol=1e-6)
+    # Adam: three steps against torch.optim.Adam
+    p = _rnd(g, 1000).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=2e-4, betas=(0.5, 0.999))
+    pg, m, v = p.detach().clone().cuda(), torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    step = torch.zeros(1, dtype=torch.int64, device='cuda')
+    for _ in range(3):
+        gr = _rnd(g, 1000)
+        p.grad = gr.clone(); opt.step()
+        ops.adam(pg, gr.cuda(), m, v, step, 2e-4, (0.5, 0.999))
+    assert int(step) == 3
+    np.testing.assert_allclose(pg.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
