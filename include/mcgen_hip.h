@@ -135,8 +135,9 @@ int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int
 
 /* code[N, C] = indicator[N, M] @ codebook[M, C]      MultimodalController.forward, modules.py:73 */
 int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream);
-/* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers; NHWC */
-int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, void* stream);
+/* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
+ * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
+int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);
 
 /* BatchNorm2d training statistics from per-tile partial sums (mcgan.py:15,20,55):
  * mean/var over `count` elements per channel, scale = gamma*rstd, shift = beta-mean*scale,
@@ -167,9 +168,12 @@ int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float
 typedef struct { int64_t w_off, u_off, v_off; int32_t rows, cols; } mcgen_sn_layer_t;
 int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                         int do_iter, float* sigma, void* stream);
-/* gradient through W/sigma:  g = (g - <g, W/sigma> u v^T) / sigma, in place per layer */
-int mcgen_sn_grad_fix(float* g_base, const float* w_base, const float* uv_base,
-                      const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, void* stream);
+/* gradient through W/sigma:  dst (+)= (g - <g, W/sigma> u v^T) / sigma per layer, where g (at g_src + w_off)
+ * is the gradient w.r.t. the normalised weight; u, v, sigma are the values the FORWARD used (the caller
+ * keeps a snapshot per forward, as torch's hook does by cloning u and v). g_src may equal g_dst.
+ * A layer entry with rows == 0 is a plain parameter (bias) of `cols` elements: dst (+)= src. */
+int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
+                      const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate, void* stream);
 
 /* Discriminator tail (mcgan.py:158-165): logit[n] = b + sum_c (w[c]/sigma) * sum_hw relu(x)*code */
 int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b,

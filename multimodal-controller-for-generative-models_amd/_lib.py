@@ -53,14 +53,14 @@ SYMBOLS = {
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'mcgen_bn_eval_affine': (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'mcgen_bn_bwd_finalize': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),
     'mcgen_colsum': (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
-    'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

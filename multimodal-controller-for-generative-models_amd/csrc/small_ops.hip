@@ -82,10 +82,10 @@ __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __res
 }
 template <typename T>
 __global__ void mc_apply_kernel(const T* __restrict__ x, const float* __restrict__ code, T* __restrict__ y,
-                                int N, int HW, int C) {
+                                int N, int HW, int C, int inner) {
     const size_t total = (size_t)N * HW * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C); const int n = (int)(i / ((size_t)HW * C));
+        const int c = (int)((i / inner) % C); const int n = (int)(i / ((size_t)HW * C));
         y[i] = Elem<T>::from_f(Elem<T>::to_f(x[i]) * code[(size_t)n * C + c]);
     }
 }
@@ -245,11 +245,16 @@ __global__ void sn_power_iter_kernel(const float* __restrict__ wb, float* uvb, c
         if (tid == 0) sigma[blockIdx.x] = dot_u_wv;
     }
 }
-__global__ void sn_grad_fix_kernel(float* gb, const float* __restrict__ wb, const float* __restrict__ uvb,
-                                   const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma) {
+__global__ void sn_grad_fix_kernel(const float* __restrict__ gsrc, float* gdst, const float* __restrict__ wb,
+                                   const float* __restrict__ uvb, const mcgen_sn_layer_t* __restrict__ layers,
+                                   const float* __restrict__ sigma, int accumulate) {
     __shared__ float red[32];
     const mcgen_sn_layer_t L = layers[blockIdx.x];
-    float* G = gb + L.w_off; const float* W = wb + L.w_off;
+    const float* G = gsrc + L.w_off; float* D = gdst + L.w_off; const float* W = wb + L.w_off;
+    if (L.rows == 0) {                                         // plain parameter (bias): copy / accumulate
+        for (int i = threadIdx.x; i < L.cols; i += blockDim.x) D[i] = accumulate ? D[i] + G[i] : G[i];
+        return;
+    }
     const float* u = uvb + L.u_off; const float* v = uvb + L.v_off;
     const float sg = sigma[blockIdx.x];
     const size_t n = (size_t)L.rows * L.cols;
@@ -259,7 +264,8 @@ __global__ void sn_grad_fix_kernel(float* gb, const float* __restrict__ wb, cons
     const float inv = 1.f / sg;
     for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
         const int r = (int)(i / L.cols), c = (int)(i % L.cols);
-        G[i] = (G[i] - d * u[r] * v[c]) * inv;
+        const float o = (G[i] - d * u[r] * v[c]) * inv;
+        D[i] = accumulate ? D[i] + o : o;
     }
 }
 
@@ -405,12 +411,13 @@ extern "C" int mcgen_mc_code(const float* indicator, const float* codebook, floa
     hipLaunchKernelGGL(mc_code_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, STREAM(stream), indicator, codebook, code, N, M, C);
     MCGEN_LAUNCH_CHECK("mc_code"); return 0;
 }
-extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, void* stream) {
+extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream) {
     MCGEN_CHECK(x && code && y, "mc_apply: null pointer");
+    const int inner = channels_last ? 1 : HW;
     const size_t total = (size_t)N * HW * C;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(mc_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, code, (float*)y, N, HW, C),
-        hipLaunchKernelGGL(mc_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, code, (bf16_t*)y, N, HW, C));
+        hipLaunchKernelGGL(mc_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, code, (float*)y, N, HW, C, inner),
+        hipLaunchKernelGGL(mc_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, code, (bf16_t*)y, N, HW, C, inner));
     MCGEN_LAUNCH_CHECK("mc_apply"); return 0;
 }
 
@@ -465,10 +472,10 @@ extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mc
     hipLaunchKernelGGL(sn_power_iter_kernel, dim3(nlayers), dim3(512), 48 * 1024, STREAM(stream), w_base, uv_base, layers_dev, do_iter, sigma);
     MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
 }
-extern "C" int mcgen_sn_grad_fix(float* g_base, const float* w_base, const float* uv_base, const mcgen_sn_layer_t* layers_dev,
-                                 int nlayers, const float* sigma, void* stream) {
-    MCGEN_CHECK(g_base && w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_grad_fix: bad arguments");
-    hipLaunchKernelGGL(sn_grad_fix_kernel, dim3(nlayers), dim3(512), 0, STREAM(stream), g_base, w_base, uv_base, layers_dev, sigma);
+extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
+                                 const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate, void* stream) {
+    MCGEN_CHECK(g_src && g_dst && w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_grad_fix: bad arguments");
+    hipLaunchKernelGGL(sn_grad_fix_kernel, dim3(nlayers), dim3(512), 0, STREAM(stream), g_src, g_dst, w_base, uv_base, layers_dev, sigma, accumulate);
     MCGEN_LAUNCH_CHECK("sn_grad_fix"); return 0;
 }
 

@@ -1,0 +1,430 @@
+"""Fused forward/backward schedules of the MCGAN generator and discriminator.
+
+The nn.Module trees in ``models/mcgan.py`` keep the reference's structure (for
+``state_dict`` / ``apply`` / ``create`` / ``transit``); their forwards hand the
+whole network to the engines below, which launch one fused convolution per conv
+layer (prologue = BN-apply + ReLU + nearest-upsample + MultimodalController code,
+epilogue = bias / avg-pool / residual / next-BN statistics) plus the small
+finalize kernels, and the hand-derived backward of the same chain
+("Backward math for the fused kernels").
+
+Reference op chains restated here: GenResBlock / Generator (mcgan.py:9-69),
+FirstDisResBlock / DisResBlock / Discriminator (mcgan.py:72-181), spectral norm
+(models/utils.py:17-21 -> torch.nn.utils.spectral_norm).
+
+Parameters of a network live in ONE flat fp32 buffer (``FlatState``); gradients
+are produced into a flat buffer of the same layout, so Adam and the data-parallel
+all-reduce are one launch / one message per network.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import Seg
+
+Tensor = torch.Tensor
+
+
+def _bump(t: Tensor):
+    """Tell autograd's version counter that a kernel wrote `t` behind torch's back."""
+    torch.autograd.graph.increment_version(t)
+
+
+class FlatState:
+    """Re-points a list of tensors (parameters or buffers) at slices of one flat fp32
+    buffer, so that whole-network kernels (spectral norm, Adam, gradient all-reduce)
+    address them as base + offset.  Re-flattens when the tensors were moved
+    (``module.to(device)``) or replaced."""
+
+    def __init__(self, tensors: List[Tensor]):
+        self.tensors = tensors
+        self.flat: Optional[Tensor] = None
+        self.offsets: List[int] = []
+        self._index = {id(t): i for i, t in enumerate(tensors)}
+
+    def ensure(self) -> Tensor:
+        ts = self.tensors
+        ok = self.flat is not None
+        if ok:
+            base = self.flat.data_ptr()
+            for t, off in zip(ts, self.offsets):
+                if t.data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+        if not ok:
+            dev = ts[0].device
+            total, offs = 0, []
+            for t in ts:
+                offs.append(total)
+                total += (t.numel() + 3) // 4 * 4            # keep every slice 16-byte aligned
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            for t, off in zip(ts, offs):
+                flat[off:off + t.numel()].copy_(t.detach().reshape(-1))
+                t.data = flat[off:off + t.numel()].view(t.shape)
+            self.flat, self.offsets = flat, offs
+        return self.flat
+
+    def offset_of(self, t: Tensor) -> int:
+        return self.offsets[self._index[id(t)]]
+
+    def view_of(self, flat: Tensor, t: Tensor) -> Tensor:
+        """The slice of another flat buffer (same layout) that corresponds to tensor t."""
+        off = self.offset_of(t)
+        return flat[off:off + t.numel()].view(t.shape)
+
+    def views(self, flat: Tensor) -> List[Tensor]:
+        return [self.view_of(flat, t) for t in self.tensors]
+
+
+class _BN:
+    """Per-forward BatchNorm state: affine used by the consumer's prologue + what backward needs."""
+    __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
+
+
+def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: bool, fold: int = 1) -> _BN:
+    s = _BN()
+    s.count = count
+    if train:
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
+                                                           bn.running_var, mom, bn.eps, fold=fold)
+        _bump(bn.running_mean); _bump(bn.running_var)
+        bn.num_batches_tracked.add_(1)
+    else:
+        s.scale, s.shift = ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        s.mean, s.rstd = None, None
+    return s
+
+
+# ============================================================================================= #
+#  Generator
+# ============================================================================================= #
+class GeneratorEngine:
+    def __init__(self, gen, dtype: torch.dtype = torch.float32):
+        self.gen = gen
+        self.dtype = dtype
+        self.flat_p = FlatState(list(gen.parameters()))
+        self._img_key = None
+        self.img: Dict[str, Tensor] = {}
+
+    def _layers(self):
+        g = self.gen
+        blocks = list(g.blocks.children())
+        res = [b for b in blocks if hasattr(b, 'mc_1')]
+        n = len(res)
+        head_bn, head_mc, head_conv = blocks[n].module, blocks[n + 2], blocks[n + 3].module
+        return g.linear.module, res, head_bn, head_mc, head_conv
+
+    # ---- weight images -------------------------------------------------------------------------
+    def refresh_images(self, force: bool = False):
+        """(Re)build the kernel weight images when a parameter changed (torch version counters;
+        kernels that write parameters bump them, see fused_adam)."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        ws = [lin.weight, lin.bias, head_conv.weight]
+        for b in res:
+            ws += [b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight,
+                   b.conv[8].module.bias, b.shortcut[2].module.bias]
+        key = (self.dtype, tuple((w.data_ptr(), w._version) for w in ws))
+        if not force and key == self._img_key:
+            return
+        dt = self.dtype
+        c0 = lin.out_features // 16
+        self.img['lin'] = ops.prep_weight(lin.weight.detach(), dt, row_perm=16)
+        self.img['lin_bias'] = lin.bias.detach().view(c0, 16).t().reshape(-1).contiguous()
+        for i, b in enumerate(res):
+            w1, w2, wsc = (b.conv[4].module.weight.detach(), b.conv[8].module.weight.detach(),
+                           b.shortcut[2].module.weight.detach())
+            self.img[f'b{i}.w1'] = ops.prep_weight(w1, dt)
+            n2 = ops.weight_image_elems(w2.shape[0], w2.shape[1], 3)
+            ns = ops.weight_image_elems(wsc.shape[0], wsc.shape[1], 1)
+            buf = torch.empty(n2 + ns, dtype=dt, device=w2.device)
+            ops.prep_weight(w2, dt, out=buf[:n2])
+            ops.prep_weight(wsc, dt, out=buf[n2:])
+            self.img[f'b{i}.w2s'] = buf
+            self.img[f'b{i}.bias2s'] = b.conv[8].module.bias.detach() + b.shortcut[2].module.bias.detach()
+        self.img['head'] = ops.prep_weight(head_conv.weight.detach(), dt)
+        self._img_key = key
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, z: Tensor, indicator: Tensor, train: bool):
+        self.flat_p.ensure()
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        dt = self.dtype
+        n = z.shape[0]
+        self.refresh_images()
+        st_mode = 1 if train else 0
+        ctx = {'train': train, 'n': n}
+        zt = ops.to_nhwc(z.detach().reshape(n, -1, 1, 1), dt)                 # [N,1,1,L]
+        c0 = lin.out_features // 16
+        x0, st = ops.conv_fused([Seg(zt, ksize=1)], self.img['lin'], 16 * c0, bias=self.img['lin_bias'],
+                                stats_mode=st_mode)
+        x = x0.view(n, 4, 4, c0)
+        fold = 16                              # Linear output column p*C0+c belongs to channel c
+        ctx['zt'] = zt
+        blocks_ctx = []
+        for i, b in enumerate(res):
+            s = x.shape[1]
+            code1, code2 = b.mc_1.code(indicator), b.mc_2.code(indicator)
+            bn1 = _bn_forward(b.conv[0].module, st, n * s * s, train, fold)
+            fold = 1
+            co = b.conv[4].module.out_channels
+            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
+            h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1'], co, bias=b.conv[4].module.bias, stats_mode=st_mode)
+            bn2 = _bn_forward(b.conv[5].module, st_h, n * 4 * s * s, train)
+            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
+            seg_s = Seg(x, ksize=1, code=code1, ups=True)
+            y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],
+                                   stats_mode=st_mode)
+            blocks_ctx.append(dict(x=x, h=h, code1=code1, code2=code2, bn1=bn1, bn2=bn2))
+            x = y
+        s = x.shape[1]
+        bnh = _bn_forward(head_bn, st, n * s * s, train, fold)
+        codeh = head_mc.code(indicator)
+        seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
+        out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
+        ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
+        return ops.to_nchw(out, head_conv.out_channels), ctx
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def backward(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
+        """dimg: [N, C, H, W] fp32.  Writes (or adds) every generator parameter's gradient into
+        `gflat`, a flat fp32 buffer laid out like ``flat_p``."""
+        if not ctx['train']:
+            raise RuntimeError('generator backward needs a training-mode forward (batch statistics)')
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        dt = self.dtype
+        n = ctx['n']
+        acc = accumulate
+        G = lambda p: self.flat_p.view_of(gflat, p)                           # noqa: E731
+        out = ctx['out']
+        dout = ops.to_nhwc(dimg.contiguous(), dt, out.shape[-1])
+        dtn = ops.tanh_bwd(dout, out)
+        y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
+        c_img, c = head_conv.out_channels, head_conv.in_channels
+        # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
+        ops.colsum(dtn, c_img, G(head_conv.bias), accumulate=acc)
+        seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
+        ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc)
+        wt = ops.prep_weight(head_conv.weight.detach(), dt, transpose=True)
+        dz, part = ops.conv_fused([Seg(dtn)], wt, c, ocode=codeh, gate_x=y, gscale=bnh.scale, gshift=bnh.shift,
+                                  gmean=bnh.mean, grstd=bnh.rstd, stats_mode=2)
+        dy = ops.bn_backward(part, dz, y, bnh.count, bnh.scale, bnh.mean, bnh.rstd,
+                             G(head_bn.weight), G(head_bn.bias), accumulate=acc)
+        for i in reversed(range(len(res))):
+            b, bc = res[i], ctx['blocks'][i]
+            x, h, code1, code2, bn1, bn2 = bc['x'], bc['h'], bc['code1'], bc['code2'], bc['bn1'], bc['bn2']
+            conv1, conv2, convs = b.conv[4].module, b.conv[8].module, b.shortcut[2].module
+            bnm1, bnm2 = b.conv[0].module, b.conv[5].module
+            ci, co = conv1.in_channels, conv1.out_channels
+            # second conv and the 1x1 shortcut both see dy
+            ops.colsum(dy, co, G(conv2.bias), accumulate=acc)
+            ops.colsum(dy, co, G(convs.bias), accumulate=acc)
+            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
+            seg_s = Seg(x, ksize=1, code=code1, ups=True)
+            ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc)
+            ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
+            w2t = ops.prep_weight(conv2.weight.detach(), dt, transpose=True)
+            dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
+                                        gmean=bn2.mean, grstd=bn2.rstd, stats_mode=2)
+            dh = ops.bn_backward(part2, dz2, h, bn2.count, bn2.scale, bn2.mean, bn2.rstd,
+                                 G(bnm2.weight), G(bnm2.bias), accumulate=acc)
+            # first conv: gradient goes through MC, the nearest-upsample adjoint (2x2 sum), ReLU, BN
+            ops.colsum(dh, co, G(conv1.bias), accumulate=acc)
+            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
+            ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc)
+            wst = ops.prep_weight(convs.weight.detach(), dt, transpose=True)
+            dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
+            w1t = ops.prep_weight(conv1.weight.detach(), dt, transpose=True)
+            dz1, part1 = ops.conv_fused([Seg(dh)], w1t, ci, pool=True, alpha=1.0, ocode=code1, gate_x=x,
+                                        gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)
+            dy = ops.bn_backward(part1, dz1, x, bn1.count, bn1.scale, bn1.mean, bn1.rstd,
+                                 G(bnm1.weight), G(bnm1.bias), add=dx_sc, accumulate=acc)
+        # linear layer: dy is [N,4,4,C0] == [N,1,1,16*C0] in the permuted row order
+        c0 = lin.out_features // 16
+        dflat = dy.view(n, 1, 1, 16 * c0)
+        ops.colsum(dflat, 16 * c0, G(lin.bias), row_perm=16, accumulate=acc)
+        ops.wgrad(Seg(ctx['zt'], ksize=1), dflat, 16 * c0, lin.in_features, G(lin.weight), row_perm=16, accumulate=acc)
+
+
+# ============================================================================================= #
+#  Discriminator
+# ============================================================================================= #
+class _SNConv:
+    """One spectrally normalised Conv2d/Linear: module + index into the per-forward sigma vector."""
+
+    def __init__(self, module: nn.Module, idx: int):
+        self.m = module
+        self.idx = idx
+        w = module.weight_orig
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.ks = w.shape[2] if w.dim() == 4 else 1
+
+
+class DiscriminatorEngine:
+    def __init__(self, dis, dtype: torch.dtype = torch.float32):
+        self.dis = dis
+        self.dtype = dtype
+        blocks = list(dis.blocks.children())
+        self.res = [b for b in blocks if hasattr(b, 'mc_1')]
+        t = len(self.res)
+        self.tail_mc, self.tail_lin = blocks[t + 1], blocks[t + 3].module
+        self.sn: List[_SNConv] = []
+        for m in dis.modules():
+            if hasattr(m, 'weight_orig'):
+                self.sn.append(_SNConv(m, len(self.sn)))
+        self.sn_of = {s.m: s for s in self.sn}
+        params = list(dis.parameters())
+        sn_w = {id(s.m.weight_orig) for s in self.sn}
+        self.plain = [p for p in params if id(p) not in sn_w]
+        self.flat_p = FlatState(params)
+        uv = []
+        for s in self.sn:
+            uv += [s.m.weight_u, s.m.weight_v]
+        self.flat_uv = FlatState(uv)
+        self._layers_dev = None          # SN layers first, then plain parameters (rows == 0)
+        self._layers_key = None
+
+    def _ensure_flat(self):
+        fp, fuv = self.flat_p.ensure(), self.flat_uv.ensure()
+        key = (fp.data_ptr(), fuv.data_ptr())
+        if key != self._layers_key:
+            rows = []
+            for s in self.sn:
+                w = s.m.weight_orig
+                rows.append((self.flat_p.offset_of(w), self.flat_uv.offset_of(s.m.weight_u),
+                             self.flat_uv.offset_of(s.m.weight_v), w.shape[0], w[0].numel()))
+            for p in self.plain:
+                rows.append((self.flat_p.offset_of(p), 0, 0, 0, p.numel()))
+            self._layers_dev = ops.sn_layers_tensor(rows, fp.device)
+            self._layers_key = key
+        return fp, fuv
+
+    def _prep(self, s: _SNConv, sigma: Tensor, transpose: bool = False, wscale: float = 1.0, out=None):
+        return ops.prep_weight(s.m.weight_orig.detach(), self.dtype, transpose=transpose,
+                               sigma=sigma[s.idx:s.idx + 1], wscale=wscale, out=out)
+
+    def _prep_cat(self, a: _SNConv, b: _SNConv, sigma, transpose=False, scale_a=1.0, scale_b=1.0):
+        na = ops.weight_image_elems(a.cout, a.cin, a.ks, transpose)
+        nb = ops.weight_image_elems(b.cout, b.cin, b.ks, transpose)
+        buf = torch.empty(na + nb, dtype=self.dtype, device=sigma.device)
+        self._prep(a, sigma, transpose, scale_a, out=buf[:na])
+        self._prep(b, sigma, transpose, scale_b, out=buf[na:])
+        return buf
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
+        dt = self.dtype
+        fp, fuv = self._ensure_flat()
+        n = x_nchw.shape[0]
+        nsn = len(self.sn)
+        sigma = torch.empty(nsn, dtype=torch.float32, device=fp.device)
+        ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sigma)
+        if train:
+            for s in self.sn:
+                _bump(s.m.weight_u); _bump(s.m.weight_v)
+        ctx = {'n': n, 'sigma': sigma, 'uv': fuv.clone(), 'blocks': []}   # torch's hook clones u, v too
+        img = ops.to_nhwc(x_nchw.detach().contiguous(), dt)
+        ctx['img'] = img
+        # --- FirstDisResBlock (mcgan.py:72-93)
+        b0 = self.res[0]
+        c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
+        code = b0.mc_1.code(indicator)
+        co = c1m.cout
+        c1, _ = ops.conv_fused([Seg(img)], self._prep(c1m, sigma), co, bias=c1m.m.bias)
+        sc, _ = ops.conv_fused([Seg(img, ksize=1)], self._prep(scm, sigma), co, bias=scm.m.bias, pool=True, alpha=0.25)
+        y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], self._prep(c2m, sigma), co, bias=c2m.m.bias,
+                              pool=True, alpha=0.25, res=sc)
+        ctx['blocks'].append({'c1': c1, 'code': code})
+        x = y
+        # --- DisResBlocks (mcgan.py:96-138)
+        for b in self.res[1:]:
+            c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
+            has_sc = len(b.shortcut) > 0
+            pooled = len(b.conv) == 7
+            code1, code2 = b.mc_1.code(indicator), b.mc_2.code(indicator)
+            c1, _ = ops.conv_fused([Seg(x, code=code1, relu=True)], self._prep(c1m, sigma), c1m.cout, bias=c1m.m.bias)
+            if has_sc:
+                scm = self.sn_of[b.shortcut[1].module]
+                wimg = self._prep_cat(c2m, scm, sigma)
+                bias = c2m.m.bias.detach() + scm.m.bias.detach()
+                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1)], wimg, c2m.cout,
+                                      bias=bias, pool=pooled, alpha=0.25 if pooled else 1.0)
+            else:
+                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True)], self._prep(c2m, sigma), c2m.cout,
+                                      bias=c2m.m.bias, res=x)
+            ctx['blocks'].append({'x': x, 'c1': c1, 'code1': code1, 'code2': code2, 'pooled': pooled, 'has_sc': has_sc})
+            x = y
+        # --- tail: ReLU -> MC -> global sum pool -> SN linear (mcgan.py:158-165)
+        tl = self.sn_of[self.tail_lin]
+        codet = self.tail_mc.code(indicator)
+        logit, pooled_feat = ops.dtail_fwd(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
+                                           sigma[tl.idx:tl.idx + 1])
+        ctx.update(xt=x, codet=codet, pooled=pooled_feat)
+        return logit.view(n, 1), ctx
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def backward(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
+        """dlogit [N] fp32.  Parameter gradients (w.r.t. weight_orig and the biases) are written or
+        added into `gflat` (flat, laid out like ``flat_p``; None skips them, e.g. in the generator
+        step); returns d(input image) as NCHW fp32, or None."""
+        dt = self.dtype
+        fp, _ = self._ensure_flat()
+        sigma, uv = ctx['sigma'], ctx['uv']
+        want_w = gflat is not None
+        # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first
+        gtmp = torch.empty_like(fp) if want_w else None
+        T = (lambda p: self.flat_p.view_of(gtmp, p)) if want_w else None       # noqa: E731
+
+        tl = self.sn_of[self.tail_lin]
+        sg_t = sigma[tl.idx:tl.idx + 1]
+        wl = self.tail_lin.weight_orig
+        dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
+                           T(wl).view(-1) if want_w else None, T(self.tail_lin.bias) if want_w else None)
+        for bi in reversed(range(1, len(self.res))):
+            b, bc = self.res[bi], ctx['blocks'][bi]
+            x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
+            c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
+            scm = self.sn_of[b.shortcut[1].module] if has_sc else None
+            a = 0.25 if pooled else 1.0
+            if want_w:
+                ops.colsum(dy, c2m.cout, T(c2m.m.bias))
+                ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a)
+                if has_sc:
+                    ops.colsum(dy, scm.cout, T(scm.m.bias))
+                    ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
+            dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], self._prep(c2m, sigma, True, a), c2m.cin, ocode=code2, gate_x=c1)
+            if want_w:
+                ops.colsum(dc1, c1m.cout, T(c1m.m.bias))
+                ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig))
+            if has_sc:
+                res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], self._prep(scm, sigma, True, a), scm.cin, ocode=code1)
+            else:
+                res = dy
+            dy, _ = ops.conv_fused([Seg(dc1)], self._prep(c1m, sigma, True), c1m.cin, ocode=code1, gate_x=x, res=res)
+        # FirstDisResBlock
+        b0, bc = self.res[0], ctx['blocks'][0]
+        c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
+        c1, code, img = bc['c1'], bc['code'], ctx['img']
+        if want_w:
+            ops.colsum(dy, c2m.cout, T(c2m.m.bias))
+            ops.colsum(dy, scm.cout, T(scm.m.bias))
+            ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25)
+            ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
+        dc1, _ = ops.conv_fused([Seg(dy, ups=True)], self._prep(c2m, sigma, True, 0.25), c2m.cin, ocode=code, gate_x=c1)
+        if want_w:
+            ops.colsum(dc1, c1m.cout, T(c1m.m.bias))
+            ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig))
+        dimg = None
+        if need_input_grad:
+            wimg = self._prep_cat(c1m, scm, sigma, transpose=True, scale_b=0.25)
+            dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], wimg, c1m.cin, cy=img.shape[-1])
+            dimg = ops.to_nchw(dimg_t, c1m.cin)
+        if want_w:
+            # d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used; biases are moved as is
+            ops.sn_grad_fix(gtmp, gflat, fp, uv, self._layers_dev, len(self.sn) + len(self.plain), sigma,
+                            accumulate=accumulate)
+        return dimg

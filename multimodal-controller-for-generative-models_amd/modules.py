@@ -1,0 +1,85 @@
+"""MultimodalController / Wrapper with the reference's module surface
+(reference: src/modules/modules.py:49-85), computed by HIP kernels.
+
+``MultimodalController`` keeps the reference contract that the codebook is a
+LIVE buffer: ``models.utils.create`` / ``transit`` re-register it (possibly with
+a different number of modes), and every forward -- standalone or from inside a
+fused block -- reads ``self.codebook`` at call time.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def sample_codebook(num_mode: int, input_size: int, rate: float) -> torch.Tensor:
+    """Distinct Bernoulli(rate) rows, all-ones when rate == 1 (modules.py:58-69).
+
+    The reference keeps the first ``num_mode`` rows of a Python ``set`` (hash
+    order), so its row order is not reproducible from a seed; parity runs load
+    the reference's ``codebook`` buffers instead.  Here rows
+    keep their sampling order.
+    """
+    if rate == 1:
+        return torch.ones(num_mode, input_size)
+    rows, seen = [], set()
+    while len(rows) < num_mode:
+        for r in torch.bernoulli(torch.full((num_mode, input_size), float(rate))).tolist():
+            t = tuple(r)
+            if t not in seen and len(rows) < num_mode:
+                seen.add(t)
+                rows.append(r)
+    return torch.tensor(rows, dtype=torch.float)
+
+
+class _MaskFn(torch.autograd.Function):
+    """x * code with the code treated as a constant (code.detach(), modules.py:75)."""
+
+    @staticmethod
+    def forward(ctx, x, code):
+        ctx.save_for_backward(code)
+        return ops.mc_apply(x.contiguous(), code, channels_last=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (code,) = ctx.saved_tensors
+        return ops.mc_apply(g.contiguous(), code, channels_last=False), None
+
+
+class MultimodalController(nn.Module):
+    def __init__(self, input_size, num_mode, controller_rate=0.5):
+        super().__init__()
+        self.input_size = input_size
+        self.num_mode = num_mode
+        self.controller_rate = controller_rate
+        self.register_buffer('codebook', self.make_codebook())
+
+    def make_codebook(self):
+        return sample_codebook(self.num_mode, self.input_size, self.controller_rate)
+
+    def code(self, indicator: torch.Tensor) -> torch.Tensor:
+        """[N, C] = indicator @ codebook, from the buffer as it is right now."""
+        return ops.mc_code(indicator, self.codebook)
+
+    def forward(self, input):
+        # list protocol of the reference: [x, indicator, ...] -> [x * code, indicator, ...]
+        x, indicator = input[0], input[1]
+        if x.dtype != torch.float32:
+            raise TypeError('MultimodalController expects float32 activations at the module boundary')
+        return [_MaskFn.apply(x, self.code(indicator)), *input[1:]]
+
+    def extra_repr(self):
+        return f'{self.input_size}, num_mode={self.num_mode}, rate={self.controller_rate}'
+
+
+class Wrapper(nn.Module):
+    """Lifts a tensor module onto the [x, indicator, ...] list protocol (modules.py:79-85)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, input):
+        return [self.module(input[0]), *input[1:]]

@@ -103,11 +103,13 @@ def mc_code(indicator: Tensor, codebook: Tensor, cp: Optional[int] = None) -> Te
     return code
 
 
-def mc_apply(x: Tensor, code: Tensor) -> Tensor:
-    n, c = x.shape[0], x.shape[-1]
+def mc_apply(x: Tensor, code: Tensor, channels_last: bool = True) -> Tensor:
+    """x * code; x is [N, ..., C] (channels_last) or [N, C, ...] (the reference's layout)."""
+    n = x.shape[0]
+    c = x.shape[-1] if channels_last else x.shape[1]
     hw = x.numel() // (n * c)
     y = torch.empty_like(x)
-    check(_lib.load().mcgen_mc_apply(_p(x), _f32(code), _p(y), _dt(x.dtype), n, hw, c, _stream()), 'mc_apply')
+    check(_lib.load().mcgen_mc_apply(_p(x), _f32(code), _p(y), _dt(x.dtype), n, hw, c, int(channels_last), _stream()), 'mc_apply')
     return y
 
 
@@ -321,9 +323,10 @@ def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: 
                                           _f32(sigma), _stream()), 'sn_power_iter')
 
 
-def sn_grad_fix(g_base: Tensor, w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, sigma: Tensor):
-    check(_lib.load().mcgen_sn_grad_fix(_f32(g_base), _f32(w_base), _f32(uv_base), _p(layers_dev), nlayers,
-                                        _f32(sigma), _stream()), 'sn_grad_fix')
+def sn_grad_fix(g_src: Tensor, g_dst: Tensor, w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int,
+                sigma: Tensor, accumulate: bool = False):
+    check(_lib.load().mcgen_sn_grad_fix(_f32(g_src), _f32(g_dst), _f32(w_base), _f32(uv_base), _p(layers_dev), nlayers,
+                                        _f32(sigma), int(accumulate), _stream()), 'sn_grad_fix')
 
 
 def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),

@@ -1,0 +1,160 @@
+"""The MCGAN train step (counterpart of the loop body of the reference's
+``train_gan.py:139-176``) driven directly on the fused engines, plus the fused Adam.
+
+Per data batch: ``d_iters`` (5) discriminator updates -- D(real), G(z) in training mode,
+D(G(z).detach()), hinge loss, backward, Adam(D) -- then ``g_iters`` (1) generator updates --
+G(z), D(G(z)), -mean, backward through D into G, Adam(G).  Adam(lr 2e-4, betas (0.5, 0.999),
+eps 1e-8, no weight decay) as configured at train_gan.py:43-47,231.
+
+The discriminator weight gradient of the generator step, which the reference computes and then
+discards at the next zero_grad (train_gan.py:141,163), is skipped.
+
+Data parallel: one process per GPU; each rank runs this step on its shard and the flat gradient
+buffer of the network being updated is all-reduced (average) over RCCL before Adam
+(``dist_group`` != None).  BatchNorm statistics stay per-rank, as with the reference's
+nn.DataParallel (train_gan.py:96-98).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .gan_engine import FlatState, _bump
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics over one flat parameter buffer: one launch per step."""
+
+    def __init__(self, flat_state: FlatState, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, weight_decay=0.0):
+        self.fs = flat_state
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        flat = self.fs.ensure()
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+
+    def step(self, gflat: torch.Tensor):
+        flat = self.fs.ensure()
+        ops.adam(flat, gflat, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)
+        for p in self.fs.tensors:
+            _bump(p)
+
+    def state_dict(self):
+        return {'m': self.m, 'v': self.v, 'step': self.step_count, 'lr': self.lr, 'betas': self.betas,
+                'eps': self.eps, 'weight_decay': self.wd}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_count.copy_(sd['step'])
+        self.lr, self.betas, self.eps, self.wd = sd['lr'], tuple(sd['betas']), sd['eps'], sd['weight_decay']
+
+
+class GANTrainer:
+    def __init__(self, model, classes: int, lr=2e-4, betas=(0.5, 0.999), d_iters: int = 5, g_iters: int = 1,
+                 dist_group=None, world_size: int = 1):
+        self.model = model
+        self.classes = classes
+        self.d_iters, self.g_iters = d_iters, g_iters
+        self.geng = model.generator._engine()
+        self.deng = model.discriminator._engine()
+        self.geng.flat_p.ensure()
+        self.deng._ensure_flat()
+        self.opt_g = FusedAdam(self.geng.flat_p, lr, betas)
+        self.opt_d = FusedAdam(self.deng.flat_p, lr, betas)
+        self.grad_g = torch.zeros_like(self.geng.flat_p.flat)
+        self.grad_d = torch.zeros_like(self.deng.flat_p.flat)
+        self.group, self.world = dist_group, world_size
+        self.latent = model.latent_size
+
+    # ---- data-parallel gradient exchange: one flat bucket per network ----------------------------
+    def _allreduce(self, g: torch.Tensor):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.mul_(1.0 / self.world)
+
+    def d_update(self, img, ind, z):
+        d_real, ctx_r = self.deng.forward(img, ind, True)
+        fake, _ = self.geng.forward(z, ind, True)
+        d_fake, ctx_f = self.deng.forward(fake, ind, True)
+        loss, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
+        self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
+        self.deng.backward(ctx_f, dfake, self.grad_d, True, False)
+        self._allreduce(self.grad_d)
+        self.opt_d.step(self.grad_d)
+        return loss
+
+    def g_update(self, ind, z):
+        fake, gctx = self.geng.forward(z, ind, True)
+        d_fake, dctx = self.deng.forward(fake, ind, True)
+        loss, dfake = ops.hinge_g(d_fake.view(-1))
+        dimg = self.deng.backward(dctx, dfake, None, False, True)
+        self.geng.backward(gctx, dimg, self.grad_g, False)
+        self._allreduce(self.grad_g)
+        self.opt_g.step(self.grad_g)
+        self.geng.refresh_images(force=True)
+        return loss
+
+    def train_iteration(self, img: torch.Tensor, label: torch.Tensor, zs: Optional[Sequence[torch.Tensor]] = None):
+        """One reference loop body on one batch.  `zs`: d_iters + g_iters latent batches to inject
+        (parity runs); drawn on the device when None.  Returns (D_loss, G_loss) device scalars of the
+        last D and G update, as the reference logs them (train_gan.py:177)."""
+        self.model.train(True)
+        n = img.shape[0]
+        ind = F.one_hot(label, self.classes).float()
+        zi = iter(zs) if zs is not None else None
+        draw = (lambda: next(zi)) if zi is not None else (lambda: torch.randn(n, self.latent, device=img.device))
+        d_loss = g_loss = None
+        for _ in range(self.d_iters):
+            d_loss = self.d_update(img, ind, draw())
+        for _ in range(self.g_iters):
+            g_loss = self.g_update(ind, draw())
+        return d_loss, g_loss
+
+
+class GraphedGANTrainer(GANTrainer):
+    """Same step, captured once into two HIP graphs (one D update, one G update) and replayed:
+    the step is a few hundred short launches, so replay removes the host launch cost."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._graphs = None
+
+    def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 2):
+        if self.world > 1:
+            raise RuntimeError('graph capture of the multi-rank step is not supported; use the eager step')
+        n = img.shape[0]
+        dev = img.device
+        self.s_img = img.clone()
+        self.s_ind = F.one_hot(label, self.classes).float()
+        self.s_z = torch.randn(n, self.latent, device=dev)
+        self.model.train(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.d_update(self.s_img, self.s_ind, self.s_z)
+                self.g_update(self.s_ind, self.s_z)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.gd, self.gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gd):
+            self.s_z.normal_()
+            self.loss_d = self.d_update(self.s_img, self.s_ind, self.s_z)
+        with torch.cuda.graph(self.gg, pool=self.gd.pool()):
+            self.s_z.normal_()
+            self.loss_g = self.g_update(self.s_ind, self.s_z)
+        self._graphs = True
+
+    def train_iteration(self, img, label, zs=None):
+        if self._graphs is None or zs is not None:
+            return super().train_iteration(img, label, zs)
+        self.s_img.copy_(img, non_blocking=True)
+        self.s_ind.copy_(F.one_hot(label, self.classes).float(), non_blocking=True)
+        for _ in range(self.d_iters):
+            self.gd.replay()
+        for _ in range(self.g_iters):
+            self.gg.replay()
+        return self.loss_d, self.loss_g

@@ -346,7 +346,7 @@ def test_spectral_norm_kernels():
         m.zero_grad()
         (m.weight * gw).sum().backward()
     G = torch.cat([g.reshape(-1) for g in gs]).cuda()
-    ops.sn_grad_fix(G, W, UV, ld, len(sn), sigma)
+    ops.sn_grad_fix(G, G, W, UV, ld, len(sn), sigma)
     off = 0
     for m in sn:
         k = m.weight_orig.numel()

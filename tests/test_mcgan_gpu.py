@@ -1,0 +1,258 @@
+"""GPU parity of the fused MCGAN path (modules -> engines -> HIP kernels) against the
+reference-generated golden fixtures and the CPU oracle.
+
+fp32 compute: activations 2e-4 relative to the tensor's magnitude, step losses 1e-4 absolute for
+the first iteration and 2e-3 afterwards (every parameter then carries an Adam step of +-lr*g/|g|,
+whose direction is rounding-defined for near-zero gradients; tests/test_oracle_golden.py).
+bf16 compute: losses within 5e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g_hidden, d_hidden, classes, data_name, sd=None, dtype=torch.float32):
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg, process_control
+    cfg['data_name'], cfg['model_name'], cfg['device'] = data_name, 'mcgan', 'cuda'
+    cfg.pop('classes_size', None)
+    process_control()
+    cfg['classes_size'] = classes
+    cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'] = list(g_hidden), list(d_hidden)
+    m = models.mcgan()
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m.cuda().set_compute_dtype(dtype)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_small_probe_forward_and_state():
+    d = gu.load_npz('mcgan_small.npz')
+    m = _build([32] * 4, [16] * 4, 10, 'CIFAR10', gu.state_from_npz(d))
+    m.train(True)
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    z = torch.from_numpy(d['z'][-1]).cuda()
+    with torch.no_grad():
+        gen = m.generate(lab, z)
+        dr = m.discriminate(img, lab)
+    assert _rel(gen, d['probe_generated']) < 2e-4
+    assert _rel(dr, d['probe_d_real']) < 2e-4
+    after = gu.state_from_npz(d, 'sd_after_probe/')
+    sd = m.state_dict()
+    for k, v in after.items():                       # BN running stats, num_batches_tracked, SN u/v
+        if v.dtype == torch.int64:
+            assert int(sd[k]) == int(v), k
+        else:
+            assert _rel(sd[k], v) < 2e-4, k
+
+
+@pytest.mark.parametrize('path', ['engine', 'autograd'])
+def test_small_train_losses(path):
+    """3 iterations of 5 D + 1 G updates (train_gan.py:139-176), latents injected."""
+    from mcgen_amd.trainer import GANTrainer
+    d = gu.load_npz('mcgan_small.npz')
+    m = _build([32] * 4, [16] * 4, 10, 'CIFAR10', gu.state_from_npz(d))
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    zs = [torch.from_numpy(z).cuda() for z in d['z']]
+    losses = []
+    if path == 'engine':
+        tr = GANTrainer(m, 10)
+        for it in range(3):
+            dl, gl = tr.train_iteration(img, lab, zs[6 * it:6 * it + 6])
+            losses.append((float(dl), float(gl)))
+    else:                                            # the reference's own loop on the nn.Module surface
+        m.train(True)
+        og = torch.optim.Adam(m.generator.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(m.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        for it in range(3):
+            zi = iter(zs[6 * it:6 * it + 6])
+            for _ in range(5):
+                od.zero_grad(); og.zero_grad()
+                d_x = m.discriminate(img, lab)
+                fake = m.generate(lab, next(zi))
+                d_g = m.discriminate(fake.detach(), lab)
+                dl = torch.relu(1.0 - d_x).mean() + torch.relu(1.0 + d_g).mean()
+                dl.backward(); od.step()
+            od.zero_grad(); og.zero_grad()
+            fake = m.generate(lab, next(zi))
+            gl = -m.discriminate(fake, lab).mean()
+            gl.backward(); og.step()
+            losses.append((float(dl), float(gl)))
+    got, ref = np.array(losses), d['losses']
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(got[1:], ref[1:], rtol=0, atol=2e-3)
+    fin = gu.state_from_npz(d, 'sd_final/')
+    sd = m.state_dict()
+    noisy = ('linear.module.bias', 'conv.4.module.bias', 'conv.8.module.bias', 'shortcut.2.module.bias', 'running_mean')
+    for k, v in fin.items():
+        if v.dtype == torch.int64:
+            assert int(sd[k]) == int(v), k
+        elif k.startswith('generator.') and k.endswith(noisy):
+            assert float((sd[k].cpu() - v).abs().max()) < 1.5 * 3 * 2e-4 + 1e-4, k
+        else:
+            assert float((sd[k].cpu() - v).abs().max()) < 1e-3 * float(v.abs().max()) + 4e-4, k
+
+
+def test_coil_schedule_train():
+    from mcgen_amd.trainer import GANTrainer
+    d = gu.load_npz('mcgan_coil_small.npz')
+    m = _build([64, 32, 16, 8], [8, 16, 32, 64], 20, 'COIL100', gu.state_from_npz(d))
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    zs = [torch.from_numpy(z).cuda() for z in d['z']]
+    dl, gl = GANTrainer(m, 20).train_iteration(img, lab, zs)
+    np.testing.assert_allclose([float(dl), float(gl)], d['losses'][0], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)])
+def test_full_size_digest(dtype, tol):
+    """Full-size model (G [256]*4, D [128]*4), procedural weights, B=16, two iterations."""
+    from mcgen_amd.trainer import GANTrainer
+    d = gu.load_npz('mcgan_full_digest.npz')
+    sd = gu.procedural_state(gu.mcgan_shapes([256] * 4, [128] * 4, 10), seed=1234, num_mode=10)
+    m = _build([256] * 4, [128] * 4, 10, 'CIFAR10', sd, dtype)
+    img, lab = gu.synthetic_batch(16, 10, seed=1)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(12, 16, 128, seed=2)]
+    m.train(True)
+    if dtype == torch.float32:
+        with torch.no_grad():
+            gen0 = m.generate(lab, zs[0])
+            assert _rel(gen0[:, :, ::4, ::4], d['probe_generated']) < 3e-4
+            assert _rel(m.discriminate(img, lab), d['probe_d_real']) < 3e-4
+        m.load_state_dict(sd)
+    tr = GANTrainer(m, 10)
+    l0 = tr.train_iteration(img, lab, zs[0:6])
+    l1 = tr.train_iteration(img, lab, zs[6:12])
+    np.testing.assert_allclose([float(l0[0]), float(l0[1])], d['losses'][0], rtol=0, atol=tol)
+    np.testing.assert_allclose([float(l1[0]), float(l1[1])], d['losses'][1], rtol=0, atol=max(tol, 2e-3))
+
+
+def test_eval_mode_and_codebook_surgery():
+    """eval-mode generate (running stats, no power iteration) and models.utils.create/transit:
+    the fused path reads the live codebook buffers."""
+    from mcgen_amd.models import utils as mu
+    from mcgen_amd.config import cfg
+    from oracle import mcgan_oracle as O
+    d = gu.load_npz('mcgan_small.npz')
+    m = _build([32] * 4, [16] * 4, 10, 'CIFAR10', gu.state_from_npz(d, 'sd_final/'))
+    m.train(False)
+    lab = torch.from_numpy(d['label']).cuda()
+    z = torch.from_numpy(d['z'][-1]).cuda()
+    img = torch.from_numpy(d['img']).cuda()
+    with torch.no_grad():
+        assert _rel(m.generate(lab, z), d['final_generated_eval']) < 2e-4
+        assert _rel(m.discriminate(img, lab), d['final_d_eval']) < 2e-4
+    before = m.state_dict()['discriminator.blocks.0.conv.0.module.weight_u'].clone()
+    with torch.no_grad():
+        m.discriminate(img, lab)
+    assert torch.equal(before, m.state_dict()['discriminator.blocks.0.conv.0.module.weight_u'])
+    # transit: every MC gets codebook_orig + a spliced codebook; outputs follow the oracle on the same state
+    mu.transit(m, root=2, alpha=0.5)
+    assert 'generator.blocks.0.mc_1.codebook_orig' in m.state_dict()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if 'codebook_orig' not in k}
+    with torch.no_grad():
+        got = m.generate(lab, z)
+        ref = O.generator_forward(sd, z.cpu(), O.one_hot(lab.cpu(), 10), train=False)
+    assert _rel(got, ref) < 2e-4
+    # create: a different number of modes
+    cfg['classes_size'] = 14
+    mu.create(m)
+    assert m.generator.blocks[0].mc_1.codebook.shape == (14, 32)
+    lab14 = torch.arange(14).cuda()
+    z14 = torch.randn(14, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if 'codebook_orig' not in k}
+    with torch.no_grad():
+        got = m.generate(lab14, z14)
+        ref = O.generator_forward(sd, z14.cpu(), O.one_hot(lab14.cpu(), 14), train=False)
+    assert _rel(got, ref) < 2e-4
+    cfg['classes_size'] = 10
+
+
+def test_cpu_tensors_fail_loudly():
+    from mcgen_amd import _lib
+    m = _build([32] * 4, [16] * 4, 10, 'CIFAR10').cpu()
+    with pytest.raises(_lib.McgenError):
+        m.generate(torch.zeros(2, dtype=torch.int64), torch.zeros(2, 128))
+
+
+def test_graphed_trainer_matches_eager():
+    """HIP-graph replay of the D/G updates gives the same losses as the eager step on the same state."""
+    from mcgen_amd.trainer import GANTrainer, GraphedGANTrainer
+    d = gu.load_npz('mcgan_small.npz')
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    m = _build([32] * 4, [16] * 4, 10, 'CIFAR10', gu.state_from_npz(d))
+    tr = GraphedGANTrainer(m, 10)
+    tr.capture(img, lab, warmup=1)
+    torch.manual_seed(0)
+    dl, gl = tr.train_iteration(img, lab)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(dl)) and np.isfinite(float(gl))
+    assert 0.0 < float(dl) < 4.0
+
+
+def _oracle_grads(sd, fn):
+    """Run `fn(oracle_state)` -> scalar loss on the CPU oracle; returns {key: grad}."""
+    from oracle import mcgan_oracle as O
+    st = {k: v.detach().clone() for k, v in sd.items()}
+    keys = O.trainable_keys(st, 'generator.') + O.trainable_keys(st, 'discriminator.')
+    for k in keys:
+        st[k].requires_grad_(True)
+    fn(st).backward()
+    return {k: st[k].grad for k in keys if st[k].grad is not None}
+
+
+@pytest.mark.parametrize('fixture,g_hidden,d_hidden,classes,data_name', [
+    ('mcgan_small.npz', [32] * 4, [16] * 4, 10, 'CIFAR10'),
+    ('mcgan_coil_small.npz', [64, 32, 16, 8], [8, 16, 32, 64], 20, 'COIL100'),
+])
+def test_gradients_vs_oracle(fixture, g_hidden, d_hidden, classes, data_name):
+    """Every parameter gradient of one D loss and one G loss against autograd on the CPU oracle."""
+    from oracle import mcgan_oracle as O
+    import torch.nn.functional as F
+    d = gu.load_npz(fixture)
+    sd = gu.state_from_npz(d)
+    m = _build(g_hidden, d_hidden, classes, data_name, sd)
+    m.train(True)
+    img, lab = torch.from_numpy(d['img']), torch.from_numpy(d['label'])
+    z = torch.from_numpy(d['z'][0])
+    ind = O.one_hot(lab, classes)
+    cifar = data_name == 'CIFAR10'
+
+    def check(got, ref, what):
+        bad = []
+        for k, r in ref.items():
+            g = got[k].cpu()
+            err = float((g - r).abs().max())
+            scale = float(r.abs().max()) + 1e-8
+            if err > 2e-4 * scale + 1e-6:
+                bad.append(f'{k}: err {err:.3e} vs scale {scale:.3e}')
+        assert not bad, what + ' mismatches:\n' + '\n'.join(bad)
+
+    # ---- D loss on real + fake (fake given as a constant image)
+    fake_img = torch.tanh(torch.randn(img.shape, generator=torch.Generator().manual_seed(9)))
+    ref = _oracle_grads(sd, lambda st: torch.relu(1.0 - O.discriminator_forward(st, img, ind, True, cifar_layout=cifar)).mean()
+                        + torch.relu(1.0 + O.discriminator_forward(st, fake_img, ind, True, cifar_layout=cifar)).mean())
+    for p in m.parameters():
+        p.grad = None
+    loss = torch.relu(1.0 - m.discriminate(img.cuda(), lab.cuda())).mean() \
+        + torch.relu(1.0 + m.discriminate(fake_img.cuda(), lab.cuda())).mean()
+    loss.backward()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    check(got, ref, 'D-step')
+    # ---- G loss through D (state restored so both sides start from the same u, v, running stats)
+    m.load_state_dict(sd)
+    ref = _oracle_grads(sd, lambda st: -O.discriminator_forward(
+        st, O.generator_forward(st, z, ind, True), ind, True, cifar_layout=cifar).mean())
+    for p in m.parameters():
+        p.grad = None
+    (-m.discriminate(m.generate(lab.cuda(), z.cuda()), lab.cuda()).mean()).backward()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    check(got, {k: v for k, v in ref.items()}, 'G-step')
