@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the MCGAN CIFAR-10 32x32 (control 0.5) train step.
+
+One "step" = one loop body of the reference's train_gan.py:139-176 on one batch of 128 images per
+GPU: 5 discriminator updates + 1 generator update (hinge loss, 2 x Adam), G [256]*4, D [128]*4,
+10 modes, synthetic U(-1,1) images / uniform labels / N(0,1) latents resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel
+(per-launch HIP-event timing of an instrumented pass of the same step) and a `cpu_baseline` object
+(the CPU oracle timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FLOP_PER_IMAGE = 44.25e9        # dense 2*MAC per image per iteration (5 D + 1 G)
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def build_model(dtype, device):
+    import golden_util as gu
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg, process_control
+    cfg.update(data_name='CIFAR10', model_name='mcgan', device=str(device))
+    cfg['control'] = {'controller_rate': '0.5'}
+    cfg.pop('classes_size', None)
+    process_control()
+    m = models.mcgan()
+    # random-init weights of the reference architecture, identical on every rank (numpy PCG64 stream)
+    sd = gu.procedural_state(gu.mcgan_shapes(cfg['gan']['generator_hidden_size'],
+                                             cfg['gan']['discriminator_hidden_size'], 10), seed=1234, num_mode=10)
+    m.load_state_dict(sd)
+    return m.to(device).set_compute_dtype(dtype), sd
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (a GPU box
+    hands each job a share of a many-core host; oversubscribing it makes the baseline meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get('MCGEN_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(sd, batch, budget_s=40.0):
+    """The CPU oracle (oracle/mcgan_oracle.py, a port pinned to the reference by golden vectors)
+    on this host's cores: one full iteration at the benchmark's batch size."""
+    import golden_util as gu
+    from oracle import mcgan_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    img, lab = gu.synthetic_batch(batch, 10, seed=1)
+    zs = gu.latent_batches(6, batch, 128, seed=2)
+    m = O.OracleMCGAN(sd, classes=10)
+    t0 = time.time()
+    m.train_iteration(img, lab, zs)
+    dt = time.time() - t0
+    return {'value': batch / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 iteration (5 D + 1 G updates) at batch {batch}, fp32, {dt:.1f} s'}
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    from mcgen_amd import ops
+    from mcgen_amd.trainer import GraphedGANTrainer
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    model, sd = build_model(dtype, dev)
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    img = torch.rand(a.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    lab = torch.randint(0, 10, (a.batch,), device=dev, generator=g)
+    torch.manual_seed(100 + rank)
+
+    log('model built')
+    tr = GraphedGANTrainer(model, 10, dist_group=group, world_size=world)
+    if not a.no_graph:
+        tr.capture(img, lab, warmup=1)
+        log('graphs captured')
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.train_iteration(img, lab)
+    barrier()
+    log('warmup done')
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dl, gl = tr.train_iteration(img, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    value = a.batch * world * a.steps / dt
+    log(f'timed region done: {value:.1f} images/s')
+    losses = (float(dl), float(gl))
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        roofline = ops.profile_step(lambda: tr.eager_iteration(img, lab), PEAK_TFLOPS[a.dtype])
+    log('roofline pass done')
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(sd, a.batch)
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (train step) MCGAN CIFAR-10 32x32', 'value': value, 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'MCGAN CIFAR-10 32x32 control=0.5, G [256]*4, D [128]*4, 10 modes, '
+                                   f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}',
+                       'graph_replay': not a.no_graph},
+            'model_flops_per_image': FLOP_PER_IMAGE,
+            'step_mfma_frac': value / world * FLOP_PER_IMAGE / (PEAK_TFLOPS[a.dtype] * 1e12),
+            'last_losses': losses,
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

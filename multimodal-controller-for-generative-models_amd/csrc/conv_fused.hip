@@ -330,6 +330,13 @@ extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
     return (int)((Mtot + t.BM - 1) / t.BM);
 }
 
+extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int* bm, int* bn) {
+    if (!p || !bm || !bn) return mcgen_fail("conv_tile: null pointer");
+    const TilePick t = pick_tile(p);
+    *bm = t.BM; *bn = t.BN;
+    return 0;
+}
+
 extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) {
     if (int rc = validate(p)) return rc;
     // pooling / whole-row tiles need at least two rows per tile

@@ -132,21 +132,33 @@ class GeneratorEngine:
         if not force and key == self._img_key:
             return
         dt = self.dtype
+        dev = lin.weight.device
         c0 = lin.out_features // 16
-        self.img['lin'] = ops.prep_weight(lin.weight.detach(), dt, row_perm=16)
-        self.img['lin_bias'] = lin.bias.detach().view(c0, 16).t().reshape(-1).contiguous()
+
+        def buf(name, numel, dtype):
+            # persistent buffers: a captured HIP graph keeps reading the same addresses
+            t = self.img.get(name)
+            if t is None or t.numel() != numel or t.dtype != dtype or t.device != dev:
+                t = torch.empty(numel, dtype=dtype, device=dev)
+                self.img[name] = t
+            return t
+
+        ops.prep_weight(lin.weight.detach(), dt, row_perm=16,
+                        out=buf('lin', ops.weight_image_elems(lin.out_features, lin.in_features, 1), dt))
+        buf('lin_bias', lin.out_features, torch.float32).view(16, c0).copy_(lin.bias.detach().view(c0, 16).t())
         for i, b in enumerate(res):
             w1, w2, wsc = (b.conv[4].module.weight.detach(), b.conv[8].module.weight.detach(),
                            b.shortcut[2].module.weight.detach())
-            self.img[f'b{i}.w1'] = ops.prep_weight(w1, dt)
+            ops.prep_weight(w1, dt, out=buf(f'b{i}.w1', ops.weight_image_elems(w1.shape[0], w1.shape[1], 3), dt))
             n2 = ops.weight_image_elems(w2.shape[0], w2.shape[1], 3)
             ns = ops.weight_image_elems(wsc.shape[0], wsc.shape[1], 1)
-            buf = torch.empty(n2 + ns, dtype=dt, device=w2.device)
-            ops.prep_weight(w2, dt, out=buf[:n2])
-            ops.prep_weight(wsc, dt, out=buf[n2:])
-            self.img[f'b{i}.w2s'] = buf
-            self.img[f'b{i}.bias2s'] = b.conv[8].module.bias.detach() + b.shortcut[2].module.bias.detach()
-        self.img['head'] = ops.prep_weight(head_conv.weight.detach(), dt)
+            cat = buf(f'b{i}.w2s', n2 + ns, dt)
+            ops.prep_weight(w2, dt, out=cat[:n2])
+            ops.prep_weight(wsc, dt, out=cat[n2:])
+            torch.add(b.conv[8].module.bias.detach(), b.shortcut[2].module.bias.detach(),
+                      out=buf(f'b{i}.bias2s', w2.shape[0], torch.float32))
+        ops.prep_weight(head_conv.weight.detach(), dt,
+                        out=buf('head', ops.weight_image_elems(head_conv.out_channels, head_conv.in_channels, 3), dt))
         self._img_key = key
 
     # ---- forward ---------------------------------------------------------------------------------

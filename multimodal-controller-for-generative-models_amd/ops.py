@@ -47,6 +47,52 @@ def _f32(t: Optional[Tensor]) -> Optional[int]:
     return _p(t)
 
 
+# ---- per-launch profiling (bench.py roofline): HIP events on the launch stream -------------------------
+_PROF = None
+
+
+def _timed(name_fn, flops: float, launch):
+    """Run `launch()`; when profiling is on, bracket it with events on the current stream."""
+    if _PROF is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = launch()
+    e.record()
+    _PROF.append((name_fn(), flops, s, e))
+    return r
+
+
+def profile_step(fn, peak_tflops: float):
+    """Run `fn` once untimed and once with every conv/wgrad launch bracketed by HIP events; returns
+    the `roofline` object for the kernel instantiation with the largest total time: algorithmic
+    FLOPs of its launches / sum of their measured durations."""
+    global _PROF
+    fn()
+    torch.cuda.synchronize()
+    _PROF = []
+    try:
+        fn()
+        torch.cuda.synchronize()
+        rec = _PROF
+    finally:
+        _PROF = None
+    agg = {}
+    for name, flops, s, e in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += s.elapsed_time(e) * 1e-3; a[2] += flops
+    if not agg:
+        return None
+    top = max(agg, key=lambda k: agg[k][1])
+    cnt, secs, flops = agg[top]
+    ach = flops / secs / 1e12
+    return {'bound': 'mfma', 'kernel': top, 'achieved': ach, 'peak': peak_tflops, 'unit': 'TFLOP/s',
+            'frac': ach / peak_tflops, 'traffic': None, 'launches_per_step': cnt,
+            'avg_launch_us': secs / cnt * 1e6, 'flops_per_launch': flops / cnt,
+            'by_kernel': {k: {'launches': v[0], 'total_ms': v[1] * 1e3, 'tflops': v[2] / v[1] / 1e12}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+
+
 def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -180,7 +226,13 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         tiles = lib.mcgen_conv_m_tiles(C.byref(p), _dt(dtype))
         stats = torch.empty((tiles, 2, cy), dtype=torch.float32, device=y.device)
         p.stats = _p(stats)
-    check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused')
+    kflops = 2.0 * n * h * w * cout * sum(s.ksize * s.ksize * s.x.shape[-1] for s in segs)
+
+    def _name():
+        bm, bn = C.c_int(), C.c_int()
+        lib.mcgen_conv_tile(C.byref(p), C.byref(bm), C.byref(bn))
+        return f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}>'
+    _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'))
     return y, stats
 
 
@@ -210,7 +262,9 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
     slabs = torch.empty((splits, elems), dtype=torch.float32, device=dy.device)
     p.slabs = _p(slabs)
-    check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad')
+    _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>',
+           2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
+           lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     check(lib.mcgen_wgrad_reduce(_p(slabs), splits, _f32(grad), cout, cin, seg.ksize, pad16(cout), row_perm,

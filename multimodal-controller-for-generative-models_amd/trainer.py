@@ -75,26 +75,41 @@ class GANTrainer:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             g.mul_(1.0 / self.world)
 
-    def d_update(self, img, ind, z):
+    # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
+    def d_compute(self, img, ind, z):
         d_real, ctx_r = self.deng.forward(img, ind, True)
         fake, _ = self.geng.forward(z, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
         loss, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
         self.deng.backward(ctx_f, dfake, self.grad_d, True, False)
-        self._allreduce(self.grad_d)
-        self.opt_d.step(self.grad_d)
         return loss
 
-    def g_update(self, ind, z):
+    def d_apply(self):
+        self.opt_d.step(self.grad_d)
+
+    def g_compute(self, ind, z):
         fake, gctx = self.geng.forward(z, ind, True)
         d_fake, dctx = self.deng.forward(fake, ind, True)
         loss, dfake = ops.hinge_g(d_fake.view(-1))
         dimg = self.deng.backward(dctx, dfake, None, False, True)
         self.geng.backward(gctx, dimg, self.grad_g, False)
-        self._allreduce(self.grad_g)
+        return loss
+
+    def g_apply(self):
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
+
+    def d_update(self, img, ind, z):
+        loss = self.d_compute(img, ind, z)
+        self._allreduce(self.grad_d)
+        self.d_apply()
+        return loss
+
+    def g_update(self, ind, z):
+        loss = self.g_compute(ind, z)
+        self._allreduce(self.grad_g)
+        self.g_apply()
         return loss
 
     def train_iteration(self, img: torch.Tensor, label: torch.Tensor, zs: Optional[Sequence[torch.Tensor]] = None):
@@ -115,16 +130,16 @@ class GANTrainer:
 
 
 class GraphedGANTrainer(GANTrainer):
-    """Same step, captured once into two HIP graphs (one D update, one G update) and replayed:
-    the step is a few hundred short launches, so replay removes the host launch cost."""
+    """Same step, captured once into HIP graphs and replayed: the step is a few hundred short
+    launches, so replay removes the host launch cost.  Four graphs -- D compute, D apply, G compute,
+    G apply -- so that the gradient all-reduce of a multi-rank run sits BETWEEN replays, on the same
+    stream, and no collective is ever captured."""
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._graphs = None
 
-    def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 2):
-        if self.world > 1:
-            raise RuntimeError('graph capture of the multi-rank step is not supported; use the eager step')
+    def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 1):
         n = img.shape[0]
         dev = img.device
         self.s_img = img.clone()
@@ -134,19 +149,28 @@ class GraphedGANTrainer(GANTrainer):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):
                 self.d_update(self.s_img, self.s_ind, self.s_z)
                 self.g_update(self.s_ind, self.s_z)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.gd, self.gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gd):
+        self.g_dc, self.g_da = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.g_gc, self.g_ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_dc):
             self.s_z.normal_()
-            self.loss_d = self.d_update(self.s_img, self.s_ind, self.s_z)
-        with torch.cuda.graph(self.gg, pool=self.gd.pool()):
+            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z)
+        pool = self.g_dc.pool()
+        with torch.cuda.graph(self.g_da, pool=pool):
+            self.d_apply()
+        with torch.cuda.graph(self.g_gc, pool=pool):
             self.s_z.normal_()
-            self.loss_g = self.g_update(self.s_ind, self.s_z)
+            self.loss_g = self.g_compute(self.s_ind, self.s_z)
+        with torch.cuda.graph(self.g_ga, pool=pool):
+            self.g_apply()
         self._graphs = True
+
+    def eager_iteration(self, img, label):
+        return GANTrainer.train_iteration(self, img, label)
 
     def train_iteration(self, img, label, zs=None):
         if self._graphs is None or zs is not None:
@@ -154,7 +178,11 @@ class GraphedGANTrainer(GANTrainer):
         self.s_img.copy_(img, non_blocking=True)
         self.s_ind.copy_(F.one_hot(label, self.classes).float(), non_blocking=True)
         for _ in range(self.d_iters):
-            self.gd.replay()
+            self.g_dc.replay()
+            self._allreduce(self.grad_d)
+            self.g_da.replay()
         for _ in range(self.g_iters):
-            self.gg.replay()
+            self.g_gc.replay()
+            self._allreduce(self.grad_g)
+            self.g_ga.replay()
         return self.loss_d, self.loss_g
