@@ -109,6 +109,7 @@ typedef struct {
     int32_t dy_ups;        /* 1: dy is the gradient of a 2x2-pooled output                  */
     float*  slabs;
     int32_t splits;
+    float*  bias_slabs;    /* [splits][Cout_w] partial column sums of dy (the bias gradient), or NULL      */
 } mcgen_wgrad_t;
 
 int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p);          /* floats per split */
@@ -118,7 +119,10 @@ int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
  * (the generator's Linear(128 -> C*4*4) viewed as NHWC, mcgan.py:51,67).
  * transpose=0 only (weight gradients are always produced in forward orientation). */
 int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
-                       int Cout_w, int row_perm, float alpha, int accumulate, void* stream);
+                       int Cout_w, int row_perm, float alpha, int accumulate,
+                       const float* bias_slabs, float* bias_grad, float* bias_grad2, void* stream);
+/* bias_slabs/bias_grad (optional): bias_grad[Cout] (+)= alpha * sum_s bias_slabs[s] (same row_perm);
+ * bias_grad2 receives the same values (a second conv that shares dy, e.g. the 1x1 shortcut). */
 
 /* Build the kernel-side weight image from fp32 master weights [Cout][Cin][k][k]:
  *   image[q][tap][co_w][32] (q = input-channel chunk of 32), element type `dtype`,
@@ -175,7 +179,8 @@ int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_laye
  * keeps a snapshot per forward, as torch's hook does by cloning u and v). g_src may equal g_dst.
  * A layer entry with rows == 0 is a plain parameter (bias) of `cols` elements: dst (+)= src. */
 int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
-                      const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate, void* stream);
+                      const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate,
+                      float* workspace /* 32 * nlayers floats */, void* stream);
 
 /* Discriminator tail (mcgan.py:158-165): logit[n] = b + sum_c (w[c]/sigma) * sum_hw relu(x)*code */
 int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b,

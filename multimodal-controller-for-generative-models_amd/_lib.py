@@ -30,7 +30,7 @@ class Wgrad(C.Structure):
     _fields_ = [('seg', Seg), ('dy', C.c_void_p),
                 ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('Cout', C.c_int32), ('Cout_w', C.c_int32), ('Cdy', C.c_int32),
-                ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32)]
+                ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32), ('bias_slabs', C.c_void_p)]
 
 
 class SnLayer(C.Structure):
@@ -48,7 +48,7 @@ SYMBOLS = {
     'mcgen_conv_fused': (_i, [C.POINTER(Conv), _i, _vp]),
     'mcgen_wgrad_slab_elems': (_i64, [C.POINTER(Wgrad)]),
     'mcgen_wgrad': (_i, [C.POINTER(Wgrad), _i, _vp]),
-    'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -61,7 +61,7 @@ SYMBOLS = {
     'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),
     'mcgen_colsum': (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
-    'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -91,19 +91,34 @@ __global__ void mc_apply_kernel(const T* __restrict__ x, const float* __restrict
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------------
-// one thread per channel; partial sums are added in tile order in fp64 (deterministic)
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* rmean, float* rvar, float momentum, float eps,
-                                   float* scale, float* shift, float* mean_o, float* rstd_o) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles; ++t)
-        for (int f = 0; f < fold; ++f) {
-            s1 += (double)part[((size_t)t * 2 + 0) * pitch + f * C + c];
-            s2 += (double)part[((size_t)t * 2 + 1) * pitch + f * C + c];
+// Block = 64 channels (lane = channel, coalesced) x 16 waves that split the partial-sum rows;
+// fp64 accumulation, waves combined in a fixed order (deterministic).
+constexpr int RED_WAVES = 16;
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int rows_total, int pitch, int fold, int C,
+                                                int c, bool live, double& s1, double& s2, double (*sh)[2][64]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (live)
+        for (int r = wave; r < rows_total; r += RED_WAVES) {
+            const int t = r / fold, f = r - t * fold;
+            a += (double)part[((size_t)t * 2 + 0) * pitch + f * C + c];
+            b += (double)part[((size_t)t * 2 + 1) * pitch + f * C + c];
         }
+    sh[wave][0][lane] = a; sh[wave][1][lane] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    for (int w = 0; w < RED_WAVES; ++w) { s1 += sh[w][0][lane]; s2 += sh[w][1][lane]; }
+}
+__global__ __launch_bounds__(64 * RED_WAVES)
+void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
+                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                        float* rmean, float* rvar, float momentum, float eps,
+                        float* scale, float* shift, float* mean_o, float* rstd_o) {
+    __shared__ double sh[RED_WAVES][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1, s2;
+    reduce_partials(part, tiles * fold, pitch, fold, C, c, c < C, s1, s2, sh);
+    if (threadIdx.x >= 64 || c >= C) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -123,15 +138,14 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     const float sc = gamma[c] / sqrtf(rvar[c] + eps);
     scale[c] = sc; shift[c] = beta[c] - rmean[c] * sc;
 }
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int C,
-                                       float* dgamma, float* dbeta, float* sums, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles; ++t) {
-        s1 += (double)part[((size_t)t * 2 + 0) * pitch + c];
-        s2 += (double)part[((size_t)t * 2 + 1) * pitch + c];
-    }
+__global__ __launch_bounds__(64 * RED_WAVES)
+void bn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int C,
+                            float* dgamma, float* dbeta, float* sums, int accumulate) {
+    __shared__ double sh[RED_WAVES][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1, s2;
+    reduce_partials(part, tiles, pitch, 1, C, c, c < C, s1, s2, sh);
+    if (threadIdx.x >= 64 || c >= C) return;
     sums[c] = (float)s1; sums[C + c] = (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
@@ -245,25 +259,45 @@ __global__ void sn_power_iter_kernel(const float* __restrict__ wb, float* uvb, c
         if (tid == 0) sigma[blockIdx.x] = dot_u_wv;
     }
 }
-__global__ void sn_grad_fix_kernel(const float* __restrict__ gsrc, float* gdst, const float* __restrict__ wb,
-                                   const float* __restrict__ uvb, const mcgen_sn_layer_t* __restrict__ layers,
-                                   const float* __restrict__ sigma, int accumulate) {
+constexpr int SNF_CHUNKS = 32;
+// pass 1: partial <G, W> per (layer, chunk)
+__global__ void sn_grad_dot_kernel(const float* __restrict__ gsrc, const float* __restrict__ wb,
+                                   const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ partial) {
     __shared__ float red[32];
     const mcgen_sn_layer_t L = layers[blockIdx.x];
-    const float* G = gsrc + L.w_off; float* D = gdst + L.w_off; const float* W = wb + L.w_off;
-    if (L.rows == 0) {                                         // plain parameter (bias): copy / accumulate
-        for (int i = threadIdx.x; i < L.cols; i += blockDim.x) D[i] = accumulate ? D[i] + G[i] : G[i];
+    if (L.rows == 0) return;
+    const float* G = gsrc + L.w_off; const float* W = wb + L.w_off;
+    const size_t n = (size_t)L.rows * L.cols;
+    const size_t per = (n + SNF_CHUNKS - 1) / SNF_CHUNKS;
+    const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+    float d = 0.f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) d = fmaf(G[i], W[i], d);
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) partial[blockIdx.x * SNF_CHUNKS + blockIdx.y] = d;
+}
+// pass 2: dst (+)= (G - <G, W/sigma> u v^T) / sigma; plain parameters (rows == 0) are moved as they are
+__global__ void sn_grad_apply_kernel(const float* __restrict__ gsrc, float* gdst, const float* __restrict__ uvb,
+                                     const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma,
+                                     const float* __restrict__ partial, int accumulate) {
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* G = gsrc + L.w_off; float* D = gdst + L.w_off;
+    if (L.rows == 0) {
+        const int per = (L.cols + SNF_CHUNKS - 1) / SNF_CHUNKS;
+        const int i0 = blockIdx.y * per, i1 = (i0 + per < L.cols) ? i0 + per : L.cols;
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) D[i] = accumulate ? D[i] + G[i] : G[i];
         return;
     }
     const float* u = uvb + L.u_off; const float* v = uvb + L.v_off;
     const float sg = sigma[blockIdx.x];
-    const size_t n = (size_t)L.rows * L.cols;
     float d = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) d = fmaf(G[i], W[i], d);
-    d = block_sum(d, red) / sg;                                // <G, W_orig / sigma>
+    for (int k = 0; k < SNF_CHUNKS; ++k) d += partial[blockIdx.x * SNF_CHUNKS + k];
+    d /= sg;
     const float inv = 1.f / sg;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int r = (int)(i / L.cols), c = (int)(i % L.cols);
+    const size_t n = (size_t)L.rows * L.cols;
+    const size_t per = (n + SNF_CHUNKS - 1) / SNF_CHUNKS;
+    const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const int r = (int)(i / L.cols), c = (int)(i - (size_t)r * L.cols);
         const float o = (G[i] - d * u[r] * v[c]) * inv;
         D[i] = accumulate ? D[i] + o : o;
     }
@@ -426,7 +460,7 @@ extern "C" int mcgen_bn_finalize(const float* partials, int tiles, int pitch, in
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
                 "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
                        gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
 }
@@ -439,7 +473,7 @@ extern "C" int mcgen_bn_eval_affine(const float* gamma, const float* beta, const
 extern "C" int mcgen_bn_bwd_finalize(const float* partials, int tiles, int pitch, int C, float* dgamma, float* dbeta,
                                      float* sums, int accumulate, void* stream) {
     MCGEN_CHECK(partials && sums && tiles > 0 && pitch >= C, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, dgamma, dbeta, sums, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, C, dgamma, dbeta, sums, accumulate);
     MCGEN_LAUNCH_CHECK("bn_bwd_finalize"); return 0;
 }
 extern "C" int mcgen_bn_bwd_apply(const void* dz, const void* x, const void* add, void* dx, int dtype, int64_t pixels, int C,
@@ -473,9 +507,12 @@ extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mc
     MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
 }
 extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
-                                 const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate, void* stream) {
-    MCGEN_CHECK(g_src && g_dst && w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_grad_fix: bad arguments");
-    hipLaunchKernelGGL(sn_grad_fix_kernel, dim3(nlayers), dim3(512), 0, STREAM(stream), g_src, g_dst, w_base, uv_base, layers_dev, sigma, accumulate);
+                                 const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate,
+                                 float* workspace, void* stream) {
+    MCGEN_CHECK(g_src && g_dst && w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0,
+                "sn_grad_fix: bad arguments (workspace must hold 32 * nlayers floats)");
+    hipLaunchKernelGGL(sn_grad_dot_kernel, dim3(nlayers, SNF_CHUNKS), dim3(256), 0, STREAM(stream), g_src, w_base, layers_dev, workspace);
+    hipLaunchKernelGGL(sn_grad_apply_kernel, dim3(nlayers, SNF_CHUNKS), dim3(256), 0, STREAM(stream), g_src, g_dst, uv_base, layers_dev, sigma, workspace, accumulate);
     MCGEN_LAUNCH_CHECK("sn_grad_fix"); return 0;
 }
 

@@ -72,6 +72,9 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     f32x4 acc[NTAP][2];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // bias gradient = column sums of dy: done by the chunk-0 workgroups on the dy tile they stage anyway
+    const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
+    float bsum = 0.f;                                  // thread (column tid&63, row quarter tid>>6)
 
     for (int tile = blockIdx.z; tile < m_tiles; tile += gridDim.z) {
         const Geo g = make_geo(WG_BM, tile, H, W);
@@ -97,6 +100,12 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
             E::store8(reinterpret_cast<T*>(ldsD + m * DPITCH + sub * 8 * ESZ), v);
         }
         __syncthreads();
+        if (do_bias) {
+            const int col = tid & 63, part = tid >> 6;
+#pragma unroll 8
+            for (int r = 0; r < WG_BM / 4; ++r)
+                bsum += E::to_f(*reinterpret_cast<const T*>(ldsD + (part * (WG_BM / 4) + r) * DPITCH + col * ESZ));
+        }
 
 #pragma unroll 1
         for (int ks = 0; ks < WG_BM / 32; ++ks) {
@@ -152,6 +161,14 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
         }
     }
 
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < p.Cout_w)
+            p.bias_slabs[(size_t)blockIdx.z * p.Cout_w + co0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    }
     // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15]
     const size_t slab_elems = (size_t)gridDim.y * NTAP * p.Cout_w * MCGEN_CK;
     float* out = p.slabs + (size_t)blockIdx.z * slab_elems + (size_t)q * NTAP * p.Cout_w * MCGEN_CK;
@@ -167,27 +184,36 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
             }
 }
 
+// Sums the split slabs in slab order (coalesced reads) and scatters into the master layout.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
                                     float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
-                                    int row_perm, float alpha, int accumulate) {
+                                    int row_perm, float alpha, int accumulate,
+                                    const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
     const int ntap = KS * KS;
-    const size_t total = (size_t)Cout * Cin * ntap;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // i indexes the master layout [co_master][ci][tap]
-        const int tap = (int)(i % ntap);
-        const int ci = (int)((i / ntap) % Cin);
-        const int com = (int)(i / ((size_t)ntap * Cin));
-        int co = com;
-        if (row_perm > 1) {                       // master row c*P + pos  <->  image row pos*Cc + c
-            const int Cc = Cout / row_perm;
-            co = (com % row_perm) * Cc + com / row_perm;
-        }
-        const int q = ci / MCGEN_CK, cl = ci % MCGEN_CK;
-        const size_t off = (((size_t)q * ntap + tap) * Cout_w + co) * MCGEN_CK + cl;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int Cc = row_perm > 1 ? Cout / row_perm : Cout;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < slab_elems; e += stride) {
+        const int cl = (int)(e % MCGEN_CK); size_t t = e / MCGEN_CK;
+        const int co = (int)(t % Cout_w); t /= Cout_w;
+        const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
+        const int ci = q * MCGEN_CK + cl;
+        if (co >= Cout || ci >= Cin) continue;
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_elems + off];
+        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_elems + e];
         s *= alpha;
+        const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;      // image row -> master row
+        const size_t i = ((size_t)com * Cin + ci) * ntap + tap;
         grad[i] = accumulate ? grad[i] + s : s;
+    }
+    if (bias_slabs && bias_grad) {
+        for (size_t co = blockIdx.x * (size_t)blockDim.x + threadIdx.x; co < (size_t)Cout; co += stride) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += bias_slabs[(size_t)z * Cout_w + co];
+            s *= alpha;
+            const int com = row_perm > 1 ? ((int)co % Cc) * row_perm + (int)co / Cc : (int)co;
+            bias_grad[com] = accumulate ? bias_grad[com] + s : s;
+            if (bias_grad2) bias_grad2[com] = accumulate ? bias_grad2[com] + s : s;
+        }
     }
 }
 
@@ -237,15 +263,16 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
 }
 
 extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
-                                  int Cout_w, int row_perm, float alpha, int accumulate, void* stream) {
+                                  int Cout_w, int row_perm, float alpha, int accumulate,
+                                  const float* bias_slabs, float* bias_grad, float* bias_grad2, void* stream) {
     MCGEN_CHECK(slabs && grad && splits >= 1, "wgrad_reduce: bad arguments");
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
     const int nchunk = (round_up(Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
-    const size_t total = (size_t)Cout * Cin * ksize * ksize;
-    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    int blocks = (int)((slab_elems + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate);
+                       slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
+                       bias_slabs, bias_grad, bias_grad2);
     MCGEN_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

@@ -218,9 +218,8 @@ class GeneratorEngine:
         y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
         c_img, c = head_conv.out_channels, head_conv.in_channels
         # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
-        ops.colsum(dtn, c_img, G(head_conv.bias), accumulate=acc)
         seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
-        ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc)
+        ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc, bias_grad=G(head_conv.bias))
         wt = ops.prep_weight(head_conv.weight.detach(), dt, transpose=True)
         dz, part = ops.conv_fused([Seg(dtn)], wt, c, ocode=codeh, gate_x=y, gscale=bnh.scale, gshift=bnh.shift,
                                   gmean=bnh.mean, grstd=bnh.rstd, stats_mode=2)
@@ -233,11 +232,9 @@ class GeneratorEngine:
             bnm1, bnm2 = b.conv[0].module, b.conv[5].module
             ci, co = conv1.in_channels, conv1.out_channels
             # second conv and the 1x1 shortcut both see dy
-            ops.colsum(dy, co, G(conv2.bias), accumulate=acc)
-            ops.colsum(dy, co, G(convs.bias), accumulate=acc)
             seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
             seg_s = Seg(x, ksize=1, code=code1, ups=True)
-            ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc)
+            ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc, bias_grad=G(conv2.bias), bias_grad2=G(convs.bias))
             ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
             w2t = ops.prep_weight(conv2.weight.detach(), dt, transpose=True)
             dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
@@ -245,9 +242,8 @@ class GeneratorEngine:
             dh = ops.bn_backward(part2, dz2, h, bn2.count, bn2.scale, bn2.mean, bn2.rstd,
                                  G(bnm2.weight), G(bnm2.bias), accumulate=acc)
             # first conv: gradient goes through MC, the nearest-upsample adjoint (2x2 sum), ReLU, BN
-            ops.colsum(dh, co, G(conv1.bias), accumulate=acc)
             seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
-            ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc)
+            ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc, bias_grad=G(conv1.bias))
             wst = ops.prep_weight(convs.weight.detach(), dt, transpose=True)
             dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
             w1t = ops.prep_weight(conv1.weight.detach(), dt, transpose=True)
@@ -258,8 +254,8 @@ class GeneratorEngine:
         # linear layer: dy is [N,4,4,C0] == [N,1,1,16*C0] in the permuted row order
         c0 = lin.out_features // 16
         dflat = dy.view(n, 1, 1, 16 * c0)
-        ops.colsum(dflat, 16 * c0, G(lin.bias), row_perm=16, accumulate=acc)
-        ops.wgrad(Seg(ctx['zt'], ksize=1), dflat, 16 * c0, lin.in_features, G(lin.weight), row_perm=16, accumulate=acc)
+        ops.wgrad(Seg(ctx['zt'], ksize=1), dflat, 16 * c0, lin.in_features, G(lin.weight), row_perm=16, accumulate=acc,
+                  bias_grad=G(lin.bias))
 
 
 # ============================================================================================= #
@@ -403,15 +399,13 @@ class DiscriminatorEngine:
             scm = self.sn_of[b.shortcut[1].module] if has_sc else None
             a = 0.25 if pooled else 1.0
             if want_w:
-                ops.colsum(dy, c2m.cout, T(c2m.m.bias))
-                ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a)
+                ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a,
+                          bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias) if has_sc else None)
                 if has_sc:
-                    ops.colsum(dy, scm.cout, T(scm.m.bias))
                     ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
             dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], self._prep(c2m, sigma, True, a), c2m.cin, ocode=code2, gate_x=c1)
             if want_w:
-                ops.colsum(dc1, c1m.cout, T(c1m.m.bias))
-                ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig))
+                ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
             if has_sc:
                 res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], self._prep(scm, sigma, True, a), scm.cin, ocode=code1)
             else:
@@ -422,14 +416,12 @@ class DiscriminatorEngine:
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
         c1, code, img = bc['c1'], bc['code'], ctx['img']
         if want_w:
-            ops.colsum(dy, c2m.cout, T(c2m.m.bias))
-            ops.colsum(dy, scm.cout, T(scm.m.bias))
-            ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25)
+            ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25,
+                      bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias))
             ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
         dc1, _ = ops.conv_fused([Seg(dy, ups=True)], self._prep(c2m, sigma, True, 0.25), c2m.cin, ocode=code, gate_x=c1)
         if want_w:
-            ops.colsum(dc1, c1m.cout, T(c1m.m.bias))
-            ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig))
+            ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
         dimg = None
         if need_input_grad:
             wimg = self._prep_cat(c1m, scm, sigma, transpose=True, scale_b=0.25)

@@ -237,8 +237,10 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
 
 
 def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bool = False,
-          alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None):
-    """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment."""
+          alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None,
+          bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None):
+    """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment; optionally also the bias
+    gradient bias_grad[Cout] (+)= alpha * sum_pixels dy (and a copy into bias_grad2)."""
     n = seg.x.shape[0]
     h = seg.x.shape[1] * (2 if seg.ups else 1)
     w = seg.x.shape[2] * (2 if seg.ups else 1)
@@ -262,13 +264,18 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
     slabs = torch.empty((splits, elems), dtype=torch.float32, device=dy.device)
     p.slabs = _p(slabs)
+    bias_slabs = None
+    if bias_grad is not None:
+        bias_slabs = torch.empty((splits, pad16(cout)), dtype=torch.float32, device=dy.device)
+    p.bias_slabs = _p(bias_slabs)
     _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>',
            2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
            lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     check(lib.mcgen_wgrad_reduce(_p(slabs), splits, _f32(grad), cout, cin, seg.ksize, pad16(cout), row_perm,
-                                 float(alpha), int(accumulate), _stream()), 'wgrad_reduce')
+                                 float(alpha), int(accumulate), _p(bias_slabs), _f32(bias_grad), _f32(bias_grad2),
+                                 _stream()), 'wgrad_reduce')
 
 
 def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
@@ -379,8 +386,9 @@ def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: 
 
 def sn_grad_fix(g_src: Tensor, g_dst: Tensor, w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int,
                 sigma: Tensor, accumulate: bool = False):
+    ws = torch.empty(32 * nlayers, dtype=torch.float32, device=g_src.device)
     check(_lib.load().mcgen_sn_grad_fix(_f32(g_src), _f32(g_dst), _f32(w_base), _f32(uv_base), _p(layers_dev), nlayers,
-                                        _f32(sigma), int(accumulate), _stream()), 'sn_grad_fix')
+                                        _f32(sigma), int(accumulate), _f32(ws), _stream()), 'sn_grad_fix')
 
 
 def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),

@@ -236,8 +236,11 @@ def test_wgrad(case, dtype):
     ref = wt.grad * 0.25
     grad = torch.full((co, ci, ks, ks), 1.0, device='cuda')
     seg = ops.Seg(_nhwc(ops, x, dtype), ksize=ks, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=ups, relu=True)
-    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, alpha=0.25, accumulate=True)
+    bg, bg2 = torch.full((co,), 2.0, device='cuda'), torch.full((co,), 3.0, device='cuda')
+    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, alpha=0.25, accumulate=True, bias_grad=bg, bias_grad2=bg2)
     _assert_close(grad - 1.0, ref, dtype, 'wgrad')
+    _assert_close(bg - 2.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad')
+    _assert_close(bg2 - 3.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad (second output)')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -258,9 +261,11 @@ def test_linear_as_conv_rowperm(dtype):
     dy = _rnd(g, n, c, 4, 4)
     dyt = ops.to_nhwc(dy.cuda(), dtype).view(n, 1, 1, c * 16)
     gw = torch.zeros(c * 16, lat, device='cuda')
-    ops.wgrad(ops.Seg(zt, ksize=1), dyt, c * 16, lat, gw, row_perm=16)
+    gb2 = torch.zeros(c * 16, device='cuda')
+    ops.wgrad(ops.Seg(zt, ksize=1), dyt, c * 16, lat, gw, row_perm=16, bias_grad=gb2)
     refw = _q(dy, dtype).reshape(n, -1).t() @ _q(z, dtype)
     _assert_close(gw, refw, dtype, 'linear wgrad')
+    _assert_close(gb2, _q(dy, dtype).reshape(n, -1).sum(0), dtype, 'linear bias grad fused in wgrad')
     gb = torch.zeros(c * 16, device='cuda')
     ops.colsum(dyt, c * 16, gb, row_perm=16)
     _assert_close(gb, _q(dy, dtype).reshape(n, -1).sum(0), dtype, 'linear bias grad')
