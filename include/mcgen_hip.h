@@ -92,7 +92,7 @@ typedef struct {
 /* number of M tiles (rows of `stats`) the launch of `p` will use */
 int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype);
 /* the (pixels x channels) output tile the launcher will pick for `p` (names the kernel instantiation) */
-int mcgen_conv_tile(const mcgen_conv_t* p, int* bm, int* bn);
+int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn);
 int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream);
 
 /* Weight gradient of the same fused convolution for ONE segment:

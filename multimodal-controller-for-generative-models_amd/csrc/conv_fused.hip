@@ -16,6 +16,7 @@
 // bf16 uses v_mfma_f32_16x16x32_bf16; f32 uses 8 x v_mfma_f32_16x16x4_f32 over the same
 // fragment (exact fp32 FMA chains) -- same LDS images, same epilogue.
 #include "conv_tile.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,21 +28,38 @@ struct ConvCfg {
     static constexpr int ESZ = Elem<T>::BYTES;
     static constexpr int APITCH = MCGEN_CK * ESZ + 16 * ESZ;   // bf16: 96 B (conflict-free b128 reads)
     static constexpr int BROW = MCGEN_CK * ESZ;                // bytes per weight row in LDS
+    static constexpr int BBYTES = BN * BROW;                   // one tap's weight tile
     static constexpr int EP = BN + 4;                          // epilogue pitch in floats
     static constexpr int NI = (BM * 9 + NT - 1) / NT;          // staging items per thread: PP*4 <= BM*2.25*4
+    static constexpr int UPR = BROW / 16;                      // 16-byte units per weight row
+    static constexpr int UNITS = BN * UPR;
+    static constexpr int NU = (UNITS + NT - 1) / NT;           // weight units per thread per tap
+    static constexpr int EPX = (BN >= 128 && BM > 64) ? BM / 64 : 1;             // epilogue passes of >= 64 pixels
+    static constexpr int PPX = BM / EPX;                       // pixels per epilogue pass
+    static constexpr int CH = BN / 8;                          // 8-channel chunks per output pixel
+    static constexpr int PROWS = NT / CH;                      // threads sharing one chunk
+    static_assert(NT % CH == 0, "epilogue thread mapping");
+    static_assert(BM % EPX == 0 && PPX % 16 == 0, "epilogue passes");
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+// Software pipeline (one barrier per tap):
+//   step t reads weights from Bbuf[t&1] and the input window from Abuf[cur];
+//   the weight tile of step t+1 sits in registers (its global loads were issued during step t-1) and is
+//   written to Bbuf[(t+1)&1] after step t's MFMAs; the loads of step t+2 are issued right after;
+//   the NEXT chunk's input window is fetched at the first tap of the current chunk and goes through
+//   the prologue into Abuf[cur^1] at its last tap.
+template <typename T, int BM, int BN, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(64 * WM * WN)
 void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     using E = Elem<T>;
     using M = Mma<T>;
     constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW, EP = C::EP;
+    constexpr int UPR = C::UPR, NU = C::NU;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsA = smem;
-    char* ldsB = smem + a_bytes;
+    char* const ldsA0 = smem;                                   // PIPE: two input-window buffers
+    char* const ldsB0 = smem + (PIPE ? 2 : 1) * a_bytes;        // PIPE: two weight-tile buffers
     float* epi = reinterpret_cast<float*>(smem);
 
     const int tid = threadIdx.x;
@@ -51,10 +69,8 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
     const int l15 = lane & 15, lg = lane >> 4;
 
     const int H = p.H, W = p.W, N = p.N;
-    const int HW = H * W;
     const int tile_m = blockIdx.x;
     const int cout0 = blockIdx.y * BN;
-
     const Geo g = make_geo(BM, blockIdx.x, H, W);
 
     f32x4 acc[FN][FM];
@@ -63,167 +79,255 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const T* wimg = reinterpret_cast<const T*>(p.w);
-    size_t wblock = 0;                                   // running [chunk][tap] block index
-    const size_t wblock_elems = (size_t)p.Cout_w * MCGEN_CK;
-
-    for (int s = 0; s < p.nseg; ++s) {
-        const mcgen_seg_t sg = p.seg[s];
-        const int halo = sg.ksize >> 1;
-        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
-
-        PatchStager<T, NT, C::NI, APITCH> stager;
-        stager.setup(sg, g, N, H, W, tid);
-        // per-lane LDS base of each pixel fragment at tap (0,0)
-        int a_base[FM];
+    // ---- weight-tile staging ---------------------------------------------------------------------
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    int total_steps = 0;
+    for (int s = 0; s < p.nseg; ++s)
+        total_steps += ((p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK) * p.seg[s].ksize * p.seg[s].ksize;
+    int b_goff[NU], b_loff[NU];                    // per-thread global / LDS byte offsets inside a tile
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-            const int m = wm * (BM / WM) + fm * 16 + l15;
-            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
-            const int r = rem >> g.lgW, c = rem & (W - 1);
-            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+    for (int k = 0; k < NU; ++k) {
+        const int u = tid + k * NT;
+        b_goff[k] = -1; b_loff[k] = -1;
+        if (u < C::UNITS) {
+            const int row = u / UPR, gu = u % UPR;
+            const int grp = gu / (ESZ / 2), within = gu % (ESZ / 2);          // 8-channel group
+            const int sw = grp ^ (3 * ((row >> 3) & 1));
+            b_loff[k] = row * BROW + (sw * (ESZ / 2) + within) * 16;
+            if (cout0 + row < p.Cout_w) b_goff[k] = (cout0 + row) * BROW + gu * 16;
         }
+    }
+    u32x4 breg[NU];
+    auto B_load = [&](int blk) {
+        const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            breg[k] = u32x4{0u, 0u, 0u, 0u};
+            if (b_goff[k] >= 0) breg[k] = *reinterpret_cast<const u32x4*>(wb + b_goff[k]);
+        }
+    };
+    auto B_write = [&](char* dst) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (b_loff[k] >= 0) *reinterpret_cast<u32x4*>(dst + b_loff[k]) = breg[k];
+    };
+    int w_row_off[FN];                             // per-lane LDS offset of each weight fragment
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
 
-        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
-        const int ntap = sg.ksize * sg.ksize;
-        for (int q = 0; q < nchunk; ++q) {
-            const int c0 = q * MCGEN_CK;
-            __syncthreads();                                  // previous chunk's MFMA reads are done
-            // ---- stage the input window of this chunk, prologue applied -----------------------
-            stager.stage(sg, c0, ldsA);
-            // ---- taps --------------------------------------------------------------------------
-            for (int tap = 0; tap < ntap; ++tap) {
-                if (tap > 0) __syncthreads();                 // previous tap's weight reads are done
-                {   // stage this tap's weight block rows [cout0, cout0+BN) with the 16B-unit swizzle
-                    const T* wb = wimg + wblock * wblock_elems;
-                    constexpr int UPR = BROW / 16;            // 16-byte units per row
-                    for (int u = tid; u < BN * UPR; u += NT) {
-                        const int row = u / UPR, gu = u % UPR;
-                        u32x4 val = {0u, 0u, 0u, 0u};
-                        if (cout0 + row < p.Cout_w)
-                            val = *reinterpret_cast<const u32x4*>(
-                                reinterpret_cast<const char*>(wb + (size_t)(cout0 + row) * MCGEN_CK) + gu * 16);
-                        const int grp = gu / (ESZ / 2), within = gu % (ESZ / 2);   // 8-channel group
-                        const int sw = grp ^ (3 * ((row >> 3) & 1));
-                        *reinterpret_cast<u32x4*>(ldsB + row * BROW + (sw * (ESZ / 2) + within) * 16) = val;
-                    }
-                }
-                __syncthreads();
-                const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
-                const int tapoff = (kh * PC + kw) * APITCH;
-                typename M::frag af[FM], wf[FN];
+    if constexpr (!PIPE) {
+        // simple form: one window buffer, one weight buffer, two barriers per tap; latency is hidden by
+        // running several workgroups per CU (small LDS / register footprint)
+        int blk = 0;
+        for (int s = 0; s < p.nseg; ++s) {
+            const mcgen_seg_t sg = p.seg[s];
+            const int halo = sg.ksize >> 1;
+            const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+            PatchStager<T, NT, C::NI, APITCH> stager;
+            stager.setup(sg, g, N, H, W, tid);
+            int a_base[FM];
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm)
-                    af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
-#pragma unroll
-                for (int fn = 0; fn < FN; ++fn) {
-                    const int row = wn * (BN / WN) + fn * 16 + l15;
-                    const int sw = lg ^ (3 * ((row >> 3) & 1));
-                    wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + row * BROW + sw * 8 * ESZ);
-                }
-#pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-                    for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
-                ++wblock;
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = wm * (BM / WM) + fm * 16 + l15;
+                const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+                const int r = rem >> g.lgW, c = rem & (W - 1);
+                a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
             }
+            const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+            const int ntap = sg.ksize * sg.ksize;
+#pragma unroll 1
+            for (int q = 0; q < nchunk; ++q) {
+                __syncthreads();                                  // previous chunk's MFMA reads are done
+                stager.stage(sg, q * MCGEN_CK, ldsA0);
+#pragma unroll 1
+                for (int tap = 0; tap < ntap; ++tap) {
+                    if (tap > 0) __syncthreads();                 // previous tap's weight reads are done
+                    B_load(blk);
+                    B_write(ldsB0);
+                    __syncthreads();
+                    const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
+                    const int tapoff = (kh * PC + kw) * APITCH;
+                    typename M::frag af[FM], wf[FN];
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm)
+                        af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA0 + a_base[fm] + tapoff);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+                        wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB0 + w_row_off[fn]);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                    ++blk;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+    int blk = 0, par = 0, acur = 0;
+        B_load(0);
+        B_write(ldsB0);
+        if (total_steps > 1) B_load(1);
+
+        for (int s = 0; s < p.nseg; ++s) {
+            const mcgen_seg_t sg = p.seg[s];
+            const int halo = sg.ksize >> 1;
+            const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+            PatchStager<T, NT, C::NI, APITCH> stager;
+            stager.setup(sg, g, N, H, W, tid);
+            int a_base[FM];                            // per-lane LDS offset of each pixel fragment at tap (0,0)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = wm * (BM / WM) + fm * 16 + l15;
+                const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+                const int r = rem >> g.lgW, c = rem & (W - 1);
+                a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+            }
+            const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+            const int ntap = sg.ksize * sg.ksize;
+            // first chunk of the segment: staged synchronously into the idle window buffer
+            acur ^= 1;
+            stager.stage(sg, 0, ldsA0 + acur * a_bytes);
+            __syncthreads();
+            typename PatchStager<T, NT, C::NI, APITCH>::raw_t araw;
+#pragma unroll 1
+            for (int q = 0; q < nchunk; ++q) {
+                const bool more = (q + 1 < nchunk);
+                const char* ldsA = ldsA0 + acur * a_bytes;
+#pragma unroll 1
+                for (int tap = 0; tap < ntap; ++tap) {
+                    if (tap == 0 && more) stager.load(sg, (q + 1) * MCGEN_CK, araw);
+                    const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
+                    const int tapoff = (kh * PC + kw) * APITCH;
+                    const char* ldsB = ldsB0 + par * C::BBYTES;
+                    typename M::frag af[FM], wf[FN];
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm)
+                        af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+                        wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                    if (blk + 1 < total_steps) {
+                        B_write(ldsB0 + (par ^ 1) * C::BBYTES);
+                        if (blk + 2 < total_steps) B_load(blk + 2);
+                    }
+                    if (tap == ntap - 1 && more) stager.write(sg, (q + 1) * MCGEN_CK, araw, ldsA0 + (acur ^ 1) * a_bytes);
+                    __syncthreads();
+                    par ^= 1; ++blk;
+                }
+                acur ^= 1;
+            }
+            acur ^= 1;                                  // undo the last flip: acur is the buffer read last
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass ----------------
-    __syncthreads();
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-            const int m = wm * (BM / WM) + fm * 16 + l15;
-            const int co = wn * (BN / WN) + fn * 16 + lg * 4;
-            *reinterpret_cast<f32x4*>(epi + m * EP + co) = acc[fn][fm];
-        }
-    __syncthreads();
-
-    constexpr int CH = BN / 8;                 // 8-channel chunks per output pixel
-    constexpr int PROWS = NT / CH;             // threads sharing one chunk
+    // ---- epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass, PPX pixels at a time
+    constexpr int CH = C::CH, PROWS = C::PROWS, PPX = C::PPX;
     const int ch = tid % CH, prow = tid / CH;
     const int co = cout0 + ch * 8;             // first channel of this thread's chunk
-    const int out_pix = p.pool ? (BM >> 2) : BM;
     const int Ho = p.pool ? (H >> 1) : H, Wo = p.pool ? (W >> 1) : W;
     const bool chunk_live = co < p.Cy;
     T* y = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* gx = reinterpret_cast<const T*>(p.gate_x);
 
-    float bias[8], gsc[8], gsh[8], gme[8], grs[8];
+    float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool ok = (co + i) < p.Cout;
-        bias[i] = (p.bias && ok) ? p.bias[co + i] : 0.f;
-        gsc[i] = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
-        gsh[i] = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
-        gme[i] = (p.gmean && ok) ? p.gmean[co + i] : 0.f;
-        grs[i] = (p.grstd && ok) ? p.grstd[co + i] : 0.f;
-    }
+    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && (co + i) < p.Cout) ? p.bias[co + i] : 0.f;
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-
     const int lgWo = p.pool ? g.lgW - 1 : g.lgW;
     const int lgTHWo = p.pool ? g.lgTHW - 2 : g.lgTHW;
-    for (int mo = prow; mo < out_pix; mo += PROWS) {
-        // output pixel mo of the tile -> (ti, ro, wo)
-        const int ti = mo >> lgTHWo, rem = mo & ((1 << lgTHWo) - 1);
-        const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
-        const int n = g.n0 + ti;
-        if (n >= N || !chunk_live) continue;
-        float v[8];
-        if (p.pool) {
-            const int m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo;
-            const float* e0 = epi + m00 * EP + ch * 8;
+    const int out_pp = p.pool ? (PPX >> 2) : PPX;          // output pixels per pass
+
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (e0[i] + e0[EP + i]) + (e0[W * EP + i] + e0[(W + 1) * EP + i]);
-        } else {
-            const float* e0 = epi + mo * EP + ch * 8;
+    for (int pass = 0; pass < C::EPX; ++pass) {
+        if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = e0[i];
-        }
-        const int ho = (p.pool ? (g.h0 >> 1) : g.h0) + ro;
-        const size_t opix = ((size_t)n * Ho + ho) * Wo + wo;
+        for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
-        if (p.ocode) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
-        }
-        if (gx) {
-            float xv[8];
-            E::load8(gx + opix * p.Cy + co, xv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float z = fmaf(xv[i], gsc[i], gsh[i]);
-                v[i] = (z > 0.f) ? v[i] : 0.f;
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m0 = wm * (BM / WM) + fm * 16;
+                if (m0 / PPX == pass) {
+                    const int m = m0 - pass * PPX + l15;
+                    const int cc = wn * (BN / WN) + fn * 16 + lg * 4;
+                    *reinterpret_cast<f32x4*>(epi + m * EP + cc) = acc[fn][fm];
+                }
             }
-            if (p.stats_mode == 2) {
+        __syncthreads();
+        for (int mo = prow; mo < out_pp; mo += PROWS) {
+            // output pixel mo of this pass -> (ti, ro, wo) inside the tile
+            const int mt = pass * out_pp + mo;
+            const int ti = mt >> lgTHWo, rem = mt & ((1 << lgTHWo) - 1);
+            const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
+            const int n = g.n0 + ti;
+            if (n >= N || !chunk_live) continue;
+            float v[8];
+            if (p.pool) {
+                const int m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo - pass * PPX;
+                const float* e0 = epi + m00 * EP + ch * 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme[i]) * grs[i]); }
+                for (int i = 0; i < 8; ++i) v[i] = (e0[i] + e0[EP + i]) + (e0[W * EP + i] + e0[(W + 1) * EP + i]);
+            } else {
+                const float* e0 = epi + mo * EP + ch * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = e0[i];
             }
-        }
-        if (res) {
-            float rv[8];
-            E::load8(res + opix * p.Cy + co, rv);
+            const int ho = (p.pool ? (g.h0 >> 1) : g.h0) + ro;
+            const size_t opix = ((size_t)n * Ho + ho) * Wo + wo;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += rv[i];
-        }
-        if (p.tanh_out) {
+            for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
+            if (p.ocode) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
-        }
+                for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
+            }
+            if (gx) {
+                float xv[8];
+                E::load8(gx + opix * p.Cy + co, xv);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if ((co + i) >= p.Cout) v[i] = 0.f;
-        if (p.stats_mode == 1) {
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (co + i) < p.Cout;
+                    const float gsc = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
+                    const float gsh = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
+                    const float z = fmaf(xv[i], gsc, gsh);
+                    v[i] = (z > 0.f) ? v[i] : 0.f;
+                }
+                if (p.stats_mode == 2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                    for (int i = 0; i < 8; ++i) {
+                        const bool ok = (co + i) < p.Cout;
+                        const float gme = ok ? p.gmean[co + i] : 0.f, grs = ok ? p.grstd[co + i] : 0.f;
+                        s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme) * grs);
+                    }
+                }
+            }
+            if (res) {
+                float rv[8];
+                E::load8(res + opix * p.Cy + co, rv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += rv[i];
+            }
+            if (p.tanh_out) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if ((co + i) >= p.Cout) v[i] = 0.f;
+            if (p.stats_mode == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+            }
+            E::store8(y + opix * p.Cy + co, v);
         }
-        E::store8(y + opix * p.Cy + co, v);
     }
 
     if (p.stats_mode != 0 && p.stats) {
@@ -247,13 +351,28 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-struct TilePick { int BM, BN; };
+struct TilePick { int BM, BN, pipe; };
 
-static TilePick pick_tile(const mcgen_conv_t* p) {
+// Output tile: widest channel tile the layer fills, then the largest pixel tile that still gives
+// every CU a workgroup (256 CUs); fp32 (parity build) is limited by LDS to the two small tiles.
+// MCGEN_CONV_CFG="BM,BN,PIPE" overrides the choice for bf16 launches with Cout_w > 16 (tuning runs).
+static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     const long M = (long)p->N * p->H * p->W;
-    if (p->Cout_w <= 16) return {128, 16};
-    if (M <= 16384 || p->Cout_w <= 64) return {64, 64};
-    return {128, 128};
+    if (p->Cout_w <= 16) return {128, 16, 0};
+    if (dtype == MCGEN_F32) return (M <= 16384 || p->Cout_w <= 64) ? TilePick{64, 64, 0} : TilePick{128, 128, 0};
+    int env_bm = 0, env_bn = 0, env_pipe = 0;
+    if (const char* e = getenv("MCGEN_CONV_CFG")) {
+        if (sscanf(e, "%d,%d,%d", &env_bm, &env_bn, &env_pipe) != 3) env_bm = 0;
+    }
+    const int HW = p->H * p->W;
+    if (env_bm > 0 && ((env_bm >= 2 * p->W) || HW <= env_bm)) return {env_bm, env_bn, env_pipe};
+    // measured on MI355X (tools/bench_conv.py): the two-barrier form at 3-4 workgroups per CU beats the
+    // register-hungry pipelined form; big tiles only where there are enough pixels to fill 256 CUs
+    const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
+    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 0};
+    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 0};
+    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 128, 0};
+    return {64, 64, 0};
 }
 
 static int patch_pixels(const mcgen_conv_t* p, int BM) {
@@ -265,7 +384,7 @@ static int patch_pixels(const mcgen_conv_t* p, int BM) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool PIPE>
 static int launch_cfg(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     const long Mtot = (long)p->N * p->H * p->W;
@@ -274,30 +393,61 @@ static int launch_cfg(const mcgen_conv_t* p, hipStream_t st) {
     const int PP = patch_pixels(p, BM);
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
     int a_bytes = round_up(PP * C::APITCH, 32);
-    int main_bytes = a_bytes + BN * C::BROW;
-    int epi_bytes = BM * C::EP * 4;
-    int red_bytes = (C::NT / (BN / 8)) * BN * 2 * 4;
+    int main_bytes = (PIPE ? 2 : 1) * (a_bytes + C::BBYTES);
+    int epi_bytes = C::PPX * C::EP * 4;
+    int red_bytes = C::PROWS * BN * 2 * 4;
     int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
-    auto kern = conv_fused_kernel<T, BM, BN, WM, WN>;
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        raised = true;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_fused_kernel<T, BM, BN, WM, WN, PIPE>;
+    static int raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+        raised = lds;
     }
     hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
     MCGEN_LAUNCH_CHECK("conv_fused");
     return 0;
 }
 
+typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
+struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
+
 template <typename T>
-static int launch_dtype(const mcgen_conv_t* p, hipStream_t st) {
-    const TilePick t = pick_tile(p);
-    if (t.BN == 16) return launch_cfg<T, 128, 16, 4, 1>(p, st);
-    if (t.BM == 64) return launch_cfg<T, 64, 64, 2, 2>(p, st);
-    return launch_cfg<T, 128, 128, 2, 2>(p, st);
+static const CfgEntry* small_table(int* n) {
+    static const CfgEntry t[] = {
+        {128, 16, 0, launch_cfg<T, 128, 16, 4, 1, false>},
+        {64, 64, 0, launch_cfg<T, 64, 64, 2, 2, false>},
+        {128, 128, 0, launch_cfg<T, 128, 128, 2, 2, false>},
+    };
+    *n = 3;
+    return t;
+}
+static const CfgEntry* bf16_table(int* n) {
+    using T = bf16_t;
+    static const CfgEntry t[] = {
+        {256, 256, 1, launch_cfg<T, 256, 256, 2, 4, true>},  {256, 256, 0, launch_cfg<T, 256, 256, 2, 4, false>},
+        {128, 256, 1, launch_cfg<T, 128, 256, 2, 4, true>},  {128, 256, 0, launch_cfg<T, 128, 256, 2, 4, false>},
+        {64, 256, 1, launch_cfg<T, 64, 256, 1, 4, true>},    {64, 256, 0, launch_cfg<T, 64, 256, 1, 4, false>},
+        {256, 128, 1, launch_cfg<T, 256, 128, 4, 2, true>},  {256, 128, 0, launch_cfg<T, 256, 128, 4, 2, false>},
+        {128, 128, 1, launch_cfg<T, 128, 128, 2, 2, true>},  {128, 128, 0, launch_cfg<T, 128, 128, 2, 2, false>},
+        {64, 128, 1, launch_cfg<T, 64, 128, 2, 2, true>},    {64, 128, 0, launch_cfg<T, 64, 128, 2, 2, false>},
+        {128, 64, 1, launch_cfg<T, 128, 64, 2, 2, true>},    {128, 64, 0, launch_cfg<T, 128, 64, 2, 2, false>},
+        {64, 64, 1, launch_cfg<T, 64, 64, 2, 2, true>},      {64, 64, 0, launch_cfg<T, 64, 64, 2, 2, false>},
+        {128, 16, 0, launch_cfg<T, 128, 16, 4, 1, false>},
+    };
+    *n = (int)(sizeof(t) / sizeof(t[0]));
+    return t;
+}
+
+static int dispatch(const mcgen_conv_t* p, int dtype, const TilePick& t, hipStream_t st) {
+    int n = 0;
+    const CfgEntry* tab = dtype == MCGEN_BF16 ? bf16_table(&n) : small_table<float>(&n);
+    for (int i = 0; i < n; ++i)
+        if (tab[i].BM == t.BM && tab[i].BN == t.BN && tab[i].pipe == t.pipe) return tab[i].fn(p, st);
+    return mcgen_fail("conv_fused: no instantiation for tile %dx%d pipe=%d dtype=%d", t.BM, t.BN, t.pipe, dtype);
 }
 
 static int validate(const mcgen_conv_t* p) {
@@ -323,27 +473,25 @@ static int validate(const mcgen_conv_t* p) {
 }  // namespace
 
 extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
-    (void)dtype;
     if (!p) return 0;
-    const TilePick t = pick_tile(p);
+    const TilePick t = pick_tile(p, dtype);
     const long Mtot = (long)p->N * p->H * p->W;
     return (int)((Mtot + t.BM - 1) / t.BM);
 }
 
-extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int* bm, int* bn) {
+extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn) {
     if (!p || !bm || !bn) return mcgen_fail("conv_tile: null pointer");
-    const TilePick t = pick_tile(p);
+    const TilePick t = pick_tile(p, dtype);
     *bm = t.BM; *bn = t.BN;
     return 0;
 }
 
 extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) {
     if (int rc = validate(p)) return rc;
+    const TilePick t = pick_tile(p, dtype);
     // pooling / whole-row tiles need at least two rows per tile
-    const TilePick t = pick_tile(p);
     MCGEN_CHECK(t.BM >= 2 * p->W || p->H * p->W <= t.BM, "conv_fused: tile of %d pixels too small for W=%d", t.BM, p->W);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MCGEN_F32) return launch_dtype<float>(p, st);
-    if (dtype == MCGEN_BF16) return launch_dtype<bf16_t>(p, st);
-    return mcgen_fail("conv_fused: unknown dtype %d", dtype);
+    if (dtype != MCGEN_F32 && dtype != MCGEN_BF16) return mcgen_fail("conv_fused: unknown dtype %d", dtype);
+    return dispatch(p, dtype, t, st);
 }

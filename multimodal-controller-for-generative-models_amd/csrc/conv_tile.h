@@ -52,24 +52,25 @@ struct PatchStager {
     int it_src[NI];      // element offset of the source pixel (+ sub-chunk), -1 = zero fill
     int it_n[NI];        // image index (row of the code table)
     int it_lds[NI];      // byte offset in the LDS window, -1 = no item
-    int it_sub[NI];      // channel offset inside the chunk: 0, 8, 16, 24
+    int it_sub[1];       // channel offset inside the chunk (0, 8, 16, 24): the same for all items of a thread
 
     __device__ __forceinline__ void setup(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W, int tid) {
         const int halo = sg.ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         const int PP = g.TI * PR * PC;
         const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
+        static_assert(NT % 4 == 0, "items of one thread share the sub-chunk");
+        it_sub[0] = (tid & 3) * 8;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int it = tid + k * NT;
-            it_src[k] = -1; it_lds[k] = -1; it_n[k] = 0; it_sub[k] = 0;
+            it_src[k] = -1; it_lds[k] = -1; it_n[k] = 0;
             if (it < PP * 4) {
                 const int sub = it & 3, pp = it >> 2;
                 const int pc = pp % PC, t2 = pp / PC;
                 const int pr = t2 % PR, ti = t2 / PR;
                 const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;
                 it_lds[k] = pp * APITCH + sub * 8 * E::BYTES;
-                it_sub[k] = sub * 8;
                 it_n[k] = n;
                 if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
                     const int hs = sg.ups ? (h >> 1) : h, ws = sg.ups ? (w >> 1) : w;
@@ -79,16 +80,82 @@ struct PatchStager {
         }
     }
 
+    // raw 8-channel groups fetched by load(), consumed by write(): lets the caller issue the global
+    // loads of the NEXT chunk early and do the prologue + LDS store after the current chunk's MFMAs
+    typedef u32x4 raw_t[NI][E::BYTES / 2];
+
+    __device__ __forceinline__ void load(const mcgen_seg_t& sg, int c0, raw_t& raw) const {
+        const char* xs = reinterpret_cast<const char*>(sg.x);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+#pragma unroll
+            for (int j = 0; j < E::BYTES / 2; ++j) raw[k][j] = u32x4{0u, 0u, 0u, 0u};
+            if (it_lds[k] >= 0 && it_src[k] >= 0 && c0 + it_sub[0] < sg.C) {
+                const char* p = xs + ((size_t)it_src[k] + c0) * E::BYTES;
+#pragma unroll
+                for (int j = 0; j < E::BYTES / 2; ++j) raw[k][j] = *reinterpret_cast<const u32x4*>(p + 16 * j);
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void unpack(const u32x4 (&r)[E::BYTES / 2], float (&v)[8]) {
+        if constexpr (E::BYTES == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = __uint_as_float(r[0][i] << 16);
+                v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = __uint_as_float(r[0][i]); v[4 + i] = __uint_as_float(r[E::BYTES / 2 - 1][i]); }
+        }
+    }
+
+    __device__ __forceinline__ void write(const mcgen_seg_t& sg, int c0, const raw_t& raw, char* ldsA) const {
+        // every item of a thread has the same sub-chunk (NT % 4 == 0), so the BN affine is loaded once
+        const int c = c0 + it_sub[0];
+        const bool cok = c < sg.C;
+        float sc[8], sh[8];
+        if (sg.scale && cok) { load8f(sg.scale + c, sc); load8f(sg.shift + c, sh); }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (it_lds[k] < 0) continue;
+            float v[8];
+            unpack(raw[k], v);
+            if (it_src[k] >= 0 && cok) {
+                if (sg.scale) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (sg.code) {
+                    float cd[8];
+                    load8f(sg.code + (size_t)it_n[k] * sg.C + c, cd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd[i];
+                }
+            }
+            E::store8(reinterpret_cast<T*>(ldsA + it_lds[k]), v);
+            __builtin_amdgcn_sched_barrier(0);          // keep items sequential: bounds the live registers
+        }
+    }
+
+    // non-pipelined form: item by item (load, prologue, LDS store) -- few live registers, so several
+    // workgroups fit on a CU and hide each other's latency
     __device__ __forceinline__ void stage(const mcgen_seg_t& sg, int c0, char* ldsA) const {
         const T* xs = reinterpret_cast<const T*>(sg.x);
+        const int c = c0 + it_sub[0];
+        const bool cok = c < sg.C;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (it_lds[k] < 0) continue;
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = 0.f;
-            const int c = c0 + it_sub[k];
-            if (it_src[k] >= 0 && c < sg.C) {
+            if (it_src[k] >= 0 && cok) {
                 E::load8(xs + (size_t)it_src[k] + c0, v);
                 if (sg.scale) {
                     float sc[8], sh[8];

@@ -184,7 +184,8 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
             }
 }
 
-// Sums the split slabs in slab order (coalesced reads) and scatters into the master layout.
+// Sums the split slabs in slab order (coalesced 16-byte reads, 4 splits in flight) and scatters into
+// the master layout.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
                                     float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                     int row_perm, float alpha, int accumulate,
@@ -192,18 +193,32 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
     const int ntap = KS * KS;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int Cc = row_perm > 1 ? Cout / row_perm : Cout;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < slab_elems; e += stride) {
+    const size_t nvec = slab_elems / 4;
+    for (size_t e4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e4 < nvec; e4 += stride) {
+        const size_t e = e4 * 4;
         const int cl = (int)(e % MCGEN_CK); size_t t = e / MCGEN_CK;
         const int co = (int)(t % Cout_w); t /= Cout_w;
         const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
         const int ci = q * MCGEN_CK + cl;
         if (co >= Cout || ci >= Cin) continue;
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_elems + e];
-        s *= alpha;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 0) * slab_elems + e);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 1) * slab_elems + e);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 2) * slab_elems + e);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 3) * slab_elems + e);
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_elems + e);
         const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;      // image row -> master row
-        const size_t i = ((size_t)com * Cin + ci) * ntap + tap;
-        grad[i] = accumulate ? grad[i] + s : s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ci + j >= Cin) break;
+            const size_t i = ((size_t)com * Cin + ci + j) * ntap + tap;
+            const float v = s[j] * alpha;
+            grad[i] = accumulate ? grad[i] + v : v;
+        }
     }
     if (bias_slabs && bias_grad) {
         for (size_t co = blockIdx.x * (size_t)blockDim.x + threadIdx.x; co < (size_t)Cout; co += stride) {
@@ -269,7 +284,7 @@ extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, i
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
     const int nchunk = (round_up(Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
-    int blocks = (int)((slab_elems + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    int blocks = (int)((slab_elems / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
                        bias_slabs, bias_grad, bias_grad2);

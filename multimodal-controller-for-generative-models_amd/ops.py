@@ -230,7 +230,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
 
     def _name():
         bm, bn = C.c_int(), C.c_int()
-        lib.mcgen_conv_tile(C.byref(p), C.byref(bm), C.byref(bn))
+        lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
         return f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}>'
     _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'))
     return y, stats
@@ -258,7 +258,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     nchunk = (seg.x.shape[-1] + 31) // 32
     if splits is None:
         blocks = ((pad16(cout) + 63) // 64) * nchunk
-        splits = max(1, min(m_tiles, (1024 + blocks - 1) // blocks))
+        splits = max(1, min(m_tiles, (512 + blocks - 1) // blocks, 64))
     p.splits = splits
     lib = _lib.load()
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
