@@ -42,6 +42,134 @@ struct ConvCfg {
     static_assert(BM % EPX == 0 && PPX % 16 == 0, "epilogue passes");
 };
 
+// Shared epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass, PPX pixels at a time.
+template <typename T, typename C, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
+                                              float* epi, int tid, int wm, int wn, int l15, int lg,
+                                              int tile_m, int cout0) {
+    using E = Elem<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, EP = C::EP;
+    const int H = p.H, W = p.W, N = p.N;
+    constexpr int CH = C::CH, PROWS = C::PROWS, PPX = C::PPX;
+    const int ch = tid % CH, prow = tid / CH;
+    const int co = cout0 + ch * 8;             // first channel of this thread's chunk
+    const int Ho = p.pool ? (H >> 1) : H, Wo = p.pool ? (W >> 1) : W;
+    const bool chunk_live = co < p.Cy;
+    T* y = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* gx = reinterpret_cast<const T*>(p.gate_x);
+
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && (co + i) < p.Cout) ? p.bias[co + i] : 0.f;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    const int lgWo = p.pool ? g.lgW - 1 : g.lgW;
+    const int lgTHWo = p.pool ? g.lgTHW - 2 : g.lgTHW;
+    const int out_pp = p.pool ? (PPX >> 2) : PPX;          // output pixels per pass
+
+#pragma unroll
+    for (int pass = 0; pass < C::EPX; ++pass) {
+        if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m0 = wm * (BM / WM) + fm * 16;
+                if (m0 / PPX == pass) {
+                    const int m = m0 - pass * PPX + l15;
+                    const int cc = wn * (BN / WN) + fn * 16 + lg * 4;
+                    *reinterpret_cast<f32x4*>(epi + m * EP + cc) = acc[fn][fm];
+                }
+            }
+        __syncthreads();
+        for (int mo = prow; mo < out_pp; mo += PROWS) {
+            // output pixel mo of this pass -> (ti, ro, wo) inside the tile
+            const int mt = pass * out_pp + mo;
+            const int ti = mt >> lgTHWo, rem = mt & ((1 << lgTHWo) - 1);
+            const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
+            const int n = g.n0 + ti;
+            if (n >= N || !chunk_live) continue;
+            float v[8];
+            if (p.pool) {
+                const int m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo - pass * PPX;
+                const float* e0 = epi + m00 * EP + ch * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (e0[i] + e0[EP + i]) + (e0[W * EP + i] + e0[(W + 1) * EP + i]);
+            } else {
+                const float* e0 = epi + mo * EP + ch * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = e0[i];
+            }
+            const int ho = (p.pool ? (g.h0 >> 1) : g.h0) + ro;
+            const size_t opix = ((size_t)n * Ho + ho) * Wo + wo;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
+            if (p.ocode) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
+            }
+            if (gx) {
+                float xv[8];
+                E::load8(gx + opix * p.Cy + co, xv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (co + i) < p.Cout;
+                    const float gsc = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
+                    const float gsh = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
+                    const float z = fmaf(xv[i], gsc, gsh);
+                    v[i] = (z > 0.f) ? v[i] : 0.f;
+                }
+                if (p.stats_mode == 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bool ok = (co + i) < p.Cout;
+                        const float gme = ok ? p.gmean[co + i] : 0.f, grs = ok ? p.grstd[co + i] : 0.f;
+                        s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme) * grs);
+                    }
+                }
+            }
+            if (res) {
+                float rv[8];
+                E::load8(res + opix * p.Cy + co, rv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += rv[i];
+            }
+            if (p.tanh_out) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if ((co + i) >= p.Cout) v[i] = 0.f;
+            if (p.stats_mode == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+            }
+            E::store8(y + opix * p.Cy + co, v);
+        }
+    }
+
+    if (p.stats_mode != 0 && p.stats) {
+        __syncthreads();                               // everyone is done reading epi
+        float* red = epi;                              // [PROWS][BN][2]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[(prow * BN + ch * 8 + i) * 2 + 0] = s1[i];
+            red[(prow * BN + ch * 8 + i) * 2 + 1] = s2[i];
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < PROWS; ++r) { a += red[(r * BN + c) * 2]; b += red[(r * BN + c) * 2 + 1]; }
+            if (cout0 + c < p.Cy) {
+                p.stats[((size_t)tile_m * 2 + 0) * p.Cy + cout0 + c] = a;
+                p.stats[((size_t)tile_m * 2 + 1) * p.Cy + cout0 + c] = b;
+            }
+        }
+    }
+}
+
 // Software pipeline (one barrier per tap):
 //   step t reads weights from Bbuf[t&1] and the input window from Abuf[cur];
 //   the weight tile of step t+1 sits in registers (its global loads were issued during step t-1) and is
@@ -229,125 +357,365 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass, PPX pixels at a time
-    constexpr int CH = C::CH, PROWS = C::PROWS, PPX = C::PPX;
-    const int ch = tid % CH, prow = tid / CH;
-    const int co = cout0 + ch * 8;             // first channel of this thread's chunk
-    const int Ho = p.pool ? (H >> 1) : H, Wo = p.pool ? (W >> 1) : W;
-    const bool chunk_live = co < p.Cy;
-    T* y = reinterpret_cast<T*>(p.y);
-    const T* res = reinterpret_cast<const T*>(p.res);
-    const T* gx = reinterpret_cast<const T*>(p.gate_x);
+    // ---- epilogue ------------------------------------------------------------------------------
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
 
-    float bias[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && (co + i) < p.Cout) ? p.bias[co + i] : 0.f;
-    float s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    const int lgWo = p.pool ? g.lgW - 1 : g.lgW;
-    const int lgTHWo = p.pool ? g.lgTHW - 2 : g.lgTHW;
-    const int out_pp = p.pool ? (PPX >> 2) : PPX;          // output pixels per pass
+// ---- "direct" form -----------------------------------------------------------------------------
+// Weights never touch LDS: the weight image stores each (chunk, tap) block as [cout][32], so the MFMA
+// A-operand fragment of 16 output channels is one contiguous, L2-resident 1 KB block that a wave loads
+// straight into registers, one tap ahead of its use.  The four waves split the OUTPUT CHANNELS (each wave
+// owns all BM pixels x BN/4 channels), so no weight byte is loaded twice and the only shared data is the
+// input window, double-buffered in LDS: ONE barrier per 32-channel chunk (9 taps of MFMAs) instead of two
+// per tap.  Between barriers a wave issues back-to-back MFMAs with its next weights and the next window
+// in flight.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256)
+void conv_direct_kernel(const mcgen_conv_t p, const int a_bytes) {
+    constexpr int WM = 1, WN = 4;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
 
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA0 = smem;                      // two input-window buffers
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = tid >> 6, wm = 0;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
 #pragma unroll
-    for (int pass = 0; pass < C::EPX; ++pass) {
-        if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn)
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    int total_steps = 0;
+    for (int s = 0; s < p.nseg; ++s)
+        total_steps += ((p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK) * p.seg[s].ksize * p.seg[s].ksize;
+    int w_off[FN];                                 // byte offset of this lane's 8-channel group, -1 = beyond Cout_w
 #pragma unroll
-            for (int fm = 0; fm < FM; ++fm) {
-                const int m0 = wm * (BM / WM) + fm * 16;
-                if (m0 / PPX == pass) {
-                    const int m = m0 - pass * PPX + l15;
-                    const int cc = wn * (BN / WN) + fn * 16 + lg * 4;
-                    *reinterpret_cast<f32x4*>(epi + m * EP + cc) = acc[fn][fm];
-                }
-            }
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = cout0 + wn * (BN / WN) + fn * 16 + l15;
+        w_off[fn] = (row < p.Cout_w) ? row * BROW + lg * 8 * ESZ : -1;
+    }
+    typename M::frag wfc[FN], wfn[FN];
+    auto W_load = [&](int blk, typename M::frag (&dst)[FN]) {
+        const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            typename M::frag z = {};
+            dst[fn] = (w_off[fn] >= 0) ? *reinterpret_cast<const typename M::frag*>(wb + w_off[fn]) : z;
+        }
+    };
+
+    int blk = 0, acur = 0;
+    W_load(0, wfc);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, NT, C::NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+        // first chunk of the segment goes into the idle buffer (last read one chunk ago, a barrier back)
+        acur ^= 1;
+        stager.stage(sg, 0, ldsA0 + acur * a_bytes);
         __syncthreads();
-        for (int mo = prow; mo < out_pp; mo += PROWS) {
-            // output pixel mo of this pass -> (ti, ro, wo) inside the tile
-            const int mt = pass * out_pp + mo;
-            const int ti = mt >> lgTHWo, rem = mt & ((1 << lgTHWo) - 1);
-            const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
-            const int n = g.n0 + ti;
-            if (n >= N || !chunk_live) continue;
-            float v[8];
-            if (p.pool) {
-                const int m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo - pass * PPX;
-                const float* e0 = epi + m00 * EP + ch * 8;
+        typename PatchStager<T, NT, C::NI, APITCH>::raw_t araw;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; ++q) {
+            const bool more = (q + 1 < nchunk);
+            const char* ldsA = ldsA0 + acur * a_bytes;
+#pragma unroll 1
+            for (int tap = 0; tap < ntap; ++tap) {
+                if (tap == 0 && more) stager.load(sg, (q + 1) * MCGEN_CK, araw);
+                if (blk + 1 < total_steps) W_load(blk + 1, wfn);
+                const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
+                const int tapoff = (kh * PC + kw) * APITCH;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = (e0[i] + e0[EP + i]) + (e0[W * EP + i] + e0[(W + 1) * EP + i]);
-            } else {
-                const float* e0 = epi + mo * EP + ch * 8;
+                for (int fm = 0; fm < FM; ++fm) {
+                    const typename M::frag af = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = e0[i];
-            }
-            const int ho = (p.pool ? (g.h0 >> 1) : g.h0) + ro;
-            const size_t opix = ((size_t)n * Ho + ho) * Wo + wo;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
-            if (p.ocode) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
-            }
-            if (gx) {
-                float xv[8];
-                E::load8(gx + opix * p.Cy + co, xv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool ok = (co + i) < p.Cout;
-                    const float gsc = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
-                    const float gsh = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
-                    const float z = fmaf(xv[i], gsc, gsh);
-                    v[i] = (z > 0.f) ? v[i] : 0.f;
+                    for (int fn = 0; fn < FN; ++fn) M::run(wfc[fn], af, acc[fn][fm]);
                 }
-                if (p.stats_mode == 2) {
+                if (tap == ntap - 1 && more) stager.write(sg, (q + 1) * MCGEN_CK, araw, ldsA0 + (acur ^ 1) * a_bytes);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool ok = (co + i) < p.Cout;
-                        const float gme = ok ? p.gmean[co + i] : 0.f, grs = ok ? p.grstd[co + i] : 0.f;
-                        s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme) * grs);
+                for (int fn = 0; fn < FN; ++fn) wfc[fn] = wfn[fn];
+                ++blk;
+            }
+            if (more) { __syncthreads(); acur ^= 1; }
+        }
+    }
+    __syncthreads();                               // all window reads done before LDS becomes the epilogue tile
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
+// ---- "direct ring" form ------------------------------------------------------------------------
+// As the direct form, but the weight fragments live in a rolling ring of RING register slots over the
+// linear (segment, chunk, tap) step sequence: step t consumes slot t % RING and immediately re-issues
+// the load of step t + RING into it, so every weight load has RING taps of MFMAs to land.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256)
+void conv_ring_kernel(const mcgen_conv_t p, const int a_bytes) {
+    constexpr int WM = 1, WN = 4, RING = 9;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA0 = smem;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = tid >> 6, wm = 0;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    int total_steps = 0;
+    for (int s = 0; s < p.nseg; ++s)
+        total_steps += ((p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK) * p.seg[s].ksize * p.seg[s].ksize;
+    int w_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = cout0 + wn * (BN / WN) + fn * 16 + l15;
+        w_off[fn] = (row < p.Cout_w) ? row * BROW + lg * 8 * ESZ : -1;
+    }
+    typename M::frag wf[RING][FN];
+    auto W_load = [&](int blk, typename M::frag (&dst)[FN]) {
+        const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            typename M::frag z = {};
+            dst[fn] = (w_off[fn] >= 0 && blk < total_steps) ? *reinterpret_cast<const typename M::frag*>(wb + w_off[fn]) : z;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RING; ++j) W_load(j, wf[j]);
+
+    // (segment, chunk, tap) state of the current step
+    int seg = 0, q = 0, tap = 0, acur = 0;
+    mcgen_seg_t sg = p.seg[0];
+    int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK, ntap = sg.ksize * sg.ksize;
+    int PC = W + 2 * (sg.ksize >> 1);
+    PatchStager<T, NT, C::NI, APITCH> stager;
+    typename PatchStager<T, NT, C::NI, APITCH>::raw_t araw;
+    int a_base[FM];
+    auto enter_segment = [&]() {
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo;
+        PC = W + 2 * halo;
+        stager.setup(sg, g, N, H, W, tid);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        acur ^= 1;                                   // idle buffer: last read one chunk (a barrier) ago
+        stager.stage(sg, 0, ldsA0 + acur * a_bytes);
+        __syncthreads();
+    };
+    enter_segment();
+
+#pragma unroll 1
+    for (int base = 0; base < total_steps; base += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int blk = base + j;
+            if (blk < total_steps) {
+                const bool more = (q + 1 < nchunk);
+                if (tap == 0 && more) stager.load(sg, (q + 1) * MCGEN_CK, araw);
+                const int kh = (ntap == 9) ? tap / 3 : 0, kw = (ntap == 9) ? tap % 3 : 0;
+                const char* ldsA = ldsA0 + acur * a_bytes + (kh * PC + kw) * APITCH;
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    const typename M::frag af = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm]);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn) M::run(wf[j][fn], af, acc[fn][fm]);
+                }
+                W_load(blk + RING, wf[j]);           // same slot, RING steps ahead
+                if (tap == ntap - 1) {
+                    if (more) {
+                        stager.write(sg, (q + 1) * MCGEN_CK, araw, ldsA0 + (acur ^ 1) * a_bytes);
+                        __syncthreads();
+                        acur ^= 1; ++q; tap = 0;
+                    } else if (seg + 1 < p.nseg) {
+                        ++seg; sg = p.seg[seg];
+                        nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK; ntap = sg.ksize * sg.ksize;
+                        q = 0; tap = 0;
+                        enter_segment();
                     }
+                } else {
+                    ++tap;
                 }
             }
-            if (res) {
-                float rv[8];
-                E::load8(res + opix * p.Cy + co, rv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += rv[i];
-            }
-            if (p.tanh_out) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if ((co + i) >= p.Cout) v[i] = 0.f;
-            if (p.stats_mode == 1) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
-            }
-            E::store8(y + opix * p.Cy + co, v);
         }
+    }
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
+// ---- "dma" form ---------------------------------------------------------------------------------
+// The two-barrier form with the weight tiles moved by LDS-DMA (global_load_lds, no VGPR round trip) into
+// a ring of RB tap slots, DIST taps ahead of their use: per tap ONE raw s_barrier behind a counted vmcnt.
+// The DMA writes LDS linearly (wave base + lane*16), so the bank swizzle is applied to the SOURCE address.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_dma_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+    constexpr int RB = 3, DIST = 2;                        // ring slots, prefetch distance (taps)
+    constexpr int NW = WM * WN;
+    constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
+    constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
+    static_assert(DIST == 2 && PPW <= 2, "vmcnt immediates below assume DIST 2 and <= 2 pieces per wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    int total_steps = 0;
+    for (int s = 0; s < p.nseg; ++s)
+        total_steps += ((p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK) * p.seg[s].ksize * p.seg[s].ksize;
+
+    // DMA piece k of this wave: 1 KB = rows [16*ESZ/2 rows...]; lane -> (row, physical 16-byte unit)
+    constexpr int UPR = C::UPR;                            // 16-byte units per row (4 bf16 / 8 fp32)
+    constexpr int RPP = 64 / UPR;                          // rows per 1 KB piece
+    int d_src[PPW];                                        // per-lane source byte offset inside a weight block, -1 = zero rows
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+        const int lgrp = grp ^ (3 * ((row >> 3) & 1));     // logical 8-channel group stored at this physical slot
+        d_src[k] = (piece < KB && cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : -1;
+    }
+    auto B_dma = [&](int blk) {
+        if (blk >= total_steps) return;
+        const char* wb = wimg + (size_t)blk * wblock_bytes;
+        char* slot = ldsB0 + (blk % RB) * C::BBYTES;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = wave * PPW + k;
+            if (piece < KB) {
+                // rows beyond Cout_w read row 0 of the block (in bounds); their outputs are never stored
+                const char* src = wb + (d_src[k] >= 0 ? d_src[k] : (lane % UPR) * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
     }
 
-    if (p.stats_mode != 0 && p.stats) {
-        __syncthreads();                               // everyone is done reading epi
-        float* red = epi;                              // [PROWS][BN][2]
+    int blk = 0;
+    B_dma(0);
+    B_dma(1);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, NT, C::NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            red[(prow * BN + ch * 8 + i) * 2 + 0] = s1[i];
-            red[(prow * BN + ch * 8 + i) * 2 + 1] = s2[i];
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
         }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            float a = 0.f, b = 0.f;
-            for (int r = 0; r < PROWS; ++r) { a += red[(r * BN + c) * 2]; b += red[(r * BN + c) * 2 + 1]; }
-            if (cout0 + c < p.Cy) {
-                p.stats[((size_t)tile_m * 2 + 0) * p.Cy + cout0 + c] = a;
-                p.stats[((size_t)tile_m * 2 + 1) * p.Cy + cout0 + c] = b;
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; ++q) {
+            // window of this chunk: everyone is past the previous chunk's reads (barrier), then publish
+            __builtin_amdgcn_s_barrier();
+            stager.stage(sg, q * MCGEN_CK, ldsA);
+#pragma unroll 1
+            for (int tap = 0; tap < ntap; ++tap) {
+                // this tap's weight tile has landed (this wave's pieces), then all waves' pieces + window writes
+                if (blk + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                B_dma(blk + DIST);                       // slot (blk+2)%3 == (blk-1)%3: its readers passed the barrier
+                const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
+                const int tapoff = (kh * PC + kw) * APITCH;
+                const char* ldsB = ldsB0 + (blk % RB) * C::BBYTES;
+                typename M::frag af[FM], wf[FN];
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                ++blk;
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -366,13 +734,15 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     }
     const int HW = p->H * p->W;
     if (env_bm > 0 && ((env_bm >= 2 * p->W) || HW <= env_bm)) return {env_bm, env_bn, env_pipe};
-    // measured on MI355X (tools/bench_conv.py): the two-barrier form at 3-4 workgroups per CU beats the
-    // register-hungry pipelined form; big tiles only where there are enough pixels to fill 256 CUs
+    // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring ("dma" form, mode 4)
+    // wins on every shape; big tiles only where there are enough pixels to fill 256 CUs, and the
+    // epilogue-heavy gradient launches (gate + BN-backward sums) prefer more, smaller workgroups
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
-    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 0};
-    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 0};
-    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 128, 0};
-    return {64, 64, 0};
+    if (M >= 65536 && rows256 && p->Cout_w > 128 && !p->gate_x) return {256, 256, 4};
+    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 4};
+    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 128, 4};
+    if (M >= 32768 && p->Cout_w > 64) return {64, 128, 4};
+    return {64, 64, 4};
 }
 
 static int patch_pixels(const mcgen_conv_t* p, int BM) {
@@ -412,6 +782,58 @@ static int launch_cfg(const mcgen_conv_t* p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int BM, int BN, bool RINGED>
+static int launch_direct(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<T, BM, BN, 1, 4>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)((Mtot + BM - 1) / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
+    const int a_bytes = round_up(PP * C::APITCH, 32);
+    int lds = 2 * a_bytes;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = RINGED ? conv_ring_kernel<T, BM, BN> : conv_direct_kernel<T, BM, BN>;
+    static int raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+        raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(direct)");
+    return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)((Mtot + BM - 1) / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
+    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    int lds = a_bytes + 3 * C::BBYTES;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_dma_kernel<T, BM, BN, WM, WN>;
+    static int raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+        raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(dma)");
+    return 0;
+}
+
 typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
 struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
 
@@ -437,6 +859,16 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 64, 1, launch_cfg<T, 128, 64, 2, 2, true>},    {128, 64, 0, launch_cfg<T, 128, 64, 2, 2, false>},
         {64, 64, 1, launch_cfg<T, 64, 64, 2, 2, true>},      {64, 64, 0, launch_cfg<T, 64, 64, 2, 2, false>},
         {128, 16, 0, launch_cfg<T, 128, 16, 4, 1, false>},
+        {128, 256, 2, launch_direct<T, 128, 256, false>}, {128, 128, 2, launch_direct<T, 128, 128, false>},
+        {64, 256, 2, launch_direct<T, 64, 256, false>},   {64, 128, 2, launch_direct<T, 64, 128, false>},
+        {128, 64, 2, launch_direct<T, 128, 64, false>},   {64, 64, 2, launch_direct<T, 64, 64, false>},
+        {256, 128, 2, launch_direct<T, 256, 128, false>}, {256, 64, 2, launch_direct<T, 256, 64, false>},
+        {256, 256, 4, launch_dma<T, 256, 256, 2, 4>}, {128, 256, 4, launch_dma<T, 128, 256, 2, 4>},
+        {256, 128, 4, launch_dma<T, 256, 128, 4, 2>}, {128, 128, 4, launch_dma<T, 128, 128, 2, 2>},
+        {64, 128, 4, launch_dma<T, 64, 128, 2, 2>},   {64, 64, 4, launch_dma<T, 64, 64, 2, 2>},
+        {128, 256, 3, launch_direct<T, 128, 256, true>}, {128, 128, 3, launch_direct<T, 128, 128, true>},
+        {64, 256, 3, launch_direct<T, 64, 256, true>},   {64, 128, 3, launch_direct<T, 64, 128, true>},
+        {128, 64, 3, launch_direct<T, 128, 64, true>},   {64, 64, 3, launch_direct<T, 64, 64, true>},
     };
     *n = (int)(sizeof(t) / sizeof(t[0]));
     return t;

@@ -46,7 +46,7 @@ static __device__ __forceinline__ Geo make_geo(int BM, int tile_m, int H, int W)
 // [window pixel][32 channels] with pitch APITCH, applying the segment's prologue:
 // nearest-x2 upsample by index, BatchNorm scale/shift, ReLU, MultimodalController code.
 // Out-of-image pixels and channels beyond C are written as zeros (the conv's zero padding).
-template <typename T, int NT, int NI, int APITCH>
+template <typename T, int NT, int NI, int APITCH, int SUBS = 4>
 struct PatchStager {
     using E = Elem<T>;
     int it_src[NI];      // element offset of the source pixel (+ sub-chunk), -1 = zero fill
@@ -59,14 +59,14 @@ struct PatchStager {
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         const int PP = g.TI * PR * PC;
         const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
-        static_assert(NT % 4 == 0, "items of one thread share the sub-chunk");
-        it_sub[0] = (tid & 3) * 8;
+        static_assert(NT % SUBS == 0, "items of one thread share the sub-chunk");
+        it_sub[0] = (tid % SUBS) * 8;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int it = tid + k * NT;
             it_src[k] = -1; it_lds[k] = -1; it_n[k] = 0;
-            if (it < PP * 4) {
-                const int sub = it & 3, pp = it >> 2;
+            if (it < PP * SUBS) {
+                const int sub = it % SUBS, pp = it / SUBS;
                 const int pc = pp % PC, t2 = pp / PC;
                 const int pr = t2 % PR, ti = t2 / PR;
                 const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;

@@ -15,28 +15,17 @@ namespace {
 
 constexpr int WG_BM = 128;     // pixels per K tile
 constexpr int WG_BCO = 64;     // output channels per workgroup
+constexpr int WG_CI = 32;      // input channels per workgroup (one 32-channel chunk of the weight image)
 constexpr int WG_NT = 256;
 
 template <typename T> struct WgTraits;
 template <> struct WgTraits<float> {
-    static constexpr int APITCH = MCGEN_CK * 4 + 16;     // rows stay 16-byte aligned for the staging stores
+    static constexpr int APITCH = WG_CI * 4 + 16;        // rows stay 16-byte aligned for the staging stores
     static constexpr int DPITCH = WG_BCO * 4 + 16;
 };
 template <> struct WgTraits<bf16_t> {
-    static constexpr int APITCH = MCGEN_CK * 2 + 16;     // 80 B: rows 8-byte aligned for the tr read
+    static constexpr int APITCH = WG_CI * 2 + 16;        // 144 B: rows 8-byte aligned for the tr read
     static constexpr int DPITCH = WG_BCO * 2 + 16;       // 144 B
-};
-
-// fragment of 8 k-values (pixels) for channel `col16 + lane&15`, rows given by byte offsets
-template <typename T> struct KFrag;
-template <> struct KFrag<float> {
-    // off8[j]: byte offset of pixel j's row; reads one float per pixel
-    static __device__ __forceinline__ f32x8 read(const char* base, const int (&off8)[8], int col_bytes) {
-        f32x8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const float*>(base + off8[j] + col_bytes);
-        return r;
-    }
 };
 
 static __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
@@ -44,15 +33,46 @@ static __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
         (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
 }
 
+// One MFMA operand fragment with k = 8 consecutive tile pixels (lane group lg) and 16 channels
+// (lane & 15) read from an LDS image laid out [pixel][channel]: bf16 by two transposing reads
+// (lane (q4, p4) supplies the address of pixel 4*half + q4, channels 4*p4..4*p4+3), fp32 by 8 scalar reads.
+template <typename T> struct KFrag;
+template <> struct KFrag<bf16_t> {
+    typedef bf16x8 frag;
+    // off2[h]: byte offset of this lane's row for half h (already includes the 8-byte column part)
+    static __device__ __forceinline__ frag read(const char* base, const int (&off)[8], int col_bytes16) {
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = lds_tr16(base + off[0] + col_bytes16);
+        u.h[1] = lds_tr16(base + off[1] + col_bytes16);
+        return u.v;
+    }
+};
+template <> struct KFrag<float> {
+    typedef f32x8 frag;
+    static __device__ __forceinline__ frag read(const char* base, const int (&off)[8], int col_bytes16) {
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const float*>(base + off[j] + col_bytes16);
+        return r;
+    }
+};
+
+// Workgroup = 64 output channels x 32 input channels x all taps.  Waves are a 2 x 2 grid:
+// wave (a, b) owns output-channel fragments {2a, 2a+1} and input-channel block b for every tap, so per
+// 32-pixel step it reads 2 dy fragments + NTAP window fragments for 2*NTAP MFMAs (small footprint:
+// 72 accumulator registers, ~35 KB LDS -> four workgroups per CU hide each other's staging latency).
 template <typename T, int KS>
-__global__ __launch_bounds__(WG_NT)
+__global__ __launch_bounds__(WG_NT, 3)
 void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
     constexpr int ESZ = E::BYTES, APITCH = TR::APITCH, DPITCH = TR::DPITCH;
     constexpr int NTAP = KS * KS;
-    constexpr int NI = (WG_BM * 9 + WG_NT - 1) / WG_NT;
+    constexpr int NPAIR = NTAP;                       // taps (this wave's ci block is fixed)
+    constexpr int NCF = WG_BCO / 32;                  // output-channel fragments per wave
+    constexpr int SUBS = WG_CI / 8;
+    constexpr int NI = (WG_BM * 9 * SUBS / 4 + WG_NT - 1) / WG_NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
@@ -62,24 +82,27 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, N = p.N;
     const int co0 = blockIdx.x * WG_BCO;
-    const int q = blockIdx.y;                       // input-channel chunk
-    const int c0 = q * MCGEN_CK;
+    const int c0 = blockIdx.y * WG_CI;
     const mcgen_seg_t sg = p.seg;
     const int halo = KS >> 1;
     const T* dy = reinterpret_cast<const T*>(p.dy);
     const int Hd = p.dy_ups ? (H >> 1) : H, Wd = p.dy_ups ? (W >> 1) : W;
 
-    f32x4 acc[NTAP][2];
+    f32x4 acc[NPAIR][NCF];
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    // bias gradient = column sums of dy: done by the chunk-0 workgroups on the dy tile they stage anyway
-    const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
+    for (int j = 0; j < NPAIR; ++j)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of dy: done by the ci-tile-0 workgroups on the dy tile they stage anyway
+    const bool do_bias = (p.bias_slabs != nullptr) && (blockIdx.y == 0);
     float bsum = 0.f;                                  // thread (column tid&63, row quarter tid>>6)
+
+    const int wa = wave >> 1, wb = wave & 1;          // output-channel half, input-channel block
 
     for (int tile = blockIdx.z; tile < m_tiles; tile += gridDim.z) {
         const Geo g = make_geo(WG_BM, tile, H, W);
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
-        PatchStager<T, WG_NT, NI, APITCH> stager;
+        PatchStager<T, WG_NT, NI, APITCH, SUBS> stager;
         stager.setup(sg, g, N, H, W, tid);
         __syncthreads();                                        // previous tile's reads are done
         stager.stage(sg, c0, ldsA);
@@ -109,54 +132,37 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
 
 #pragma unroll 1
         for (int ks = 0; ks < WG_BM / 32; ++ks) {
+            // byte offsets of this lane's k rows (pixels ks*32 + 8*lg ...) in the window and in the dy tile
+            int offA[8], offD[8];
             if constexpr (sizeof(T) == 4) {
-                // fp32: lane group lg covers pixels ks*32 + 8*lg + j, j = 0..7
-                int offA[8], offD[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int m = ks * 32 + lg * 8 + j;
                     const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
                     const int r = rem >> g.lgW, c = rem & (W - 1);
-                    offA[j] = ((ti * PR + r) * PC + c) * APITCH;
-                    offD[j] = m * DPITCH;
-                }
-                const f32x8 dfrag = KFrag<float>::read(ldsD, offD, (wave * 16 + l15) * 4);
-#pragma unroll
-                for (int tap = 0; tap < NTAP; ++tap) {
-                    const int tapoff = ((tap / KS) * PC + (tap % KS)) * APITCH;
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const f32x8 afrag = KFrag<float>::read(ldsA + tapoff, offA, (f * 16 + l15) * 4);
-                        M::run(dfrag, afrag, acc[tap][f]);
-                    }
+                    offA[j] = ((ti * PR + r) * PC + c) * APITCH + l15 * 4;
+                    offD[j] = m * DPITCH + l15 * 4;
                 }
             } else {
-                // bf16: two transposing reads per fragment; lane (q4 = l15>>2, p4 = l15&3) supplies the
-                // address of pixel 8*lg + 4*half + q4, channels 4*p4 .. 4*p4+3 of the 16-channel block
                 const int q4 = l15 >> 2, p4 = l15 & 3;
-                int offA2[2], offD2[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int m = ks * 32 + lg * 8 + hf * 4 + q4;
                     const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
                     const int r = rem >> g.lgW, c = rem & (W - 1);
-                    offA2[hf] = ((ti * PR + r) * PC + c) * APITCH + p4 * 8;
-                    offD2[hf] = m * DPITCH + p4 * 8;
+                    offA[hf] = ((ti * PR + r) * PC + c) * APITCH + p4 * 8;
+                    offD[hf] = m * DPITCH + p4 * 8;
                 }
-                union { bf16x8 v; s16x4 h[2]; } dfrag;
-                dfrag.h[0] = lds_tr16(ldsD + offD2[0] + wave * 32);
-                dfrag.h[1] = lds_tr16(ldsD + offD2[1] + wave * 32);
+            }
+            typename M::frag dfrag[NCF];
 #pragma unroll
-                for (int tap = 0; tap < NTAP; ++tap) {
-                    const int tapoff = ((tap / KS) * PC + (tap % KS)) * APITCH;
+            for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KFrag<T>::read(ldsD, offD, (wa * NCF + cf) * 16 * ESZ);
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        union { bf16x8 v; s16x4 h[2]; } afrag;
-                        afrag.h[0] = lds_tr16(ldsA + tapoff + offA2[0] + f * 32);
-                        afrag.h[1] = lds_tr16(ldsA + tapoff + offA2[1] + f * 32);
-                        acc[tap][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag.v, afrag.v, acc[tap][f], 0, 0, 0);
-                    }
-                }
+            for (int j = 0; j < NPAIR; ++j) {
+                const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;
+                const typename M::frag afrag = KFrag<T>::read(ldsA + tapoff, offA, wb * 16 * ESZ);
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf) M::run(dfrag[cf], afrag, acc[j][cf]);
             }
         }
     }
@@ -169,19 +175,23 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
         if (tid < 64 && co0 + tid < p.Cout_w)
             p.bias_slabs[(size_t)blockIdx.z * p.Cout_w + co0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
     }
-    // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15]
-    const size_t slab_elems = (size_t)gridDim.y * NTAP * p.Cout_w * MCGEN_CK;
-    float* out = p.slabs + (size_t)blockIdx.z * slab_elems + (size_t)q * NTAP * p.Cout_w * MCGEN_CK;
+    // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15] of block (tap j, co fragment cf)
+    const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
+    float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
+    const int q = blockIdx.y;
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap)
+    for (int j = 0; j < NPAIR; ++j) {
+        const int col = wb * 16 + l15;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int cf = 0; cf < NCF; ++cf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wave * 16 + lg * 4 + r;
+                const int co = co0 + (wa * NCF + cf) * 16 + lg * 4 + r;
                 if (co < p.Cout_w)
-                    out[((size_t)tap * p.Cout_w + co) * MCGEN_CK + f * 16 + l15] = acc[tap][f][r];
+                    out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r];
             }
+    }
 }
 
 // Sums the split slabs in slab order (coalesced 16-byte reads, 4 splits in flight) and scatters into
@@ -242,7 +252,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int PP = mcgen_patch_pixels(WG_BM, p->H, p->W, KS);
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
-    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, (p->seg.C + WG_CI - 1) / WG_CI, p->splits);
     auto kern = wgrad_kernel<T, KS>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
