@@ -59,9 +59,18 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* gx = reinterpret_cast<const T*>(p.gate_x);
 
-    float bias[8];
+    // per-thread channel vectors (this thread always handles the same 8 channels)
+    const bool vec_ok = (p.Cout % 8 == 0) && (co + 8 <= p.Cout);
+    float bias[8], gsc[8], gsh[8], gme[8], grs[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && (co + i) < p.Cout) ? p.bias[co + i] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = (co + i) < p.Cout;
+        bias[i] = (p.bias && ok) ? p.bias[co + i] : 0.f;
+        gsc[i] = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
+        gsh[i] = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
+        gme[i] = (p.gmean && ok) ? p.gmean[co + i] : 0.f;
+        grs[i] = (p.grstd && ok) ? p.grstd[co + i] : 0.f;
+    }
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -107,27 +116,27 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
             if (p.ocode) {
+                if (vec_ok) {
+                    float oc[8];
+                    load8f(p.ocode + (size_t)n * p.Cout + co, oc);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
+                    for (int i = 0; i < 8; ++i) v[i] *= oc[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= ((co + i) < p.Cout) ? p.ocode[(size_t)n * p.Cout + co + i] : 0.f;
+                }
             }
             if (gx) {
                 float xv[8];
                 E::load8(gx + opix * p.Cy + co, xv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const bool ok = (co + i) < p.Cout;
-                    const float gsc = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
-                    const float gsh = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
-                    const float z = fmaf(xv[i], gsc, gsh);
+                    const float z = fmaf(xv[i], gsc[i], gsh[i]);
                     v[i] = (z > 0.f) ? v[i] : 0.f;
                 }
                 if (p.stats_mode == 2) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool ok = (co + i) < p.Cout;
-                        const float gme = ok ? p.gmean[co + i] : 0.f, grs = ok ? p.grstd[co + i] : 0.f;
-                        s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme) * grs);
-                    }
+                    for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * ((xv[i] - gme[i]) * grs[i]); }
                 }
             }
             if (res) {
@@ -735,10 +744,9 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     const int HW = p->H * p->W;
     if (env_bm > 0 && ((env_bm >= 2 * p->W) || HW <= env_bm)) return {env_bm, env_bn, env_pipe};
     // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring ("dma" form, mode 4)
-    // wins on every shape; big tiles only where there are enough pixels to fill 256 CUs, and the
-    // epilogue-heavy gradient launches (gate + BN-backward sums) prefer more, smaller workgroups
+    // wins on every shape; big tiles only where there are enough pixels to fill 256 CUs
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
-    if (M >= 65536 && rows256 && p->Cout_w > 128 && !p->gate_x) return {256, 256, 4};
+    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 4};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 4};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 128, 4};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 4};
