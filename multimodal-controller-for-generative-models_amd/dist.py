@@ -1,0 +1,46 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).  The reference's only multi-GPU mode is single-process
+nn.DataParallel (train_gan.py:96-98): replicas share weights, see disjoint batch shards, keep
+per-replica BatchNorm statistics, and their gradients are summed onto device 0.  Here every rank owns
+a replica; the flat gradient buffer of the network being updated is averaged with ONE all-reduce
+(4.2 MB for D, 17.1 MB for G at CIFAR-10 sizes), then every rank applies the same Adam step.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+    Returns (rank, world, local_rank); world == 1 without the variables (no group is created)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def allreduce_mean_(flat: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """In-place average of one flat gradient bucket over the ranks (no-op for world == 1)."""
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+    return flat
+
+
+def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers (the reference replicates
+    device 0's module, and keeps device 0's running statistics / u, v)."""
+    for t in tensors:
+        dist.broadcast(t.data, src, group=group)

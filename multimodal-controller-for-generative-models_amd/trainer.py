@@ -71,9 +71,8 @@ class GANTrainer:
     # ---- data-parallel gradient exchange: one flat bucket per network ----------------------------
     def _allreduce(self, g: torch.Tensor):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world)
+            from .dist import allreduce_mean_
+            allreduce_mean_(g, self.world, self.group)
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
     def d_compute(self, img, ind, z):

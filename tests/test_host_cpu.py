@@ -1,0 +1,154 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the
+module tree matches the reference's state_dict keys, the cfg table, codebook sampling and surgery,
+and the product path refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mcgen_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()                                   # binds every name in SYMBOLS (AttributeError if missing)
+    header = open(os.path.join(ROOT, 'include', 'mcgen_hip.h')).read()
+    declared = set(re.findall(r'\b(mcgen_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.mcgen_abi_version() == 1
+    # struct sizes agree with the C side: weight image size query is pure host code
+    assert lib.mcgen_weight_image_elems(128, 3, 3, 0) == 1 * 9 * 128 * 32
+    assert lib.mcgen_weight_image_elems(128, 3, 3, 1) == 4 * 9 * 16 * 32
+    assert lib.mcgen_weight_image_elems(4096, 128, 1, 0) == 4 * 4096 * 32
+
+
+def test_bad_arguments_are_rejected_before_launch():
+    from mcgen_amd import _lib
+    lib = _lib.load()
+    p = _lib.Conv()
+    p.nseg = 3
+    assert lib.mcgen_conv_fused(ctypes.byref(p), _lib.F32, None) != 0
+    assert b'nseg' in lib.mcgen_last_error()
+    p.nseg = 1; p.N = 1; p.H = 6; p.W = 6
+    assert lib.mcgen_conv_fused(ctypes.byref(p), _lib.F32, None) != 0
+    assert b'powers of two' in lib.mcgen_last_error()
+
+
+def _cfg_for(data_name, classes=None):
+    from mcgen_amd.config import cfg, process_control
+    cfg.update(data_name=data_name, model_name='mcgan', device='cpu')
+    cfg['control'] = {'controller_rate': '0.5'}
+    cfg.pop('classes_size', None)
+    process_control()
+    if classes:
+        cfg['classes_size'] = classes
+    return cfg
+
+
+def test_process_control_table():
+    cfg = _cfg_for('CIFAR10')
+    assert cfg['data_shape'] == [3, 32, 32] and cfg['classes_size'] == 10
+    assert cfg['gan']['generator_hidden_size'] == [256] * 4 and cfg['gan']['discriminator_hidden_size'] == [128] * 4
+    assert cfg['gan']['latent_size'] == 128 and cfg['batch_size'] == {'train': 128, 'test': 512}
+    assert cfg['controller_rate'] == 0.5
+    cfg = _cfg_for('COIL100')
+    assert cfg['gan']['generator_hidden_size'] == [512, 256, 128, 64] and cfg['classes_size'] == 100
+    cfg = _cfg_for('Omniglot')
+    assert cfg['data_shape'] == [1, 32, 32] and cfg['classes_size'] == 1623
+    from mcgen_amd.config import cfg as c2, process_control
+    c2['data_name'] = 'nope'
+    with pytest.raises(ValueError):
+        process_control()
+    _cfg_for('CIFAR10')
+
+
+@pytest.mark.parametrize('fixture,g,d,classes,name', [
+    ('mcgan_small.npz', [32] * 4, [16] * 4, 10, 'CIFAR10'),
+    ('mcgan_coil_small.npz', [64, 32, 16, 8], [8, 16, 32, 64], 20, 'COIL100'),
+])
+def test_module_tree_loads_reference_state_dict(fixture, g, d, classes, name):
+    from mcgen_amd import models
+    cfg = _cfg_for(name, classes)
+    cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'] = g, d
+    m = models.mcgan()
+    sd = gu.state_from_npz(gu.load_npz(fixture))
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd)
+    assert gu.mcgan_shapes(g, d, classes, cifar_layout=(name == 'CIFAR10')) == {k: tuple(v.shape) for k, v in sd.items()}
+    # the shared mc_1 instance shows up under aliased keys
+    blk = m.generator.blocks[0]
+    assert blk.conv[3] is blk.mc_1 and blk.shortcut[1] is blk.mc_1 and blk.conv[7] is blk.mc_2
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == sum(int(np.prod(v.shape)) for k, v in sd.items() if k.endswith(('.weight', '.bias', '.weight_orig')))
+    _cfg_for('CIFAR10')
+
+
+def test_full_size_parameter_count():
+    from mcgen_amd import models
+    _cfg_for('CIFAR10')
+    m = models.mcgan()
+    assert sum(p.numel() for p in m.parameters()) == 5330564
+    assert sum(p.numel() for p in m.generator.parameters()) == 4276739
+    # init_param: xavier on the SN-wrapped weights too (it runs after make_SpectralNormalization)
+    w = m.discriminator.blocks[1].conv[2].module.weight_orig
+    assert abs(float(w.abs().max()) - (6 / 2304) ** 0.5) < 1e-3
+
+
+def test_codebook_sampling_and_surgery():
+    from mcgen_amd.modules import MultimodalController, sample_codebook
+    from mcgen_amd.models import utils as mu
+    from mcgen_amd.config import cfg
+    torch.manual_seed(0)
+    cb = sample_codebook(100, 24, 0.5)
+    assert cb.shape == (100, 24) and set(cb.unique().tolist()) <= {0.0, 1.0}
+    assert len({tuple(r) for r in cb.tolist()}) == 100
+    assert torch.equal(sample_codebook(7, 5, 1), torch.ones(7, 5))
+    mc = MultimodalController(16, 10, 0.5)
+    assert 'codebook' in dict(mc.named_buffers()) and mc.codebook.shape == (10, 16)
+    cfg['device'] = 'cpu'
+    orig = mc.codebook.clone()
+    out = mu.transit_codebook(mc.codebook, root=3, alpha=0.25)
+    cross = int(round(0.75 * 16))
+    assert torch.equal(out[3], mc.codebook[3])
+    assert all(torch.equal(out[i, :cross], mc.codebook[3, :cross]) for i in range(10))
+    assert all(torch.equal(out[i, cross:], mc.codebook[i, cross:]) for i in range(10))
+    holder = torch.nn.Sequential(mc)
+    mu.transit(holder, 3, 0.25)
+    assert torch.equal(mc.codebook_orig, orig) and torch.equal(mc.codebook, out)
+    cfg['classes_size'] = 6
+    mu.create(holder)
+    assert mc.codebook.shape == (6, 16)
+    cfg['classes_size'] = 10
+
+
+def test_no_cpu_fallback():
+    from mcgen_amd import _lib, models, ops
+    cfg = _cfg_for('CIFAR10')
+    cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'] = [16] * 4, [16] * 4
+    m = models.mcgan()
+    with pytest.raises(_lib.McgenError):
+        m.generate(torch.zeros(2, dtype=torch.int64), torch.zeros(2, 128))
+    with pytest.raises(_lib.McgenError):
+        ops.mc_code(torch.zeros(2, 10), torch.zeros(10, 16))
+    _cfg_for('CIFAR10')
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'multimodal-controller-for-generative-models_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dp, f)

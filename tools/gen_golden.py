@@ -235,6 +235,44 @@ def fx_mcgan_coil():
 FIXTURES = {'mc_unit': fx_mc_unit, 'blocks': fx_blocks, 'mcgan_small': fx_mcgan_small,
             'mcgan_full': fx_mcgan_full, 'mcgan_coil': fx_mcgan_coil}
 
+def fx_dp_emulation():
+    """Two-replica data parallel as the reference's nn.DataParallel computes it (train_gan.py:96-98):
+    the same weights see two batch shards (per-shard BatchNorm statistics), gradients are averaged.
+    Stored: the averaged gradients of one D loss and one G loss on the reduced-width model."""
+    import models
+    set_gan_cfg([32] * 4, [16] * 4, 10)
+    torch.manual_seed(0)
+    model = models.mcgan()
+    model.train(True)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    B = 8
+    img, lab = gu.synthetic_batch(B, 10, seed=21)
+    z = gu.latent_batches(2, B, 128, seed=22)
+    arrays = np_state(sd0, 'sd/')
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy(); arrays['z'] = torch.stack(z).numpy()
+    shards = [slice(0, B // 2), slice(B // 2, B)]
+    for step in ('d', 'g'):
+        acc = None
+        for sh in shards:
+            model.load_state_dict(sd0)
+            model.zero_grad()
+            if step == 'd':
+                d_x = model.discriminate(img[sh], lab[sh])
+                fake = model.generate(lab[sh], z[0][sh])
+                loss = F.relu(1.0 - d_x).mean() + F.relu(1.0 + model.discriminate(fake.detach(), lab[sh])).mean()
+            else:
+                loss = -model.discriminate(model.generate(lab[sh], z[1][sh]), lab[sh]).mean()
+            loss.backward()
+            net = model.discriminator if step == 'd' else model.generator
+            g = {n: p.grad.clone() for n, p in net.named_parameters()}
+            acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+        for n, v in acc.items():
+            arrays[f'grad_{step}/{n}'] = (v / len(shards)).numpy()
+    save('mcgan_dp2.npz', **arrays)
+
+
+FIXTURES['dp'] = fx_dp_emulation
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
