@@ -54,30 +54,49 @@ struct PatchStager {
     int it_lds[NI];      // byte offset in the LDS window, -1 = no item
     int it_sub[1];       // channel offset inside the chunk (0, 8, 16, 24): the same for all items of a thread
 
-    __device__ __forceinline__ void setup(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W, int tid) {
-        const int halo = sg.ksize >> 1;
+    int it_pos[NI];      // packed window position of the item: pr | pc << 8 | ti << 16
+
+    // Tile-independent part (integer divisions by the window width): once per kernel / segment.
+    __device__ __forceinline__ void setup_static(int ksize, const Geo& g, int W, int tid) {
+        const int halo = ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         const int PP = g.TI * PR * PC;
-        const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
         static_assert(NT % SUBS == 0, "items of one thread share the sub-chunk");
         it_sub[0] = (tid % SUBS) * 8;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int it = tid + k * NT;
-            it_src[k] = -1; it_lds[k] = -1; it_n[k] = 0;
+            it_lds[k] = -1; it_pos[k] = 0;
             if (it < PP * SUBS) {
                 const int sub = it % SUBS, pp = it / SUBS;
                 const int pc = pp % PC, t2 = pp / PC;
                 const int pr = t2 % PR, ti = t2 / PR;
-                const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;
                 it_lds[k] = pp * APITCH + sub * 8 * E::BYTES;
+                it_pos[k] = pr | (pc << 8) | (ti << 16);
+            }
+        }
+    }
+    // Tile-dependent part: source offsets and validity for the tile described by g (a few adds per item).
+    __device__ __forceinline__ void bind(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W) {
+        const int halo = sg.ksize >> 1;
+        const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            it_src[k] = -1; it_n[k] = 0;
+            if (it_lds[k] >= 0) {
+                const int pr = it_pos[k] & 255, pc = (it_pos[k] >> 8) & 255, ti = it_pos[k] >> 16;
+                const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;
                 it_n[k] = n;
                 if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
                     const int hs = sg.ups ? (h >> 1) : h, ws = sg.ups ? (w >> 1) : w;
-                    it_src[k] = ((n * Hs + hs) * Ws + ws) * sg.C + sub * 8;
+                    it_src[k] = ((n * Hs + hs) * Ws + ws) * sg.C + it_sub[0];
                 }
             }
         }
+    }
+    __device__ __forceinline__ void setup(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W, int tid) {
+        setup_static(sg.ksize, g, W, tid);
+        bind(sg, g, N, H, W);
     }
 
     // raw 8-channel groups fetched by load(), consumed by write(): lets the caller issue the global

@@ -24,8 +24,10 @@ template <> struct WgTraits<float> {
     static constexpr int DPITCH = WG_BCO * 4 + 16;
 };
 template <> struct WgTraits<bf16_t> {
-    static constexpr int APITCH = WG_CI * 2 + 16;        // 144 B: rows 8-byte aligned for the tr read
-    static constexpr int DPITCH = WG_BCO * 2 + 16;       // 144 B
+    // pitches of 32 B x odd: the 8 pixel rows one half-wave touches in a transposing read fall on 8
+    // distinct 32-byte bank groups (conflict-free with the k mapping below)
+    static constexpr int APITCH = WG_CI * 2 + 32;        // 96 B
+    static constexpr int DPITCH = WG_BCO * 2 + 32;       // 160 B
 };
 
 static __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
@@ -33,26 +35,28 @@ static __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
         (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
 }
 
-// One MFMA operand fragment with k = 8 consecutive tile pixels (lane group lg) and 16 channels
-// (lane & 15) read from an LDS image laid out [pixel][channel]: bf16 by two transposing reads
-// (lane (q4, p4) supplies the address of pixel 4*half + q4, channels 4*p4..4*p4+3), fp32 by 8 scalar reads.
+// k mapping of one 32-pixel MFMA step: element j of lane group lg is tile pixel 16*(j>>2) + 4*lg + (j&3).
+// (Any bijection works as long as both operands use it; this one makes each transposing read cover 16
+// consecutive pixel rows, 8 per half-wave.)
+// One operand fragment: 8 pixels (k) x 16 channels (lane & 15) from an LDS image laid out [pixel][channel].
 template <typename T> struct KFrag;
 template <> struct KFrag<bf16_t> {
     typedef bf16x8 frag;
-    // off2[h]: byte offset of this lane's row for half h (already includes the 8-byte column part)
-    static __device__ __forceinline__ frag read(const char* base, const int (&off)[8], int col_bytes16) {
+    static constexpr int NOFF = 2;        // byte offset of the lane's row for each half (includes the 8-byte column part)
+    static __device__ __forceinline__ frag read(const char* base, const int (&off)[NOFF], int imm) {
         union { bf16x8 v; s16x4 h[2]; } u;
-        u.h[0] = lds_tr16(base + off[0] + col_bytes16);
-        u.h[1] = lds_tr16(base + off[1] + col_bytes16);
+        u.h[0] = lds_tr16(base + off[0] + imm);
+        u.h[1] = lds_tr16(base + off[1] + imm);
         return u.v;
     }
 };
 template <> struct KFrag<float> {
     typedef f32x8 frag;
-    static __device__ __forceinline__ frag read(const char* base, const int (&off)[8], int col_bytes16) {
+    static constexpr int NOFF = 8;
+    static __device__ __forceinline__ frag read(const char* base, const int (&off)[NOFF], int imm) {
         f32x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const float*>(base + off[j] + col_bytes16);
+        for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const float*>(base + off[j] + imm);
         return r;
     }
 };
@@ -60,19 +64,21 @@ template <> struct KFrag<float> {
 // Workgroup = 64 output channels x 32 input channels x all taps.  Waves are a 2 x 2 grid:
 // wave (a, b) owns output-channel fragments {2a, 2a+1} and input-channel block b for every tap, so per
 // 32-pixel step it reads 2 dy fragments + NTAP window fragments for 2*NTAP MFMAs (small footprint:
-// 72 accumulator registers, ~35 KB LDS -> four workgroups per CU hide each other's staging latency).
-template <typename T, int KS>
+// 72 accumulator registers, ~35 KB LDS -> several workgroups per CU hide each other's staging latency).
+// LGW = log2(W) is a template parameter so that every tap offset is an instruction immediate.
+template <typename T, int KS, int LGW>
 __global__ __launch_bounds__(WG_NT, 3)
 void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
+    using KF = KFrag<T>;
     constexpr int ESZ = E::BYTES, APITCH = TR::APITCH, DPITCH = TR::DPITCH;
     constexpr int NTAP = KS * KS;
-    constexpr int NPAIR = NTAP;                       // taps (this wave's ci block is fixed)
     constexpr int NCF = WG_BCO / 32;                  // output-channel fragments per wave
-    constexpr int SUBS = WG_CI / 8;
-    constexpr int NI = (WG_BM * 9 * SUBS / 4 + WG_NT - 1) / WG_NT;
+    constexpr int NI = (WG_BM * 9 + WG_NT - 1) / WG_NT;
+    constexpr int W = 1 << LGW, halo = KS >> 1, PC = W + 2 * halo;
+    constexpr int KSTEPS = WG_BM / 32;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
@@ -80,47 +86,73 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int H = p.H, W = p.W, N = p.N;
+    const int H = p.H, N = p.N;
     const int co0 = blockIdx.x * WG_BCO;
-    const int c0 = blockIdx.y * WG_CI;
+    const int q = blockIdx.y;                       // input-channel chunk
+    const int c0 = q * MCGEN_CK;
     const mcgen_seg_t sg = p.seg;
-    const int halo = KS >> 1;
-    const T* dy = reinterpret_cast<const T*>(p.dy);
+    const char* dy = reinterpret_cast<const char*>(p.dy);
     const int Hd = p.dy_ups ? (H >> 1) : H, Wd = p.dy_ups ? (W >> 1) : W;
-
-    f32x4 acc[NPAIR][NCF];
-#pragma unroll
-    for (int j = 0; j < NPAIR; ++j)
-#pragma unroll
-        for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // bias gradient = column sums of dy: done by the ci-tile-0 workgroups on the dy tile they stage anyway
-    const bool do_bias = (p.bias_slabs != nullptr) && (blockIdx.y == 0);
-    float bsum = 0.f;                                  // thread (column tid&63, row quarter tid>>6)
-
     const int wa = wave >> 1, wb = wave & 1;          // output-channel half, input-channel block
 
+    f32x4 acc[NTAP][NCF];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
+    float bsum = 0.f;                                  // thread (column tid&63, row quarter tid>>6)
+
+    // tile-relative geometry is the same for every tile: fragment row offsets are computed once
+    const Geo g0 = make_geo(WG_BM, 0, H, W);
+    const int PR = g0.TH + 2 * halo;
+    auto make_off = [&](int ks, int (&oa)[KF::NOFF], int (&od)[KF::NOFF]) {
+#pragma unroll
+        for (int j = 0; j < KF::NOFF; ++j) {
+            // bf16: j = half, this lane supplies row q4 = l15>>2 of the 4-row block; fp32: j = element
+            const int kk = (KF::NOFF == 2) ? (16 * j + 4 * lg + (l15 >> 2)) : (16 * (j >> 2) + 4 * lg + (j & 3));
+            const int m = ks * 32 + kk;
+            const int ti = m >> g0.lgTHW, rem = m & ((1 << g0.lgTHW) - 1);
+            const int r = rem >> LGW, c = rem & (W - 1);
+            const int colb = (KF::NOFF == 2) ? (l15 & 3) * 8 : l15 * 4;
+            oa[j] = ((ti * PR + r) * PC + c) * APITCH + colb + wb * 16 * ESZ;
+            od[j] = m * DPITCH + colb + wa * NCF * 16 * ESZ;
+        }
+    };
+    constexpr bool PRE = (KF::NOFF == 2);              // bf16: 16 registers hold all steps' offsets; fp32 recomputes
+    int offA[PRE ? KSTEPS : 1][KF::NOFF], offD[PRE ? KSTEPS : 1][KF::NOFF];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) make_off(ks, offA[ks], offD[ks]);
+    }
+    // dy staging items of this thread: (pixel m, 16-byte unit) -> source pixel offset is tile dependent,
+    // the LDS offset is not
+    constexpr int DUNITS = WG_BCO * ESZ / 16;           // 16-byte units per dy row (8 bf16 / 16 fp32)
+    constexpr int DITEMS = WG_BM * DUNITS / WG_NT;
+    static_assert(WG_BM * DUNITS % WG_NT == 0, "dy staging");
+
+    PatchStager<T, WG_NT, NI, APITCH> stager;
+    stager.setup_static(KS, g0, W, tid);
     for (int tile = blockIdx.z; tile < m_tiles; tile += gridDim.z) {
         const Geo g = make_geo(WG_BM, tile, H, W);
-        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
-        PatchStager<T, WG_NT, NI, APITCH, SUBS> stager;
-        stager.setup(sg, g, N, H, W, tid);
+        stager.bind(sg, g, N, H, W);
         __syncthreads();                                        // previous tile's reads are done
         stager.stage(sg, c0, ldsA);
-        // dy tile: [pixel m][64 co]
-        for (int it = tid; it < WG_BM * (WG_BCO / 8); it += WG_NT) {
-            const int sub = it & 7, m = it >> 3;
-            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
-            const int r = rem >> g.lgW, c = rem & (W - 1);
-            const int n = g.n0 + ti, h = g.h0 + r;
-            float v[8];
+        // dy tile: [pixel m][64 co], raw 16-byte copies
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = 0.f;
-            const int co = co0 + sub * 8;
-            if (n < N && co < p.Cdy) {
+        for (int k = 0; k < DITEMS; ++k) {
+            const int it = tid + k * WG_NT;
+            const int u = it % DUNITS, m = it / DUNITS;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> LGW, c = rem & (W - 1);
+            const int n = g.n0 + ti, h = g.h0 + r;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int cob = (co0 * ESZ + u * 16);                // byte offset of this unit inside the dy pixel row
+            if (n < N && cob < p.Cdy * ESZ) {
                 const int hd = p.dy_ups ? (h >> 1) : h, wd = p.dy_ups ? (c >> 1) : c;
-                E::load8(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy + co, v);
+                v = *reinterpret_cast<const u32x4*>(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy * ESZ + cob);
             }
-            E::store8(reinterpret_cast<T*>(ldsD + m * DPITCH + sub * 8 * ESZ), v);
+            *reinterpret_cast<u32x4*>(ldsD + m * DPITCH + u * 16) = v;
         }
         __syncthreads();
         if (do_bias) {
@@ -129,38 +161,19 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
             for (int r = 0; r < WG_BM / 4; ++r)
                 bsum += E::to_f(*reinterpret_cast<const T*>(ldsD + (part * (WG_BM / 4) + r) * DPITCH + col * ESZ));
         }
-
-#pragma unroll 1
-        for (int ks = 0; ks < WG_BM / 32; ++ks) {
-            // byte offsets of this lane's k rows (pixels ks*32 + 8*lg ...) in the window and in the dy tile
-            int offA[8], offD[8];
-            if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int m = ks * 32 + lg * 8 + j;
-                    const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
-                    const int r = rem >> g.lgW, c = rem & (W - 1);
-                    offA[j] = ((ti * PR + r) * PC + c) * APITCH + l15 * 4;
-                    offD[j] = m * DPITCH + l15 * 4;
-                }
-            } else {
-                const int q4 = l15 >> 2, p4 = l15 & 3;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int m = ks * 32 + lg * 8 + hf * 4 + q4;
-                    const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
-                    const int r = rem >> g.lgW, c = rem & (W - 1);
-                    offA[hf] = ((ti * PR + r) * PC + c) * APITCH + p4 * 8;
-                    offD[hf] = m * DPITCH + p4 * 8;
-                }
-            }
+#pragma unroll (PRE ? KSTEPS : 1)
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if constexpr (!PRE) make_off(ks, offA[0], offD[0]);
+            const int (&oA)[KF::NOFF] = offA[PRE ? ks : 0];
+            const int (&oD)[KF::NOFF] = offD[PRE ? ks : 0];
             typename M::frag dfrag[NCF];
 #pragma unroll
-            for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KFrag<T>::read(ldsD, offD, (wa * NCF + cf) * 16 * ESZ);
+            for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KF::read(ldsD, oD, cf * 16 * ESZ);
 #pragma unroll
-            for (int j = 0; j < NPAIR; ++j) {
-                const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;
-                const typename M::frag afrag = KFrag<T>::read(ldsA + tapoff, offA, wb * 16 * ESZ);
+            for (int j = 0; j < NTAP; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;       // compile-time
+                const typename M::frag afrag = KF::read(ldsA, oA, tapoff);
 #pragma unroll
                 for (int cf = 0; cf < NCF; ++cf) M::run(dfrag[cf], afrag, acc[j][cf]);
             }
@@ -179,9 +192,8 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
     float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
-    const int q = blockIdx.y;
 #pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
+    for (int j = 0; j < NTAP; ++j) {
         const int col = wb * 16 + l15;
 #pragma unroll
         for (int cf = 0; cf < NCF; ++cf)
@@ -244,7 +256,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
 
-template <typename T, int KS>
+template <typename T, int KS, int LGW>
 static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     using TR = WgTraits<T>;
     const long Mtot = (long)p->N * p->H * p->W;
@@ -252,8 +264,8 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int PP = mcgen_patch_pixels(WG_BM, p->H, p->W, KS);
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
-    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, (p->seg.C + WG_CI - 1) / WG_CI, p->splits);
-    auto kern = wgrad_kernel<T, KS>;
+    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    auto kern = wgrad_kernel<T, KS, LGW>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         raised = true;
@@ -263,6 +275,29 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, *p, a_bytes, m_tiles);
     MCGEN_LAUNCH_CHECK("wgrad");
     return 0;
+}
+
+template <typename T>
+static int launch_t(const mcgen_wgrad_t* p, hipStream_t st) {
+    const int lgw = ilog2_exact(p->W);
+    if (p->seg.ksize == 3) {
+        switch (lgw) {
+            case 2: return launch<T, 3, 2>(p, st);
+            case 3: return launch<T, 3, 3>(p, st);
+            case 4: return launch<T, 3, 4>(p, st);
+            case 5: return launch<T, 3, 5>(p, st);
+        }
+    } else {
+        switch (lgw) {
+            case 0: return launch<T, 1, 0>(p, st);
+            case 1: return launch<T, 1, 1>(p, st);
+            case 2: return launch<T, 1, 2>(p, st);
+            case 3: return launch<T, 1, 3>(p, st);
+            case 4: return launch<T, 1, 4>(p, st);
+            case 5: return launch<T, 1, 5>(p, st);
+        }
+    }
+    return mcgen_fail("wgrad: no instantiation for ksize %d at W = %d", p->seg.ksize, p->W);
 }
 
 }  // namespace
@@ -282,8 +317,8 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
     MCGEN_CHECK(p->splits >= 1 && p->splits <= 65535, "wgrad: bad splits");
     MCGEN_CHECK(!p->dy_ups || (p->H >= 2 && p->W >= 2), "wgrad: dy_ups needs H, W >= 2");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MCGEN_F32) return p->seg.ksize == 3 ? launch<float, 3>(p, st) : launch<float, 1>(p, st);
-    if (dtype == MCGEN_BF16) return p->seg.ksize == 3 ? launch<bf16_t, 3>(p, st) : launch<bf16_t, 1>(p, st);
+    if (dtype == MCGEN_F32) return launch_t<float>(p, st);
+    if (dtype == MCGEN_BF16) return launch_t<bf16_t>(p, st);
     return mcgen_fail("wgrad: unknown dtype %d", dtype);
 }
 
