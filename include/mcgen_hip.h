@@ -135,12 +135,23 @@ int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int transpose);
 int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
                       int transpose, int row_perm, const float* sigma, float wscale, void* stream);
 
+/* the same for all layers of a network pass in ONE launch; sigma = sigma_base[sigma_idx] (idx < 0: none) */
+typedef struct {
+    const float* w; void* image;
+    int32_t Cout, Cin, ksize, transpose, row_perm, sigma_idx;
+    float wscale; int32_t _pad;
+} mcgen_prep_t;
+int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream);
+
 /* layout / dtype conversion at the module boundary (the reference works on NCHW fp32) */
 int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 
 /* code[N, C] = indicator[N, M] @ codebook[M, C]      MultimodalController.forward, modules.py:73 */
 int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream);
+/* codes of all MultimodalController layers of a network in ONE launch: code_base + out_off <- indicator @ codebook */
+typedef struct { const float* codebook; int64_t out_off; int32_t M, C; } mcgen_code_t;
+int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream);
 /* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);

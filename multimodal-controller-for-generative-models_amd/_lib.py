@@ -33,6 +33,16 @@ class Wgrad(C.Structure):
                 ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32), ('bias_slabs', C.c_void_p)]
 
 
+class Prep(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('image', C.c_void_p),
+                ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('transpose', C.c_int32),
+                ('row_perm', C.c_int32), ('sigma_idx', C.c_int32), ('wscale', C.c_float), ('_pad', C.c_int32)]
+
+
+class Code(C.Structure):
+    _fields_ = [('codebook', C.c_void_p), ('out_off', C.c_int64), ('M', C.c_int32), ('C', C.c_int32)]
+
+
 class SnLayer(C.Structure):
     _fields_ = [('w_off', C.c_int64), ('u_off', C.c_int64), ('v_off', C.c_int64),
                 ('rows', C.c_int32), ('cols', C.c_int32)]
@@ -51,6 +61,8 @@ SYMBOLS = {
     'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
+    'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

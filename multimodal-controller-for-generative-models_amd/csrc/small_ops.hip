@@ -69,7 +69,51 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// all weight images of a network pass in one launch: blockIdx.y = descriptor
+template <typename T>
+__global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs, const float* __restrict__ sigma_base) {
+    const mcgen_prep_t d = descs[blockIdx.y];
+    const int KS = d.ksize, Cout = d.Cout, Cin = d.Cin, transpose = d.transpose, row_perm = d.row_perm;
+    const float* __restrict__ w = d.w;
+    T* __restrict__ img = reinterpret_cast<T*>(d.image);
+    const int ntap = KS * KS;
+    const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
+    const int rows_w = (rows + 15) / 16 * 16;
+    const int nchunk = (((kdim + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t total = (size_t)nchunk * ntap * rows_w * MCGEN_CK;
+    const float sc = (d.sigma_idx >= 0) ? d.wscale / sigma_base[d.sigma_idx] : d.wscale;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % MCGEN_CK); size_t t = i / MCGEN_CK;
+        const int row = (int)(t % rows_w); t /= rows_w;
+        const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
+        const int k = q * MCGEN_CK + col;
+        float v = 0.f;
+        if (row < rows && k < kdim) {
+            int co = transpose ? k : row;
+            const int ci = transpose ? row : k;
+            if (row_perm > 1) { const int Cc = Cout / row_perm; co = (co % Cc) * row_perm + co / Cc; }
+            const int kh = tap / KS, kw = tap % KS;
+            const int mtap = transpose ? ((KS - 1 - kh) * KS + (KS - 1 - kw)) : tap;
+            v = w[((size_t)co * Cin + ci) * ntap + mtap] * sc;
+        }
+        img[i] = Elem<T>::from_f(v);
+    }
+}
+
 // ---- MultimodalController ---------------------------------------------------------------------------
+// codes of every MultimodalController of a network in one launch: blockIdx.y = descriptor
+__global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_code_t* __restrict__ descs,
+                                     float* __restrict__ code_base, int N) {
+    const mcgen_code_t d = descs[blockIdx.y];
+    const size_t total = (size_t)N * d.C;
+    float* code = code_base + d.out_off;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d.C), n = (int)(i / d.C);
+        float s = 0.f;
+        for (int m = 0; m < d.M; ++m) s = fmaf(ind[(size_t)n * d.M + m], d.codebook[(size_t)m * d.C + c], s);
+        code[i] = s;
+    }
+}
 __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __restrict__ cb, float* __restrict__ code,
                                int N, int M, int C) {
     const size_t total = (size_t)N * C;
@@ -438,6 +482,19 @@ extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cou
         hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale),
         hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale));
     MCGEN_LAUNCH_CHECK("prep_weight"); return 0;
+}
+
+extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream) {
+    MCGEN_CHECK(descs_dev && n > 0, "prep_weight_batch: bad arguments");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_weight_batch_kernel<float>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base),
+        hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
+    MCGEN_LAUNCH_CHECK("prep_weight_batch"); return 0;
+}
+extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream) {
+    MCGEN_CHECK(indicator && descs_dev && code_base && n > 0 && N > 0, "mc_code_batch: bad arguments");
+    hipLaunchKernelGGL(mc_code_batch_kernel, dim3(8, n), dim3(256), 0, STREAM(stream), indicator, descs_dev, code_base, N);
+    MCGEN_LAUNCH_CHECK("mc_code_batch"); return 0;
 }
 
 extern "C" int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream) {

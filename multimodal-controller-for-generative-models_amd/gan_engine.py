@@ -110,6 +110,9 @@ class GeneratorEngine:
         self.flat_p = FlatState(list(gen.parameters()))
         self._img_key = None
         self.img: Dict[str, Tensor] = {}
+        self._prep_fwd = self._prep_bwd = None
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        self._codes = ops.CodeBatch([m for b in res for m in (b.mc_1, b.mc_2)] + [head_mc])
 
     def _layers(self):
         g = self.gen
@@ -143,23 +146,46 @@ class GeneratorEngine:
                 self.img[name] = t
             return t
 
-        ops.prep_weight(lin.weight.detach(), dt, row_perm=16,
-                        out=buf('lin', ops.weight_image_elems(lin.out_features, lin.in_features, 1), dt))
+        if self._prep_fwd is None or self._prep_fwd.dtype != dt or not self._prep_fwd.valid():
+            jobs = [(lin.weight, buf('lin', ops.weight_image_elems(lin.out_features, lin.in_features, 1), dt), False, 16, -1, 1.0)]
+            for i, b in enumerate(res):
+                w1, w2, wsc = b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight
+                jobs.append((w1, buf(f'b{i}.w1', ops.weight_image_elems(w1.shape[0], w1.shape[1], 3), dt), False, 1, -1, 1.0))
+                n2 = ops.weight_image_elems(w2.shape[0], w2.shape[1], 3)
+                ns = ops.weight_image_elems(wsc.shape[0], wsc.shape[1], 1)
+                cat = buf(f'b{i}.w2s', n2 + ns, dt)
+                jobs.append((w2, cat[:n2], False, 1, -1, 1.0))
+                jobs.append((wsc, cat[n2:], False, 1, -1, 1.0))
+            jobs.append((head_conv.weight, buf('head', ops.weight_image_elems(head_conv.out_channels, head_conv.in_channels, 3), dt),
+                         False, 1, -1, 1.0))
+            self._prep_fwd = ops.PrepBatch([(w.detach(), im, t, rp, si, sc) for w, im, t, rp, si, sc in jobs], dt)
+        self._prep_fwd.run()
         buf('lin_bias', lin.out_features, torch.float32).view(16, c0).copy_(lin.bias.detach().view(c0, 16).t())
         for i, b in enumerate(res):
-            w1, w2, wsc = (b.conv[4].module.weight.detach(), b.conv[8].module.weight.detach(),
-                           b.shortcut[2].module.weight.detach())
-            ops.prep_weight(w1, dt, out=buf(f'b{i}.w1', ops.weight_image_elems(w1.shape[0], w1.shape[1], 3), dt))
-            n2 = ops.weight_image_elems(w2.shape[0], w2.shape[1], 3)
-            ns = ops.weight_image_elems(wsc.shape[0], wsc.shape[1], 1)
-            cat = buf(f'b{i}.w2s', n2 + ns, dt)
-            ops.prep_weight(w2, dt, out=cat[:n2])
-            ops.prep_weight(wsc, dt, out=cat[n2:])
             torch.add(b.conv[8].module.bias.detach(), b.shortcut[2].module.bias.detach(),
-                      out=buf(f'b{i}.bias2s', w2.shape[0], torch.float32))
-        ops.prep_weight(head_conv.weight.detach(), dt,
-                        out=buf('head', ops.weight_image_elems(head_conv.out_channels, head_conv.in_channels, 3), dt))
+                      out=buf(f'b{i}.bias2s', b.conv[8].module.out_channels, torch.float32))
         self._img_key = key
+
+    def _prep_backward_images(self):
+        """Transposed/flipped images for the input gradients, one launch (called at the start of backward)."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        dt = self.dtype
+        dev = lin.weight.device
+        if self._prep_bwd is None or self._prep_bwd.dtype != dt or not self._prep_bwd.valid():
+            jobs = []
+            self.img_t = {}
+            def tbuf(name, w):
+                ks = w.shape[2]
+                t = torch.empty(ops.weight_image_elems(w.shape[0], w.shape[1], ks, True), dtype=dt, device=dev)
+                self.img_t[name] = t
+                jobs.append((w.detach(), t, True, 1, -1, 1.0))
+            tbuf('head', head_conv.weight)
+            for i, b in enumerate(res):
+                tbuf(f'b{i}.w1', b.conv[4].module.weight)
+                tbuf(f'b{i}.w2', b.conv[8].module.weight)
+                tbuf(f'b{i}.ws', b.shortcut[2].module.weight)
+            self._prep_bwd = ops.PrepBatch(jobs, dt)
+        self._prep_bwd.run()
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, z: Tensor, indicator: Tensor, train: bool):
@@ -178,9 +204,10 @@ class GeneratorEngine:
         fold = 16                              # Linear output column p*C0+c belongs to channel c
         ctx['zt'] = zt
         blocks_ctx = []
+        codes = self._codes.run(indicator)
         for i, b in enumerate(res):
             s = x.shape[1]
-            code1, code2 = b.mc_1.code(indicator), b.mc_2.code(indicator)
+            code1, code2 = codes[2 * i], codes[2 * i + 1]
             bn1 = _bn_forward(b.conv[0].module, st, n * s * s, train, fold)
             fold = 1
             co = b.conv[4].module.out_channels
@@ -195,7 +222,7 @@ class GeneratorEngine:
             x = y
         s = x.shape[1]
         bnh = _bn_forward(head_bn, st, n * s * s, train, fold)
-        codeh = head_mc.code(indicator)
+        codeh = codes[-1]
         seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
         out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
@@ -213,6 +240,7 @@ class GeneratorEngine:
         acc = accumulate
         G = lambda p: self.flat_p.view_of(gflat, p)                           # noqa: E731
         out = ctx['out']
+        self._prep_backward_images()
         dout = ops.to_nhwc(dimg.contiguous(), dt, out.shape[-1])
         dtn = ops.tanh_bwd(dout, out)
         y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
@@ -220,7 +248,7 @@ class GeneratorEngine:
         # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
         seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
         ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc, bias_grad=G(head_conv.bias))
-        wt = ops.prep_weight(head_conv.weight.detach(), dt, transpose=True)
+        wt = self.img_t['head']
         dz, part = ops.conv_fused([Seg(dtn)], wt, c, ocode=codeh, gate_x=y, gscale=bnh.scale, gshift=bnh.shift,
                                   gmean=bnh.mean, grstd=bnh.rstd, stats_mode=2)
         dy = ops.bn_backward(part, dz, y, bnh.count, bnh.scale, bnh.mean, bnh.rstd,
@@ -236,7 +264,7 @@ class GeneratorEngine:
             seg_s = Seg(x, ksize=1, code=code1, ups=True)
             ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc, bias_grad=G(conv2.bias), bias_grad2=G(convs.bias))
             ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
-            w2t = ops.prep_weight(conv2.weight.detach(), dt, transpose=True)
+            w2t = self.img_t[f'b{i}.w2']
             dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
                                         gmean=bn2.mean, grstd=bn2.rstd, stats_mode=2)
             dh = ops.bn_backward(part2, dz2, h, bn2.count, bn2.scale, bn2.mean, bn2.rstd,
@@ -244,9 +272,9 @@ class GeneratorEngine:
             # first conv: gradient goes through MC, the nearest-upsample adjoint (2x2 sum), ReLU, BN
             seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
             ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc, bias_grad=G(conv1.bias))
-            wst = ops.prep_weight(convs.weight.detach(), dt, transpose=True)
+            wst = self.img_t[f'b{i}.ws']
             dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
-            w1t = ops.prep_weight(conv1.weight.detach(), dt, transpose=True)
+            w1t = self.img_t[f'b{i}.w1']
             dz1, part1 = ops.conv_fused([Seg(dh)], w1t, ci, pool=True, alpha=1.0, ocode=code1, gate_x=x,
                                         gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)
             dy = ops.bn_backward(part1, dz1, x, bn1.count, bn1.scale, bn1.mean, bn1.rstd,
@@ -295,6 +323,10 @@ class DiscriminatorEngine:
         self.flat_uv = FlatState(uv)
         self._layers_dev = None          # SN layers first, then plain parameters (rows == 0)
         self._layers_key = None
+        mcs = [self.res[0].mc_1] + [m for b in self.res[1:] for m in (b.mc_1, b.mc_2)] + [self.tail_mc]
+        self._codes = ops.CodeBatch(mcs)
+        self._prep_fwd = self._prep_bwd = None
+        self.img: Dict[str, Tensor] = {}
 
     def _ensure_flat(self):
         fp, fuv = self.flat_p.ensure(), self.flat_uv.ensure()
@@ -311,17 +343,54 @@ class DiscriminatorEngine:
             self._layers_key = key
         return fp, fuv
 
-    def _prep(self, s: _SNConv, sigma: Tensor, transpose: bool = False, wscale: float = 1.0, out=None):
-        return ops.prep_weight(s.m.weight_orig.detach(), self.dtype, transpose=transpose,
-                               sigma=sigma[s.idx:s.idx + 1], wscale=wscale, out=out)
+    def _build_preps(self):
+        """Job lists of the forward and backward weight images (persistent buffers, sigma by index)."""
+        dt = self.dtype
+        dev = self.flat_p.flat.device
+        self.img = {}
 
-    def _prep_cat(self, a: _SNConv, b: _SNConv, sigma, transpose=False, scale_a=1.0, scale_b=1.0):
-        na = ops.weight_image_elems(a.cout, a.cin, a.ks, transpose)
-        nb = ops.weight_image_elems(b.cout, b.cin, b.ks, transpose)
-        buf = torch.empty(na + nb, dtype=self.dtype, device=sigma.device)
-        self._prep(a, sigma, transpose, scale_a, out=buf[:na])
-        self._prep(b, sigma, transpose, scale_b, out=buf[na:])
-        return buf
+        def img(name, s: _SNConv, transpose, parts=None):
+            n = ops.weight_image_elems(s.cout, s.cin, s.ks, transpose)
+            t = torch.empty(n, dtype=dt, device=dev)
+            self.img[name] = t
+            return t
+
+        def cat(name, a: _SNConv, b: _SNConv, transpose):
+            na = ops.weight_image_elems(a.cout, a.cin, a.ks, transpose)
+            nb = ops.weight_image_elems(b.cout, b.cin, b.ks, transpose)
+            t = torch.empty(na + nb, dtype=dt, device=dev)
+            self.img[name] = t
+            return t[:na], t[na:]
+
+        fwd, bwd = [], []
+        W = lambda s: s.m.weight_orig.detach()                                # noqa: E731
+        b0 = self.res[0]
+        c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
+        fwd += [(W(c1m), img('0.c1', c1m, False), False, 1, c1m.idx, 1.0),
+                (W(scm), img('0.sc', scm, False), False, 1, scm.idx, 1.0),
+                (W(c2m), img('0.c2', c2m, False), False, 1, c2m.idx, 1.0)]
+        bwd.append((W(c2m), img('0.c2t', c2m, True), True, 1, c2m.idx, 0.25))
+        ta, tb = cat('0.dimg', c1m, scm, True)
+        bwd += [(W(c1m), ta, True, 1, c1m.idx, 1.0), (W(scm), tb, True, 1, scm.idx, 0.25)]
+        for i, b in enumerate(self.res[1:], start=1):
+            c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
+            has_sc, pooled = len(b.shortcut) > 0, len(b.conv) == 7
+            a = 0.25 if pooled else 1.0
+            fwd.append((W(c1m), img(f'{i}.c1', c1m, False), False, 1, c1m.idx, 1.0))
+            if has_sc:
+                scm = self.sn_of[b.shortcut[1].module]
+                ta, tb = cat(f'{i}.c2s', c2m, scm, False)
+                fwd += [(W(c2m), ta, False, 1, c2m.idx, 1.0), (W(scm), tb, False, 1, scm.idx, 1.0)]
+                bwd.append((W(scm), img(f'{i}.sct', scm, True), True, 1, scm.idx, a))
+            else:
+                fwd.append((W(c2m), img(f'{i}.c2', c2m, False), False, 1, c2m.idx, 1.0))
+            bwd += [(W(c2m), img(f'{i}.c2t', c2m, True), True, 1, c2m.idx, a),
+                    (W(c1m), img(f'{i}.c1t', c1m, True), True, 1, c1m.idx, 1.0)]
+        self._prep_fwd, self._prep_bwd = ops.PrepBatch(fwd, dt), ops.PrepBatch(bwd, dt)
+
+    def _ensure_preps(self):
+        if self._prep_fwd is None or self._prep_fwd.dtype != self.dtype or not self._prep_fwd.valid():
+            self._build_preps()
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
@@ -335,40 +404,43 @@ class DiscriminatorEngine:
             for s in self.sn:
                 _bump(s.m.weight_u); _bump(s.m.weight_v)
         ctx = {'n': n, 'sigma': sigma, 'uv': fuv.clone(), 'blocks': []}   # torch's hook clones u, v too
+        self._ensure_preps()
+        self._prep_fwd.run(sigma)                 # every W / sigma image of this pass in one launch
+        codes = self._codes.run(indicator)
+        I = self.img
         img = ops.to_nhwc(x_nchw.detach().contiguous(), dt)
         ctx['img'] = img
         # --- FirstDisResBlock (mcgan.py:72-93)
         b0 = self.res[0]
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
-        code = b0.mc_1.code(indicator)
+        code = codes[0]
         co = c1m.cout
-        c1, _ = ops.conv_fused([Seg(img)], self._prep(c1m, sigma), co, bias=c1m.m.bias)
-        sc, _ = ops.conv_fused([Seg(img, ksize=1)], self._prep(scm, sigma), co, bias=scm.m.bias, pool=True, alpha=0.25)
-        y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], self._prep(c2m, sigma), co, bias=c2m.m.bias,
+        c1, _ = ops.conv_fused([Seg(img)], I['0.c1'], co, bias=c1m.m.bias)
+        sc, _ = ops.conv_fused([Seg(img, ksize=1)], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
+        y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], I['0.c2'], co, bias=c2m.m.bias,
                               pool=True, alpha=0.25, res=sc)
         ctx['blocks'].append({'c1': c1, 'code': code})
         x = y
         # --- DisResBlocks (mcgan.py:96-138)
-        for b in self.res[1:]:
+        for i, b in enumerate(self.res[1:], start=1):
             c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
             has_sc = len(b.shortcut) > 0
             pooled = len(b.conv) == 7
-            code1, code2 = b.mc_1.code(indicator), b.mc_2.code(indicator)
-            c1, _ = ops.conv_fused([Seg(x, code=code1, relu=True)], self._prep(c1m, sigma), c1m.cout, bias=c1m.m.bias)
+            code1, code2 = codes[2 * i - 1], codes[2 * i]
+            c1, _ = ops.conv_fused([Seg(x, code=code1, relu=True)], I[f'{i}.c1'], c1m.cout, bias=c1m.m.bias)
             if has_sc:
                 scm = self.sn_of[b.shortcut[1].module]
-                wimg = self._prep_cat(c2m, scm, sigma)
                 bias = c2m.m.bias.detach() + scm.m.bias.detach()
-                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1)], wimg, c2m.cout,
+                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1)], I[f'{i}.c2s'], c2m.cout,
                                       bias=bias, pool=pooled, alpha=0.25 if pooled else 1.0)
             else:
-                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True)], self._prep(c2m, sigma), c2m.cout,
+                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True)], I[f'{i}.c2'], c2m.cout,
                                       bias=c2m.m.bias, res=x)
             ctx['blocks'].append({'x': x, 'c1': c1, 'code1': code1, 'code2': code2, 'pooled': pooled, 'has_sc': has_sc})
             x = y
         # --- tail: ReLU -> MC -> global sum pool -> SN linear (mcgan.py:158-165)
         tl = self.sn_of[self.tail_lin]
-        codet = self.tail_mc.code(indicator)
+        codet = codes[-1]
         logit, pooled_feat = ops.dtail_fwd(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
                                            sigma[tl.idx:tl.idx + 1])
         ctx.update(xt=x, codet=codet, pooled=pooled_feat)
@@ -387,6 +459,9 @@ class DiscriminatorEngine:
         gtmp = torch.empty_like(fp) if want_w else None
         T = (lambda p: self.flat_p.view_of(gtmp, p)) if want_w else None       # noqa: E731
 
+        self._ensure_preps()
+        self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
+        I = self.img
         tl = self.sn_of[self.tail_lin]
         sg_t = sigma[tl.idx:tl.idx + 1]
         wl = self.tail_lin.weight_orig
@@ -403,14 +478,14 @@ class DiscriminatorEngine:
                           bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias) if has_sc else None)
                 if has_sc:
                     ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
-            dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], self._prep(c2m, sigma, True, a), c2m.cin, ocode=code2, gate_x=c1)
+            dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
             if want_w:
                 ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
             if has_sc:
-                res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], self._prep(scm, sigma, True, a), scm.cin, ocode=code1)
+                res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1)
             else:
                 res = dy
-            dy, _ = ops.conv_fused([Seg(dc1)], self._prep(c1m, sigma, True), c1m.cin, ocode=code1, gate_x=x, res=res)
+            dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
         # FirstDisResBlock
         b0, bc = self.res[0], ctx['blocks'][0]
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
@@ -419,13 +494,12 @@ class DiscriminatorEngine:
             ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25,
                       bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias))
             ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
-        dc1, _ = ops.conv_fused([Seg(dy, ups=True)], self._prep(c2m, sigma, True, 0.25), c2m.cin, ocode=code, gate_x=c1)
+        dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)
         if want_w:
             ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
         dimg = None
         if need_input_grad:
-            wimg = self._prep_cat(c1m, scm, sigma, transpose=True, scale_b=0.25)
-            dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], wimg, c1m.cin, cy=img.shape[-1])
+            dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
             dimg = ops.to_nchw(dimg_t, c1m.cin)
         if want_w:
             # d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used; biases are moved as is

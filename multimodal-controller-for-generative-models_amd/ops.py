@@ -396,3 +396,84 @@ def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, be
     assert step.dtype == torch.int64
     check(_lib.load().mcgen_adam(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, betas[0], betas[1], eps,
                                  weight_decay, _p(step), _stream()), 'adam')
+
+
+# ---- batched small launches (one launch per network pass instead of one per layer) ----------------------
+def _struct_table(arr, device) -> Tensor:
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+class PrepBatch:
+    """A fixed list of weight-image jobs (master weight -> persistent image buffer) run as ONE launch.
+    jobs: (weight tensor, image tensor, transpose, row_perm, sigma_idx or -1, wscale)."""
+
+    def __init__(self, jobs, dtype: torch.dtype):
+        self.dtype = dtype
+        self.jobs = jobs
+        arr = (_lib.Prep * len(jobs))()
+        for d, (w, img, transpose, row_perm, sidx, wscale) in zip(arr, jobs):
+            cout, cin = w.shape[0], w.shape[1]
+            ks = w.shape[2] if w.dim() == 4 else 1
+            assert img.numel() == weight_image_elems(cout, cin, ks, transpose) and img.dtype == dtype
+            d.w, d.image = _f32(w), _p(img)
+            d.Cout, d.Cin, d.ksize, d.transpose, d.row_perm, d.sigma_idx = cout, cin, ks, int(transpose), row_perm, sidx
+            d.wscale = float(wscale)
+        self.key = tuple((w.data_ptr(), img.data_ptr()) for w, img, *_ in jobs)
+        self.table = _struct_table(arr, jobs[0][0].device)
+        self.n = len(jobs)
+
+    def valid(self) -> bool:
+        return self.key == tuple((w.data_ptr(), img.data_ptr()) for w, img, *_ in self.jobs)
+
+    def run(self, sigma: Optional[Tensor] = None):
+        check(_lib.load().mcgen_prep_weight_batch(_p(self.table), self.n, _f32(sigma), _dt(self.dtype), _stream()),
+              'prep_weight_batch')
+
+
+class CodeBatch:
+    """Codes of a list of MultimodalController modules in ONE launch; rebuilt when a codebook buffer was
+    re-registered (models.utils.create / transit) or moved."""
+
+    def __init__(self, mcs):
+        self.mcs = list(mcs)
+        self._key = None
+
+    def _ensure(self):
+        key = tuple((m.codebook.data_ptr(), tuple(m.codebook.shape)) for m in self.mcs)
+        if key != self._key:
+            arr = (_lib.Code * len(self.mcs))()
+            off = 0
+            self.offsets = []
+            for d, m in zip(arr, self.mcs):
+                cb = m.codebook
+                if cb.dtype != torch.float32 or not cb.is_contiguous():
+                    raise _lib.McgenError('codebook must be a contiguous float32 buffer')
+                d.codebook, d.out_off, d.M, d.C = _p(cb), off, cb.shape[0], cb.shape[1]
+                self.offsets.append((off, cb.shape[1]))
+                off += 0                                   # per-forward: offsets scale with N, filled in run()
+            self._arr = arr
+            self._key = key
+            self._n_cached = None
+
+    def run(self, indicator: Tensor):
+        """-> list of [N, C] code tensors (views of one buffer), in module order."""
+        self._ensure()
+        n = indicator.shape[0]
+        if self._n_cached != n:
+            off = 0
+            for d in self._arr:
+                d.out_off = off
+                off += n * d.C
+            self._total = off
+            self._table = _struct_table(self._arr, indicator.device)
+            self._n_cached = n
+        if indicator.shape[1] != self._arr[0].M:
+            raise _lib.McgenError(f'indicator has {indicator.shape[1]} modes, codebook has {self._arr[0].M}')
+        buf = torch.empty(self._total, dtype=torch.float32, device=indicator.device)
+        check(_lib.load().mcgen_mc_code_batch(_f32(indicator.contiguous()), _p(self._table), len(self.mcs), _f32(buf), n,
+                                              _stream()), 'mc_code_batch')
+        out, off = [], 0
+        for d in self._arr:
+            out.append(buf[off:off + n * d.C].view(n, d.C))
+            off += n * d.C
+        return out
