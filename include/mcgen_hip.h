@@ -109,7 +109,7 @@ typedef struct {
     int32_t dy_ups;        /* 1: dy is the gradient of a 2x2-pooled output                  */
     float*  slabs;
     int32_t splits;
-    float*  bias_slabs;    /* [splits][Cout_w] partial column sums of dy (the bias gradient), or NULL      */
+    float*  bias_slabs;    /* [splits*4][Cout_w] partial column sums of dy (the bias gradient), or NULL    */
 } mcgen_wgrad_t;
 
 int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p);          /* floats per split */

@@ -10,6 +10,7 @@
 // fragments with scalar reads.  Pixel groups (blockIdx.z) write separate fp32 slabs in the
 // weight-image layout; mcgen_wgrad_reduce adds the slabs in a fixed order (deterministic).
 #include "conv_tile.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -161,7 +162,7 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
             for (int r = 0; r < WG_BM / 4; ++r)
                 bsum += E::to_f(*reinterpret_cast<const T*>(ldsD + (part * (WG_BM / 4) + r) * DPITCH + col * ESZ));
         }
-#pragma unroll (PRE ? KSTEPS : 1)
+#pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if constexpr (!PRE) make_off(ks, offA[0], offD[0]);
             const int (&oA)[KF::NOFF] = offA[PRE ? ks : 0];
@@ -181,12 +182,9 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     }
 
     if (do_bias) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        red[tid] = bsum;
-        __syncthreads();
-        if (tid < 64 && co0 + tid < p.Cout_w)
-            p.bias_slabs[(size_t)blockIdx.z * p.Cout_w + co0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        // four row-quarter partial sums per column; mcgen_wgrad_reduce adds all splits*4 rows in order
+        const int col = tid & 63, part = tid >> 6;
+        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)blockIdx.z * 4 + part) * p.Cout_w + co0 + col] = bsum;
     }
     // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15] of block (tap j, co fragment cf)
     const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
@@ -203,6 +201,160 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
                 if (co < p.Cout_w)
                     out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r];
             }
+    }
+}
+
+// ---- producer / consumer form -------------------------------------------------------------------------
+// The staging of a tile (global loads, prologue VALU, LDS stores) costs several times the MFMA time of
+// the tile, so the workgroup is split by role: waves 4-7 (producers) stage tile i+1 into the idle LDS
+// buffers while waves 0-3 (consumers) run the transposing reads + MFMAs of tile i; one barrier per tile.
+// VALU and MFMA issue from different waves of a SIMD overlap, which the single-role kernel cannot do.
+template <typename T, int KS, int LGW>
+__global__ __launch_bounds__(2 * WG_NT, 2)
+void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
+    using E = Elem<T>;
+    using M = Mma<T>;
+    using TR = WgTraits<T>;
+    using KF = KFrag<T>;
+    constexpr int ESZ = E::BYTES, APITCH = TR::APITCH, DPITCH = TR::DPITCH;
+    constexpr int NTAP = KS * KS;
+    constexpr int NCF = WG_BCO / 32;
+    constexpr int NI = (WG_BM * 9 + WG_NT - 1) / WG_NT;
+    constexpr int W = 1 << LGW, halo = KS >> 1, PC = W + 2 * halo;
+    constexpr int KSTEPS = WG_BM / 32;
+    constexpr int D_BYTES = WG_BM * DPITCH;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA0 = smem;                       // [2][a_bytes]
+    char* const ldsD0 = smem + 2 * a_bytes;         // [2][D_BYTES]
+
+    const int tid = threadIdx.x;
+    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    const int rtid = tid & 255;                     // thread index inside its role group
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, N = p.N;
+    const int co0 = blockIdx.x * WG_BCO;
+    const int q = blockIdx.y;
+    const int c0 = q * MCGEN_CK;
+    const mcgen_seg_t sg = p.seg;
+    const char* dy = reinterpret_cast<const char*>(p.dy);
+    const int Hd = p.dy_ups ? (H >> 1) : H, Wd = p.dy_ups ? (W >> 1) : W;
+    const int wa = wave >> 1, wb = wave & 1;
+    const Geo g0 = make_geo(WG_BM, 0, H, W);
+    const int PR = g0.TH + 2 * halo;
+    const int cnt = (m_tiles - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // tiles of this workgroup
+    const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
+    constexpr int DUNITS = WG_BCO * ESZ / 16;
+    constexpr int DITEMS = WG_BM * DUNITS / WG_NT;
+
+    if (producer) {
+        PatchStager<T, WG_NT, NI, APITCH> stager;
+        stager.setup_static(KS, g0, W, rtid);
+        auto stage_tile = [&](int i) {
+            const int tile = blockIdx.z + i * gridDim.z;
+            const Geo g = make_geo(WG_BM, tile, H, W);
+            char* ldsA = ldsA0 + (i & 1) * a_bytes;
+            char* ldsD = ldsD0 + (i & 1) * D_BYTES;
+            stager.bind(sg, g, N, H, W);
+            stager.stage(sg, c0, ldsA);
+#pragma unroll
+            for (int k = 0; k < DITEMS; ++k) {
+                const int it = rtid + k * WG_NT;
+                const int u = it % DUNITS, m = it / DUNITS;
+                const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+                const int r = rem >> LGW, c = rem & (W - 1);
+                const int n = g.n0 + ti, h = g.h0 + r;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                const int cob = (co0 * ESZ + u * 16);
+                if (n < N && cob < p.Cdy * ESZ) {
+                    const int hd = p.dy_ups ? (h >> 1) : h, wd = p.dy_ups ? (c >> 1) : c;
+                    v = *reinterpret_cast<const u32x4*>(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy * ESZ + cob);
+                }
+                *reinterpret_cast<u32x4*>(ldsD + m * DPITCH + u * 16) = v;
+            }
+        };
+        if (cnt > 0) stage_tile(0);
+        for (int i = 0; i < cnt; ++i) {
+            __syncthreads();                         // tile i published; buffers of tile i-1 are free
+            if (i + 1 < cnt) stage_tile(i + 1);
+        }
+        __syncthreads();                             // matches the consumers' final barrier
+        return;
+    }
+
+    // ---- consumers ---------------------------------------------------------------------------------------
+    f32x4 acc[NTAP][NCF];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    auto make_off = [&](int ks, int (&oa)[KF::NOFF], int (&od)[KF::NOFF]) {
+#pragma unroll
+        for (int j = 0; j < KF::NOFF; ++j) {
+            const int kk = (KF::NOFF == 2) ? (16 * j + 4 * lg + (l15 >> 2)) : (16 * (j >> 2) + 4 * lg + (j & 3));
+            const int m = ks * 32 + kk;
+            const int ti = m >> g0.lgTHW, rem = m & ((1 << g0.lgTHW) - 1);
+            const int r = rem >> LGW, c = rem & (W - 1);
+            const int colb = (KF::NOFF == 2) ? (l15 & 3) * 8 : l15 * 4;
+            oa[j] = ((ti * PR + r) * PC + c) * APITCH + colb + wb * 16 * ESZ;
+            od[j] = m * DPITCH + colb + wa * NCF * 16 * ESZ;
+        }
+    };
+    constexpr bool PRE = (KF::NOFF == 2);
+    int offA[PRE ? KSTEPS : 1][KF::NOFF], offD[PRE ? KSTEPS : 1][KF::NOFF];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) make_off(ks, offA[ks], offD[ks]);
+    }
+    for (int i = 0; i < cnt; ++i) {
+        __syncthreads();
+        const char* ldsA = ldsA0 + (i & 1) * a_bytes;
+        const char* ldsD = ldsD0 + (i & 1) * D_BYTES;
+        if (do_bias) {
+            const int col = rtid & 63, part = rtid >> 6;
+#pragma unroll 8
+            for (int r = 0; r < WG_BM / 4; ++r)
+                bsum += E::to_f(*reinterpret_cast<const T*>(ldsD + (part * (WG_BM / 4) + r) * DPITCH + col * ESZ));
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if constexpr (!PRE) make_off(ks, offA[0], offD[0]);
+            const int (&oA)[KF::NOFF] = offA[PRE ? ks : 0];
+            const int (&oD)[KF::NOFF] = offD[PRE ? ks : 0];
+            typename M::frag dfrag[NCF];
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KF::read(ldsD, oD, cf * 16 * ESZ);
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j) {
+                const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;
+                const typename M::frag afrag = KF::read(ldsA, oA, tapoff);
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf) M::run(dfrag[cf], afrag, acc[j][cf]);
+            }
+        }
+    }
+    __syncthreads();                                 // last barrier shared with the producers (they exit after it)
+    // slab[z][q][tap][co][32]
+    const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
+    float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int col = wb * 16 + l15;
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wa * NCF + cf) * 16 + lg * 4 + r;
+                if (co < p.Cout_w)
+                    out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r];
+            }
+    }
+    if (do_bias) {
+        const int col = rtid & 63, part = rtid >> 6;
+        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)blockIdx.z * 4 + part) * p.Cout_w + co0 + col] = bsum;
     }
 }
 
@@ -243,13 +395,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
         }
     }
     if (bias_slabs && bias_grad) {
-        for (size_t co = blockIdx.x * (size_t)blockDim.x + threadIdx.x; co < (size_t)Cout; co += stride) {
+        // one wave per output channel: lanes split the splits*4 partial rows, fixed-order butterfly
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        for (int co = blockIdx.x * nwv + wv; co < Cout; co += gridDim.x * nwv) {
             float s = 0.f;
-            for (int z = 0; z < splits; ++z) s += bias_slabs[(size_t)z * Cout_w + co];
-            s *= alpha;
-            const int com = row_perm > 1 ? ((int)co % Cc) * row_perm + (int)co / Cc : (int)co;
-            bias_grad[com] = accumulate ? bias_grad[com] + s : s;
-            if (bias_grad2) bias_grad2[com] = accumulate ? bias_grad2[com] + s : s;
+            for (int z = lane; z < splits * 4; z += 64) s += bias_slabs[(size_t)z * Cout_w + co];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) {
+                s *= alpha;
+                const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;
+                bias_grad[com] = accumulate ? bias_grad[com] + s : s;
+                if (bias_grad2) bias_grad2[com] = accumulate ? bias_grad2[com] + s : s;
+            }
         }
     }
 }
@@ -265,6 +422,21 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
     dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
+    const bool pc = mode ? (mode[0] == '1') : true;
+    if (pc) {
+        const int lds2 = 2 * a_bytes + 2 * WG_BM * TR::DPITCH;
+        auto kern2 = wgrad_pc_kernel<T, KS, LGW>;
+        static bool raised2 = false;
+        if (lds2 > 64 * 1024 && !raised2) {
+            raised2 = true;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern2, grid, dim3(2 * WG_NT), lds2, st, *p, a_bytes, m_tiles);
+        MCGEN_LAUNCH_CHECK("wgrad(pc)");
+        return 0;
+    }
     auto kern = wgrad_kernel<T, KS, LGW>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {

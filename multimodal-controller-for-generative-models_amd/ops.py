@@ -266,7 +266,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     p.slabs = _p(slabs)
     bias_slabs = None
     if bias_grad is not None:
-        bias_slabs = torch.empty((splits, pad16(cout)), dtype=torch.float32, device=dy.device)
+        bias_slabs = torch.empty((splits * 4, pad16(cout)), dtype=torch.float32, device=dy.device)
     p.bias_slabs = _p(bias_slabs)
     _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>',
            2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
