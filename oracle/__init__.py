@@ -6,9 +6,12 @@ import it, and only as the checker.  The product path (the package
 ``multimodal-controller-for-generative-models_amd`` / import alias ``mcgen_amd``)
 never imports this package and raises if its HIP library is missing.
 
+Modules: ``mcgan_oracle`` (headline model + train step), ``mcvae_oracle``,
+``mcglow_oracle``, ``mcpixelcnn_oracle``.
+
 Parity status: PINNED.  The reference publishes no golden vectors (SURVEY.md
 section 4), so the oracle is pinned by vectors produced by importing the
 reference's ``models``/``modules`` packages on CPU in the build container
 (``tools/gen_golden.py``; committed fixtures under ``tests/golden/``) and
-checked by ``tests/test_oracle_golden.py``.
+checked by ``tests/test_oracle_golden.py`` and ``tests/test_oracle_other_models.py``.
 """

@@ -81,6 +81,38 @@ def procedural_state(shapes: Dict[str, tuple], seed: int, num_mode: int) -> Dict
     return sd
 
 
+def procedural_state_generic(shapes: Dict[str, tuple], seed: int) -> Dict[str, torch.Tensor]:
+    """Stand-in weights for any reference-format state dict (used where aliasing does not matter):
+    matrices/filters ~ U(+-sqrt(3/fan_in)), BN weights ~ N(1, 0.02), biases small, codebooks distinct
+    Bernoulli(0.5) rows shared per (modes, width) position by key order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, torch.Tensor] = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        leaf = k.rsplit('.', 1)[-1]
+        if leaf == 'codebook':
+            while True:
+                cb = (rng.random(shp) < 0.5).astype(np.float32)
+                if len({tuple(r) for r in cb.tolist()}) == shp[0]:
+                    break
+            sd[k] = torch.from_numpy(cb)
+        elif leaf == 'running_mean':
+            sd[k] = torch.zeros(shp)
+        elif leaf == 'running_var':
+            sd[k] = torch.ones(shp)
+        elif leaf == 'num_batches_tracked':
+            sd[k] = torch.zeros(shp, dtype=torch.int64)
+        elif leaf == 'bias':
+            sd[k] = torch.from_numpy(rng.uniform(-0.05, 0.05, shp).astype(np.float32))
+        elif len(shp) == 1:
+            sd[k] = torch.from_numpy((1.0 + 0.02 * rng.standard_normal(shp)).astype(np.float32))
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            a = float(np.sqrt(3.0 / fan_in))
+            sd[k] = torch.from_numpy(rng.uniform(-a, a, shp).astype(np.float32))
+    return sd
+
+
 def _codebook_owner(key: str) -> str:
     """Map an aliased codebook key to its owning module's key (mc_1 / mc_2)."""
     parts = key.split('.')

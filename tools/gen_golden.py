@@ -273,6 +273,150 @@ def fx_dp_emulation():
 
 FIXTURES['dp'] = fx_dp_emulation
 
+class _PatchedNoise:
+    """Make torch.randn_like / torch.rand_like return (and record) tensors from a seeded CPU generator,
+    so the noise the reference draws INSIDE its models becomes part of the fixture."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.drawn = []
+
+    def __enter__(self):
+        self._randn_like, self._rand_like = torch.randn_like, torch.rand_like
+        torch.randn_like = lambda t, **k: self._draw(torch.randn(t.shape, generator=self.g))
+        torch.rand_like = lambda t, **k: self._draw(torch.rand(t.shape, generator=self.g))
+        return self
+
+    def _draw(self, t):
+        self.drawn.append(t.clone())
+        return t
+
+    def __exit__(self, *a):
+        torch.randn_like, torch.rand_like = self._randn_like, self._rand_like
+
+
+def _single_opt_steps(model, inputs, noise_seed, steps, arrays, clip=1.0, lr=3e-4):
+    """train_vae.py:98-126 / train_glow.py / train_pixelcnn.py loop body: zero_grad, forward, backward,
+    clip_grad_norm_(1), Adam(lr 3e-4).step()."""
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for s in range(steps):
+        with _PatchedNoise(noise_seed + s) as pn:
+            opt.zero_grad()
+            out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()})
+            out['loss'].backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            opt.step()
+        losses.append(out['loss'].item())
+        for j, t in enumerate(pn.drawn):
+            arrays[f'noise/{s}/{j}'] = t.numpy()
+        if s == 0:
+            first = out
+    arrays['losses'] = np.array(losses, dtype=np.float64)
+    return first
+
+
+def fx_mcvae_small():
+    """MCVAE (config 0 family), reduced width [8, 16, 32], latent 16, B=8, 3 optimizer steps."""
+    import models
+    cfg['model_name'] = 'mcvae'; cfg['data_name'] = 'CIFAR10'; cfg['device'] = 'cpu'; cfg['classes_size'] = 10
+    cfg['controller_rate'] = 0.5; cfg['data_shape'] = [3, 32, 32]
+    cfg['vae'] = {'hidden_size': [8, 16, 32], 'latent_size': 16, 'num_res_block': 2, 'embedding_size': 32}
+    torch.manual_seed(0)
+    model = models.mcvae(); model.train(True)
+    arrays = np_state(model.state_dict(), 'sd/')
+    img, lab = gu.synthetic_batch(8, 10, seed=31)
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy()
+    first = _single_opt_steps(model, {'img': img, 'label': lab}, 100, 3, arrays)
+    arrays['mu0'] = first['mu'].detach().numpy(); arrays['logvar0'] = first['logvar'].detach().numpy()
+    arrays['img0'] = first['img'].detach().numpy()
+    arrays.update(np_state(model.state_dict(), 'sd_final/'))
+    model.train(False)
+    z = torch.randn(8, 16, generator=torch.Generator().manual_seed(5))
+    arrays['gen_z'] = z.numpy()
+    with torch.no_grad():
+        arrays['generated_eval'] = model.generate(lab, z).numpy()
+    save('mcvae_small.npz', **arrays)
+
+
+def fx_mcvae_full():
+    """Config 0 of BASELINE.json: MCVAE CIFAR-10 (hidden [64,128,256], latent 128), batch 32, on CPU:
+    losses of 2 optimizer steps + output digests; weights = the reference's own seed-0 init, stored."""
+    import models
+    cfg['model_name'] = 'mcvae'; cfg['data_name'] = 'CIFAR10'; cfg['device'] = 'cpu'; cfg['classes_size'] = 10
+    cfg['controller_rate'] = 0.5; cfg['data_shape'] = [3, 32, 32]
+    cfg['vae'] = {'hidden_size': [64, 128, 256], 'latent_size': 128, 'num_res_block': 2, 'embedding_size': 32}
+    torch.manual_seed(0)
+    model = models.mcvae(); model.train(True)
+    assert sum(p.numel() for p in model.parameters()) == 7628931
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gu.procedural_state_generic(shapes, seed=4321)
+    model.load_state_dict(sd)
+    arrays = {'shape_keys': np.array(sorted(shapes)), 'shape_vals': np.array([str(shapes[k]) for k in sorted(shapes)])}
+    img, lab = gu.synthetic_batch(32, 10, seed=1)
+    first = _single_opt_steps(model, {'img': img, 'label': lab}, 200, 2, arrays)
+    arrays['mu0_digest'] = gu.checksum(first['mu']); arrays['img0_digest'] = gu.checksum(first['img'])
+    arrays['img0_sample'] = first['img'].detach().numpy()[:4, :, ::4, ::4].copy()
+    save('mcvae_full_digest.npz', **arrays)
+
+
+def fx_mcpixelcnn_small():
+    """MCGatedPixelCNN, hidden 16, 4 layers, 32 codes, 8x8 code maps, B=6, 3 optimizer steps."""
+    import models
+    cfg['model_name'] = 'mcpixelcnn'; cfg['device'] = 'cpu'; cfg['classes_size'] = 10; cfg['controller_rate'] = 0.5
+    cfg['pixelcnn'] = {'num_layer': 4, 'hidden_size': 16, 'num_embedding': 32}
+    torch.manual_seed(0)
+    model = models.mcpixelcnn(); model.train(True)
+    arrays = np_state(model.state_dict(), 'sd/')
+    g = torch.Generator().manual_seed(41)
+    codes = torch.randint(0, 32, (6, 8, 8), generator=g)
+    lab = torch.randint(0, 10, (6,), generator=g)
+    arrays['codes'] = codes.numpy(); arrays['label'] = lab.numpy()
+    first = _single_opt_steps(model, {'img': codes, 'label': lab}, 300, 3, arrays)
+    arrays['logits0'] = first['logits'].detach().numpy()
+    arrays.update(np_state(model.state_dict(), 'sd_final/'))
+    model.train(False)
+    with torch.no_grad():
+        arrays['logits_eval'] = model({'img': codes, 'label': lab})['logits'].numpy()
+    save('mcpixelcnn_small.npz', **arrays)
+
+
+def fx_mcglow_small():
+    """MCGlow [1,32,32], K=2, L=3, hidden 32, 12 modes, B=4: ActNorm data init (first forward), 2 optimizer
+    steps, reverse(reconstruct) and sampling from fixed z."""
+    import models
+    cfg['model_name'] = 'mcglow'; cfg['device'] = 'cpu'; cfg['classes_size'] = 12; cfg['controller_rate'] = 0.5
+    cfg['data_shape'] = [1, 32, 32]
+    cfg['glow'] = {'hidden_size': 32, 'K': 2, 'L': 3, 'affine': True, 'conv_lu': True}
+    torch.manual_seed(0); np.random.seed(0)
+    model = models.mcglow(); model.train(True)
+    arrays = np_state(model.state_dict(), 'sd/')
+    img, lab = gu.synthetic_batch(4, 12, seed=51, shape=(1, 32, 32))
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy()
+    with _PatchedNoise(400) as pn, torch.no_grad():                       # train_glow.py:60-67 data-dependent init
+        model({'img': img.clone(), 'label': lab})
+    arrays['noise/init/0'] = pn.drawn[0].numpy()
+    arrays.update(np_state(model.state_dict(), 'sd_init/'))
+    first = _single_opt_steps(model, {'img': img, 'label': lab}, 500, 2, arrays)
+    for i, z in enumerate(first['z']):
+        arrays[f'z0/{i}'] = z.detach().numpy()
+    arrays.update(np_state(model.state_dict(), 'sd_final/'))
+    model.train(False)
+    with torch.no_grad(), _PatchedNoise(600) as pn:
+        out = model({'img': img.clone(), 'label': lab})
+        arrays['noise/eval/0'] = pn.drawn[0].numpy()
+        arrays['loss_eval'] = np.array(out['loss'].item())
+        rec = model.reverse({'z': out['z'], 'label': lab, 'reconstruct': True})['img']
+        arrays['reconstructed'] = rec.numpy()
+        gz = [torch.randn(4, *s, generator=torch.Generator().manual_seed(7 + i)) * 0.7 for i, s in enumerate(model.make_z_shapes())]
+        for i, z in enumerate(gz):
+            arrays[f'gen_z/{i}'] = z.numpy()
+        arrays['generated'] = model.generate(lab, gz).numpy()
+    save('mcglow_small.npz', **arrays)
+
+
+FIXTURES.update(mcvae_small=fx_mcvae_small, mcvae_full=fx_mcvae_full, mcpixelcnn=fx_mcpixelcnn_small, mcglow=fx_mcglow_small)
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
