@@ -727,6 +727,152 @@ void conv_dma_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "dma3" form: as "dma", but THREE taps per barrier ------------------------------------------------
+// A ring slot holds the weight tiles of a group of up to 3 taps (one kernel row of a 3x3 filter); the
+// group after the current one is in flight (2 slots).  Every group issues the same number of DMA
+// instructions (short groups re-load their last tap), so the counted vmcnt is a compile-time constant.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+    constexpr int TPS = 3;
+    constexpr int NW = WM * WN;
+    constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
+    constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
+    constexpr int SLOT = TPS * C::BBYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    // group bookkeeping over the linear (segment, chunk, tap) sequence
+    const int nt0 = p.seg[0].ksize * p.seg[0].ksize, nc0 = (p.seg[0].C + MCGEN_CK - 1) / MCGEN_CK;
+    const int gpc0 = (nt0 == 9) ? 3 : 1;                   // groups per chunk
+    const int G0 = nc0 * gpc0, S0 = nc0 * nt0;
+    int nt1 = 1, nc1 = 0, gpc1 = 1;
+    if (p.nseg > 1) { nt1 = p.seg[1].ksize * p.seg[1].ksize; nc1 = (p.seg[1].C + MCGEN_CK - 1) / MCGEN_CK; gpc1 = (nt1 == 9) ? 3 : 1; }
+    const int GT = G0 + nc1 * gpc1;                        // total groups
+
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    int d_src[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+        const int lgrp = grp ^ (3 * ((row >> 3) & 1));
+        d_src[k] = (piece < KB && cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : -1;
+    }
+    auto G_dma = [&](int gi) {                             // all taps of group gi -> slot gi & 1
+        if (gi >= GT) return;
+        int blk0, ntg;
+        if (gi < G0) { ntg = (nt0 == 9) ? 3 : 1; blk0 = gi * ntg; }
+        else { const int gj = gi - G0; ntg = (nt1 == 9) ? 3 : 1; blk0 = S0 + gj * ntg; }
+        char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+            const int blk = blk0 + (t < ntg ? t : ntg - 1);        // short group: re-load the last tap (constant DMA count)
+            const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) {
+                const int piece = wave * PPW + k;
+                if (piece < KB) {
+                    const char* src = wb + (d_src[k] >= 0 ? d_src[k] : (lane % UPR) * 16);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(slot + t * C::BBYTES + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
+
+    int gi = 0;
+    G_dma(0);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, NT, C::NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+        const int gpc = (ntap == 9) ? 3 : 1, ntg = (ntap == 9) ? 3 : 1;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; ++q) {
+            __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
+            stager.stage(sg, q * MCGEN_CK, ldsA);
+#pragma unroll 1
+            for (int gq = 0; gq < gpc; ++gq) {
+                // this group's tiles have landed (this wave's pieces); then all waves' pieces + window writes
+                if (gi + 1 < GT) { /* the next group is NOT yet issued here: nothing newer in flight */ }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                G_dma(gi + 1);                            // slot (gi+1)&1: its readers (group gi-1) passed the barrier
+                const char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) {
+                    if (t < ntg) {
+                        const int tap = gq * ntg + t;
+                        const int kh = (ntap == 9) ? tap / 3 : 0, kw = (ntap == 9) ? tap % 3 : 0;
+                        const int tapoff = (kh * PC + kw) * APITCH;
+                        const char* ldsB = slot + t * C::BBYTES;
+                        typename M::frag af[FM], wf[FN];
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm)
+                            af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+                            wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                            for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                    }
+                }
+                ++gi;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct TilePick { int BM, BN, pipe; };
 
@@ -743,14 +889,15 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     }
     const int HW = p->H * p->W;
     if (env_bm > 0 && ((env_bm >= 2 * p->W) || HW <= env_bm)) return {env_bm, env_bn, env_pipe};
-    // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring ("dma" form, mode 4)
-    // wins on every shape; big tiles only where there are enough pixels to fill 256 CUs
+    // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring with three taps per
+    // barrier ("dma3" form, mode 5) wins on every shape; big tiles only where there are enough pixels to
+    // fill 256 CUs
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
-    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 4};
-    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 4};
-    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 128, 4};
-    if (M >= 32768 && p->Cout_w > 64) return {64, 128, 4};
-    return {64, 64, 4};
+    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 5};
+    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
+    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, 5};
+    if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
+    return {64, 64, 5};
 }
 
 static int patch_pixels(const mcgen_conv_t* p, int BM) {
@@ -816,7 +963,7 @@ static int launch_direct(const mcgen_conv_t* p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int TPS = 1>
 static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     const long Mtot = (long)p->N * p->H * p->W;
@@ -825,12 +972,12 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     const int PP = patch_pixels(p, BM);
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
     const int a_bytes = round_up(PP * C::APITCH, 1024);
-    int lds = a_bytes + 3 * C::BBYTES;
+    int lds = a_bytes + (TPS == 3 ? 6 : 3) * C::BBYTES;
     const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
-    auto kern = conv_dma_kernel<T, BM, BN, WM, WN>;
+    auto kern = (TPS == 3) ? conv_dma3_kernel<T, BM, BN, WM, WN> : conv_dma_kernel<T, BM, BN, WM, WN>;
     static int raised = 0;
     if (lds > 64 * 1024 && lds > raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -874,6 +1021,9 @@ static const CfgEntry* bf16_table(int* n) {
         {256, 256, 4, launch_dma<T, 256, 256, 2, 4>}, {128, 256, 4, launch_dma<T, 128, 256, 2, 4>},
         {256, 128, 4, launch_dma<T, 256, 128, 4, 2>}, {128, 128, 4, launch_dma<T, 128, 128, 2, 2>},
         {64, 128, 4, launch_dma<T, 64, 128, 2, 2>},   {64, 64, 4, launch_dma<T, 64, 64, 2, 2>},
+        {256, 256, 5, launch_dma<T, 256, 256, 2, 4, 3>}, {128, 256, 5, launch_dma<T, 128, 256, 2, 4, 3>},
+        {256, 128, 5, launch_dma<T, 256, 128, 4, 2, 3>}, {128, 128, 5, launch_dma<T, 128, 128, 2, 2, 3>},
+        {64, 128, 5, launch_dma<T, 64, 128, 2, 2, 3>},   {64, 64, 5, launch_dma<T, 64, 64, 2, 2, 3>},
         {128, 256, 3, launch_direct<T, 128, 256, true>}, {128, 128, 3, launch_direct<T, 128, 128, true>},
         {64, 256, 3, launch_direct<T, 64, 256, true>},   {64, 128, 3, launch_direct<T, 64, 128, true>},
         {128, 64, 3, launch_direct<T, 128, 64, true>},   {64, 64, 3, launch_direct<T, 64, 64, true>},
