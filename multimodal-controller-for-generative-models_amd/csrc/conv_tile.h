@@ -162,6 +162,69 @@ struct PatchStager {
         }
     }
 
+    // ---- forms with caller-held per-tile metadata (two tiles in flight: wgrad producers) ----------------
+    __device__ __forceinline__ void bind_into(const mcgen_seg_t& sg, const Geo& g, int N, int H, int W,
+                                              int (&src)[NI], int (&nn)[NI]) const {
+        const int halo = sg.ksize >> 1;
+        const int Hs = sg.ups ? (H >> 1) : H, Ws = sg.ups ? (W >> 1) : W;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            src[k] = -1; nn[k] = 0;
+            if (it_lds[k] >= 0) {
+                const int pr = it_pos[k] & 255, pc = (it_pos[k] >> 8) & 255, ti = it_pos[k] >> 16;
+                const int n = g.n0 + ti, h = g.h0 + pr - halo, w = pc - halo;
+                nn[k] = n;
+                if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                    const int hs = sg.ups ? (h >> 1) : h, ws = sg.ups ? (w >> 1) : w;
+                    src[k] = ((n * Hs + hs) * Ws + ws) * sg.C + it_sub[0];
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void load_ext(const mcgen_seg_t& sg, int c0, const int (&src)[NI], raw_t& raw) const {
+        const char* xs = reinterpret_cast<const char*>(sg.x);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+#pragma unroll
+            for (int j = 0; j < E::BYTES / 2; ++j) raw[k][j] = u32x4{0u, 0u, 0u, 0u};
+            if (it_lds[k] >= 0 && src[k] >= 0 && c0 + it_sub[0] < sg.C) {
+                const char* p = xs + ((size_t)src[k] + c0) * E::BYTES;
+#pragma unroll
+                for (int j = 0; j < E::BYTES / 2; ++j) raw[k][j] = *reinterpret_cast<const u32x4*>(p + 16 * j);
+            }
+        }
+    }
+    __device__ __forceinline__ void write_ext(const mcgen_seg_t& sg, int c0, const int (&src)[NI], const int (&nn)[NI],
+                                              const raw_t& raw, char* ldsA) const {
+        const int c = c0 + it_sub[0];
+        const bool cok = c < sg.C;
+        float sc[8], sh[8];
+        if (sg.scale && cok) { load8f(sg.scale + c, sc); load8f(sg.shift + c, sh); }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (it_lds[k] < 0) continue;
+            float v[8];
+            unpack(raw[k], v);
+            if (src[k] >= 0 && cok) {
+                if (sg.scale) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (sg.code) {
+                    float cd[8];
+                    load8f(sg.code + (size_t)nn[k] * sg.C + c, cd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd[i];
+                }
+            }
+            E::store8(reinterpret_cast<T*>(ldsA + it_lds[k]), v);
+        }
+    }
+
     // non-pipelined form: item by item (load, prologue, LDS store) -- few live registers, so several
     // workgroups fit on a CU and hide each other's latency
     __device__ __forceinline__ void stage(const mcgen_seg_t& sg, int c0, char* ldsA) const {

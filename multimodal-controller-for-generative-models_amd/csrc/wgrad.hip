@@ -251,33 +251,53 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     if (producer) {
         PatchStager<T, WG_NT, NI, APITCH> stager;
         stager.setup_static(KS, g0, W, rtid);
-        auto stage_tile = [&](int i) {
+        // Two register sets: while the tile that is due next goes through the prologue into LDS, the loads
+        // of the tile after it are already in flight (prefetch distance of two tiles).
+        struct TileRegs {
+            int src[NI], nn[NI];
+            typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw;
+            u32x4 d[DITEMS];
+        };
+        auto fetch = [&](int i, TileRegs& r) {
             const int tile = blockIdx.z + i * gridDim.z;
             const Geo g = make_geo(WG_BM, tile, H, W);
-            char* ldsA = ldsA0 + (i & 1) * a_bytes;
-            char* ldsD = ldsD0 + (i & 1) * D_BYTES;
-            stager.bind(sg, g, N, H, W);
-            stager.stage(sg, c0, ldsA);
+            stager.bind_into(sg, g, N, H, W, r.src, r.nn);
+            stager.load_ext(sg, c0, r.src, r.raw);
 #pragma unroll
             for (int k = 0; k < DITEMS; ++k) {
                 const int it = rtid + k * WG_NT;
                 const int u = it % DUNITS, m = it / DUNITS;
                 const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
-                const int r = rem >> LGW, c = rem & (W - 1);
-                const int n = g.n0 + ti, h = g.h0 + r;
-                u32x4 v = {0u, 0u, 0u, 0u};
+                const int r_ = rem >> LGW, c = rem & (W - 1);
+                const int n = g.n0 + ti, h = g.h0 + r_;
+                r.d[k] = u32x4{0u, 0u, 0u, 0u};
                 const int cob = (co0 * ESZ + u * 16);
                 if (n < N && cob < p.Cdy * ESZ) {
                     const int hd = p.dy_ups ? (h >> 1) : h, wd = p.dy_ups ? (c >> 1) : c;
-                    v = *reinterpret_cast<const u32x4*>(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy * ESZ + cob);
+                    r.d[k] = *reinterpret_cast<const u32x4*>(dy + ((size_t)(n * Hd + hd) * Wd + wd) * p.Cdy * ESZ + cob);
                 }
-                *reinterpret_cast<u32x4*>(ldsD + m * DPITCH + u * 16) = v;
             }
         };
-        if (cnt > 0) stage_tile(0);
-        for (int i = 0; i < cnt; ++i) {
-            __syncthreads();                         // tile i published; buffers of tile i-1 are free
-            if (i + 1 < cnt) stage_tile(i + 1);
+        auto commit = [&](int i, const TileRegs& r) {
+            stager.write_ext(sg, c0, r.src, r.nn, r.raw, ldsA0 + (i & 1) * a_bytes);
+            char* ldsD = ldsD0 + (i & 1) * D_BYTES;
+#pragma unroll
+            for (int k = 0; k < DITEMS; ++k) {
+                const int it = rtid + k * WG_NT;
+                *reinterpret_cast<u32x4*>(ldsD + (it / DUNITS) * DPITCH + (it % DUNITS) * 16) = r.d[k];
+            }
+        };
+        TileRegs ra, rb;
+        if (cnt > 0) { fetch(0, ra); commit(0, ra); }
+        if (cnt > 1) fetch(1, ra);
+        for (int i = 0; i < cnt; i += 2) {
+            __syncthreads();                         // tile i published; the buffers of tile i-1 are free
+            if (i + 2 < cnt) fetch(i + 2, rb);
+            if (i + 1 < cnt) commit(i + 1, ra);
+            if (i + 1 >= cnt) break;
+            __syncthreads();                         // tile i+1 published
+            if (i + 3 < cnt) fetch(i + 3, ra);
+            if (i + 2 < cnt) commit(i + 2, rb);
         }
         __syncthreads();                             // matches the consumers' final barrier
         return;
@@ -423,7 +443,8 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int lds = a_bytes + WG_BM * TR::DPITCH;
     dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
     const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
-    const bool pc = mode ? (mode[0] == '1') : true;
+    // the role split only pays when a workgroup walks several tiles (staging of tile i+1 overlaps tile i)
+    const bool pc = mode ? (mode[0] == '1') : (m_tiles >= 4 * p->splits);
     if (pc) {
         const int lds2 = 2 * a_bytes + 2 * WG_BM * TR::DPITCH;
         auto kern2 = wgrad_pc_kernel<T, KS, LGW>;

@@ -8,6 +8,7 @@ Nothing here has a CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -231,7 +232,11 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     def _name():
         bm, bn = C.c_int(), C.c_int()
         lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
-        return f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}>'
+        base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}>'
+        if _os.environ.get('MCGEN_PROF_SHAPES'):
+            base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
+                ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')
+        return base
     _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'))
     return y, stats
 
@@ -258,6 +263,8 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     nchunk = (seg.x.shape[-1] + 31) // 32
     if splits is None:
         blocks = ((pad16(cout) + 63) // 64) * nchunk
+        # enough workgroups to fill the chip matters more than the slab traffic (measured: 8x8 layers lose
+        # 20 % with 16 instead of 64 splits)
         splits = max(1, min(m_tiles, (512 + blocks - 1) // blocks, 64))
     p.splits = splits
     lib = _lib.load()
@@ -268,7 +275,8 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     if bias_grad is not None:
         bias_slabs = torch.empty((splits * 4, pad16(cout)), dtype=torch.float32, device=dy.device)
     p.bias_slabs = _p(bias_slabs)
-    _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>',
+    _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>' + (
+        f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _os.environ.get('MCGEN_PROF_SHAPES') else ''),
            2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
            lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
