@@ -873,6 +873,176 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "res" form: whole input window resident --------------------------------------------------------------
+// For layers with few pixels (8x8, 16x16 maps) a workgroup's MFMA time is a few microseconds, so every
+// exposed global round trip shows.  Here ALL channels of the tile's input window are staged once (all
+// loads in flight together), the weight tiles stream through a 3-slot LDS-DMA ring of 3-tap groups two
+// groups ahead, and the main loop is barrier + MFMAs only.  LDS: window [pixel][C] at pitch 2C+32 bytes.
+template <typename T, int BM, int BN, int WM, int WN, int NQ, int RB>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_res_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, BROW = C::BROW;
+    constexpr int TPS = 3, DIST = RB - 1;                  // ring slots; groups in flight ahead of the consumer
+    constexpr int NW = WM * WN;
+    constexpr int KB = C::BBYTES / 1024;
+    constexpr int PPW = (KB + NW - 1) / NW;
+    constexpr int SLOT = TPS * C::BBYTES;
+    constexpr int NIR = (BM * 9 + NT - 1) / NT;            // staging items per thread per 32-channel chunk
+    static_assert(PPW * TPS * (DIST - 1) <= 63, "vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    const int nt0 = p.seg[0].ksize * p.seg[0].ksize, nc0 = (p.seg[0].C + MCGEN_CK - 1) / MCGEN_CK;
+    const int G0 = nc0 * ((nt0 == 9) ? 3 : 1), S0 = nc0 * nt0;
+    int nt1 = 1, nc1 = 0;
+    if (p.nseg > 1) { nt1 = p.seg[1].ksize * p.seg[1].ksize; nc1 = (p.seg[1].C + MCGEN_CK - 1) / MCGEN_CK; }
+    const int GT = G0 + nc1 * ((nt1 == 9) ? 3 : 1);
+
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    int d_src[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+        const int lgrp = grp ^ (3 * ((row >> 3) & 1));
+        d_src[k] = (piece < KB && cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : -1;
+    }
+    auto G_dma = [&](int gi) {
+        if (gi >= GT) return;
+        int blk0, ntg;
+        if (gi < G0) { ntg = (nt0 == 9) ? 3 : 1; blk0 = gi * ntg; }
+        else { const int gj = gi - G0; ntg = (nt1 == 9) ? 3 : 1; blk0 = S0 + gj * ntg; }
+        char* slot = ldsB0 + (gi % RB) * SLOT;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+            const int blk = blk0 + (t < ntg ? t : ntg - 1);
+            const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) {
+                const int piece = wave * PPW + k;
+                if (piece < KB) {
+                    const char* src = wb + (d_src[k] >= 0 ? d_src[k] : (lane % UPR) * 16);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(slot + t * C::BBYTES + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
+
+    int gi = 0;
+#pragma unroll
+    for (int j = 0; j < DIST; ++j) G_dma(j);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int apitch = nchunk * MCGEN_CK * ESZ + 16 * ESZ;       // bytes per window pixel: all channels + pad
+        // ---- stage the whole window: all chunks' loads first, then prologue + LDS stores -----------------
+        {
+            // the stager works on 32-channel chunks with its own (compile-time) pitch; here the pitch is a run
+            // time value, so the LDS offsets are recomputed: pixel index = it_lds / CHUNK_PITCH
+            constexpr int CP = MCGEN_CK * ESZ + 16 * ESZ;
+            PatchStager<T, NT, NIR, CP> stager;
+            stager.setup(sg, g, N, H, W, tid);
+            typename PatchStager<T, NT, NIR, CP>::raw_t raw[NQ];
+            if (s > 0) __builtin_amdgcn_s_barrier();       // previous segment's window reads are done
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nchunk) stager.load(sg, q * MCGEN_CK, raw[q]);
+            // re-base the LDS offsets to the resident layout
+#pragma unroll
+            for (int k = 0; k < NIR; ++k)
+                if (stager.it_lds[k] >= 0) {
+                    const int pp = stager.it_lds[k] / CP, sub = stager.it_lds[k] % CP;
+                    stager.it_lds[k] = pp * apitch + sub;
+                }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nchunk) stager.write(sg, q * MCGEN_CK, raw[q], ldsA + q * MCGEN_CK * ESZ);
+        }
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * apitch + lg * 8 * ESZ;
+        }
+        const int ntap = sg.ksize * sg.ksize;
+        const int gpc = (ntap == 9) ? 3 : 1, ntg = (ntap == 9) ? 3 : 1;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; ++q) {
+#pragma unroll 1
+            for (int gq = 0; gq < gpc; ++gq) {
+                // group gi landed (this wave's pieces; gi+1 may still be in flight), then everyone's + the window
+                // DIST-1 newer groups are in flight behind group gi (fewer near the end: then drain)
+                if (gi + DIST - 1 < GT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * TPS * (DIST - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                G_dma(gi + DIST);                         // slot (gi+DIST)%RB == (gi-1)%RB: its readers passed the barrier
+                const char* slot = ldsB0 + (gi % RB) * SLOT;
+                const char* ldsAq = ldsA + q * MCGEN_CK * ESZ;
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) {
+                    if (t < ntg) {
+                        const int tap = gq * ntg + t;
+                        const int kh = (ntap == 9) ? tap / 3 : 0, kw = (ntap == 9) ? tap % 3 : 0;
+                        const int tapoff = (kh * PC + kw) * apitch;
+                        const char* ldsB = slot + t * C::BBYTES;
+                        typename M::frag af[FM], wf[FN];
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm)
+                            af[fm] = *reinterpret_cast<const typename M::frag*>(ldsAq + a_base[fm] + tapoff);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+                            wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                            for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                    }
+                }
+                ++gi;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct TilePick { int BM, BN, pipe; };
 
@@ -897,7 +1067,9 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, 5};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
-    return {64, 64, 5};
+    int small_mode = 5;
+    if (const char* e = getenv("MCGEN_CONV_SMALL")) small_mode = atoi(e);       // tuning override for the 64x64 fallback
+    return {64, 64, small_mode};
 }
 
 static int patch_pixels(const mcgen_conv_t* p, int BM) {
@@ -989,6 +1161,37 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NQ, int RB>
+static int launch_res(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)((Mtot + BM - 1) / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= ((BM * 9 + C::NT - 1) / C::NT) * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
+    int cmax = 0;
+    for (int s = 0; s < p->nseg; ++s) if (p->seg[s].C > cmax) cmax = p->seg[s].C;
+    const int nchunk = (cmax + MCGEN_CK - 1) / MCGEN_CK;
+    MCGEN_CHECK(nchunk <= NQ, "conv_fused(res): %d channels exceed the resident window plan", cmax);
+    const int apitch = nchunk * MCGEN_CK * C::ESZ + 16 * C::ESZ;
+    const int a_bytes = round_up(PP * apitch, 1024);
+    int lds = a_bytes + RB * 3 * C::BBYTES;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(res): tile %dx%d with %d channels needs %d bytes of LDS", BM, BN, cmax, lds);
+    auto kern = conv_res_kernel<T, BM, BN, WM, WN, NQ, RB>;
+    static int raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+        raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(res)");
+    return 0;
+}
+
 typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
 struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
 
@@ -1024,6 +1227,10 @@ static const CfgEntry* bf16_table(int* n) {
         {256, 256, 5, launch_dma<T, 256, 256, 2, 4, 3>}, {128, 256, 5, launch_dma<T, 128, 256, 2, 4, 3>},
         {256, 128, 5, launch_dma<T, 256, 128, 4, 2, 3>}, {128, 128, 5, launch_dma<T, 128, 128, 2, 2, 3>},
         {64, 128, 5, launch_dma<T, 64, 128, 2, 2, 3>},   {64, 64, 5, launch_dma<T, 64, 64, 2, 2, 3>},
+        {64, 64, 6, launch_res<T, 64, 64, 2, 2, 8, 3>},   {64, 128, 6, launch_res<T, 64, 128, 2, 2, 8, 3>},
+        {128, 128, 6, launch_res<T, 128, 128, 2, 2, 8, 3>}, {128, 16, 6, launch_res<T, 128, 16, 4, 1, 8, 3>},
+        {64, 64, 7, launch_res<T, 64, 64, 2, 2, 8, 8>},   {64, 128, 7, launch_res<T, 64, 128, 2, 2, 4, 4>},
+        {128, 16, 7, launch_res<T, 128, 16, 4, 1, 8, 8>},
         {128, 256, 3, launch_direct<T, 128, 256, true>}, {128, 128, 3, launch_direct<T, 128, 128, true>},
         {64, 256, 3, launch_direct<T, 64, 256, true>},   {64, 128, 3, launch_direct<T, 64, 128, true>},
         {128, 64, 3, launch_direct<T, 128, 64, true>},   {64, 64, 3, launch_direct<T, 64, 64, true>},

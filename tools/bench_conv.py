@@ -87,7 +87,11 @@ if __name__ == '__main__':
     ap.add_argument('--cfgs', nargs='*', default=['default'])
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default=None)
+    ap.add_argument('--n', type=int, default=128)
+    ap.add_argument('--us', action='store_true', help='print microseconds instead of TFLOP/s')
     a = ap.parse_args()
+    N = a.n
+    globals()['N'] = a.n
     L = wgrad_layers() if a.wgrad else layers()
     names = [n for n in L if a.only is None or n in a.only.split(',')]
     print('cfg'.ljust(14) + ''.join(n.rjust(9) for n in names) + '   (TFLOP/s)')
@@ -101,7 +105,7 @@ if __name__ == '__main__':
             fn, flops = L[n]
             try:
                 t = timeit(fn)
-                row += f'{flops / t / 1e12:9.0f}'
+                row += f'{t * 1e6:9.1f}' if a.us else f'{flops / t / 1e12:9.0f}'
             except Exception as ex:
                 row += '      err'
         print(row, flush=True)
