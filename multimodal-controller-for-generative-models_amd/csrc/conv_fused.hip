@@ -1051,7 +1051,7 @@ struct TilePick { int BM, BN, pipe; };
 // MCGEN_CONV_CFG="BM,BN,PIPE" overrides the choice for bf16 launches with Cout_w > 16 (tuning runs).
 static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     const long M = (long)p->N * p->H * p->W;
-    if (p->Cout_w <= 16) return {128, 16, 0};
+    if (p->Cout_w <= 16) return {128, 16, dtype == MCGEN_BF16 ? 5 : 0};
     if (dtype == MCGEN_F32) return (M <= 16384 || p->Cout_w <= 64) ? TilePick{64, 64, 0} : TilePick{128, 128, 0};
     int env_bm = 0, env_bn = 0, env_pipe = 0;
     if (const char* e = getenv("MCGEN_CONV_CFG")) {
@@ -1227,6 +1227,7 @@ static const CfgEntry* bf16_table(int* n) {
         {256, 256, 5, launch_dma<T, 256, 256, 2, 4, 3>}, {128, 256, 5, launch_dma<T, 128, 256, 2, 4, 3>},
         {256, 128, 5, launch_dma<T, 256, 128, 4, 2, 3>}, {128, 128, 5, launch_dma<T, 128, 128, 2, 2, 3>},
         {64, 128, 5, launch_dma<T, 64, 128, 2, 2, 3>},   {64, 64, 5, launch_dma<T, 64, 64, 2, 2, 3>},
+        {128, 16, 5, launch_dma<T, 128, 16, 4, 1, 3>},
         {64, 64, 6, launch_res<T, 64, 64, 2, 2, 8, 3>},   {64, 128, 6, launch_res<T, 64, 128, 2, 2, 8, 3>},
         {128, 128, 6, launch_res<T, 128, 128, 2, 2, 8, 3>}, {128, 16, 6, launch_res<T, 128, 16, 4, 1, 8, 3>},
         {64, 64, 7, launch_res<T, 64, 64, 2, 2, 8, 8>},   {64, 128, 7, launch_res<T, 64, 128, 2, 2, 4, 4>},

@@ -251,58 +251,72 @@ __device__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
-// one workgroup per layer
-__global__ void sn_power_iter_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
-                                     int do_iter, float* sigma) {
-    __shared__ float red[32];
-    extern __shared__ float sh[];                  // [rows + cols]
+// Power iteration split over the chip: RS row slices per layer.
+//   k1  partial[l][s][j] = sum_{i in slice s} W[i][j] u[i]                      (grid: layers x RS)
+//   k2  v = normalize(sum_s partial)                                             (grid: layers)
+//   k3  t[i] = W[i][:] . v                                                       (grid: layers x RS, wave per row)
+//   k4  u = t / max(|t|, eps), sigma = u . t     (no iteration: sigma = u_old . t) (grid: layers)
+constexpr int SN_RS = 8;
+__global__ void sn_k1_wtu(const float* __restrict__ wb, const float* __restrict__ uvb,
+                          const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws, int ws_stride) {
     const mcgen_sn_layer_t L = layers[blockIdx.x];
-    const float* W = wb + L.w_off;
-    float* u = uvb + L.u_off; float* v = uvb + L.v_off;
-    float* su = sh; float* sv = sh + L.rows;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < L.rows; i += nt) su[i] = u[i];
-    for (int j = tid; j < L.cols; j += nt) sv[j] = v[j];
-    __syncthreads();
-    if (do_iter) {
-        // v = normalize(W^T u)
-        float nrm = 0.f;
-        for (int j = tid; j < L.cols; j += nt) {
-            float s = 0.f;
-            for (int i = 0; i < L.rows; ++i) s = fmaf(W[(size_t)i * L.cols + j], su[i], s);
-            sv[j] = s; nrm += s * s;
-        }
-        nrm = sqrtf(block_sum(nrm, red));
-        const float inv = 1.f / fmaxf(nrm, 1e-12f);
-        for (int j = tid; j < L.cols; j += nt) sv[j] *= inv;
-        __syncthreads();
-    }
-    // t = W v  (rows); one wave per row stripe
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-    float dot_u_wv = 0.f, nrm2 = 0.f;
-    for (int i = wave; i < L.rows; i += nw) {
+    const float* W = wb + L.w_off; const float* u = uvb + L.u_off;
+    const int per = (L.rows + SN_RS - 1) / SN_RS;
+    const int r0 = blockIdx.y * per, r1 = min(L.rows, r0 + per);
+    float* part = ws + (size_t)blockIdx.x * ws_stride + (size_t)blockIdx.y * L.cols;
+    for (int j = threadIdx.x; j < L.cols; j += blockDim.x) {
         float s = 0.f;
-        for (int j = lane; j < L.cols; j += 64) s = fmaf(W[(size_t)i * L.cols + j], sv[j], s);
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        s = __shfl(s, 0);
-        if (lane == 0) {
-            if (do_iter) { nrm2 += s * s; su[i] = s; }      // su now holds W v (unnormalised)
-            else dot_u_wv += su[i] * s;
-        }
-    }
-    if (do_iter) {
-        nrm2 = block_sum(nrm2, red);                          // also orders the su writes
-        const float n = sqrtf(nrm2);
-        const float inv = 1.f / fmaxf(n, 1e-12f);
-        // u = Wv / max(|Wv|, eps);  sigma = u . (W v) = |Wv|^2 * inv
-        for (int i = tid; i < L.rows; i += nt) u[i] = su[i] * inv;
-        for (int j = tid; j < L.cols; j += nt) v[j] = sv[j];
-        if (tid == 0) sigma[blockIdx.x] = nrm2 * inv;
-    } else {
-        dot_u_wv = block_sum(dot_u_wv, red);
-        if (tid == 0) sigma[blockIdx.x] = dot_u_wv;
+        for (int i = r0; i < r1; ++i) s = fmaf(W[(size_t)i * L.cols + j], u[i], s);
+        part[j] = s;
     }
 }
+__global__ void sn_k2_v(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws, int ws_stride) {
+    __shared__ float red[32];
+    extern __shared__ float sv[];
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* part = ws + (size_t)blockIdx.x * ws_stride;
+    float nrm = 0.f;
+    for (int j = threadIdx.x; j < L.cols; j += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < SN_RS; ++k) s += part[(size_t)k * L.cols + j];
+        sv[j] = s; nrm += s * s;
+    }
+    nrm = sqrtf(block_sum(nrm, red));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    float* v = uvb + L.v_off;
+    for (int j = threadIdx.x; j < L.cols; j += blockDim.x) v[j] = sv[j] * inv;
+}
+__global__ void sn_k3_wv(const float* __restrict__ wb, const float* __restrict__ uvb,
+                         const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws, int ws_stride, int t_off) {
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* W = wb + L.w_off; const float* v = uvb + L.v_off;
+    float* t = ws + (size_t)blockIdx.x * ws_stride + t_off;
+    const int per = (L.rows + SN_RS - 1) / SN_RS;
+    const int r0 = blockIdx.y * per, r1 = min(L.rows, r0 + per);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int i = r0 + wave; i < r1; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < L.cols; j += 64) s = fmaf(W[(size_t)i * L.cols + j], v[j], s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) t[i] = s;
+    }
+}
+__global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws,
+                        int ws_stride, int t_off, int do_iter, float* sigma) {
+    __shared__ float red[32];
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* t = ws + (size_t)blockIdx.x * ws_stride + t_off;
+    float* u = uvb + L.u_off;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += blockDim.x) a += do_iter ? t[i] * t[i] : u[i] * t[i];
+    a = block_sum(a, red);
+    if (do_iter) {
+        const float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
+        for (int i = threadIdx.x; i < L.rows; i += blockDim.x) u[i] = t[i] * inv;
+        if (threadIdx.x == 0) sigma[blockIdx.x] = a * inv;
+    } else if (threadIdx.x == 0) sigma[blockIdx.x] = a;
+}
+
 constexpr int SNF_CHUNKS = 32;
 // pass 1: partial <G, W> per (layer, chunk)
 __global__ void sn_grad_dot_kernel(const float* __restrict__ gsrc, const float* __restrict__ wb,
@@ -378,19 +392,31 @@ __global__ void dtail_bwd_dx_kernel(const float* __restrict__ dlogit, const T* _
         dx[i] = Elem<T>::from_f(Elem<T>::to_f(x[i]) > 0.f ? g : 0.f);
     }
 }
-// dw[c] (wrt the NORMALISED weight; mcgen_sn_grad_fix maps it to weight_orig) and db
-__global__ void dtail_bwd_w_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled,
-                                   float* dw, float* db, int N, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// dw[c] (wrt the NORMALISED weight; mcgen_sn_grad_fix maps it to weight_orig) and db.
+// block = 64 channels x 4 sample quarters (independent loads in flight), fixed-order combine.
+__global__ __launch_bounds__(256)
+void dtail_bwd_w_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled,
+                        float* dw, float* db, int N, int C, int accumulate) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int n0 = part * ((N + 3) / 4), n1 = min(N, n0 + (N + 3) / 4);
+    float s = 0.f;
     if (c < C) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s = fmaf(dlogit[n], pooled[(size_t)n * C + c], s);
-        dw[c] = accumulate ? dw[c] + s : s;
+#pragma unroll 8
+        for (int n = n0; n < n1; ++n) s = fmaf(dlogit[n], pooled[(size_t)n * C + c], s);
     }
-    if (c == 0) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dlogit[n];
-        db[0] = accumulate ? db[0] + s : s;
+    sh[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        dw[c] = accumulate ? dw[c] + t : t;
+    }
+    if (blockIdx.x == 0 && part == 1) {                     // db = sum dlogit, one wave
+        float t = 0.f;
+        for (int n = lane; n < N; n += 64) t += dlogit[n];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        if (lane == 0) db[0] = accumulate ? db[0] + t : t;
     }
 }
 
@@ -557,10 +583,17 @@ extern "C" int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int p
 }
 
 extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
-                                   int do_iter, float* sigma, void* stream) {
-    MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && nlayers > 0, "sn_power_iter: bad arguments");
-    // rows + cols <= 128 + 9*1024 floats at most for the supported models: 48 KiB of LDS is ample
-    hipLaunchKernelGGL(sn_power_iter_kernel, dim3(nlayers), dim3(512), 48 * 1024, STREAM(stream), w_base, uv_base, layers_dev, do_iter, sigma);
+                                   int do_iter, float* sigma, float* workspace, int max_rows, int max_cols, void* stream) {
+    MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0 && max_rows > 0 && max_cols > 0,
+                "sn_power_iter: bad arguments (workspace: nlayers * (8 * max_cols + max_rows) floats)");
+    MCGEN_CHECK(max_cols * 4 <= 60 * 1024, "sn_power_iter: layers wider than 15360 columns are not supported");
+    const int t_off = SN_RS * max_cols, ws_stride = t_off + max_rows;
+    if (do_iter) {
+        hipLaunchKernelGGL(sn_k1_wtu, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride);
+        hipLaunchKernelGGL(sn_k2_v, dim3(nlayers), dim3(256), max_cols * 4, STREAM(stream), uv_base, layers_dev, workspace, ws_stride);
+    }
+    hipLaunchKernelGGL(sn_k3_wv, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride, t_off);
+    hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, do_iter, sigma);
     MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
 }
 extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
@@ -589,7 +622,7 @@ extern "C" int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, co
         hipLaunchKernelGGL(dtail_bwd_dx_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), dlogit, (const float*)x, code, w, sigma, (float*)dx, N, HW, C),
         hipLaunchKernelGGL(dtail_bwd_dx_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), dlogit, (const bf16_t*)x, code, w, sigma, (bf16_t*)dx, N, HW, C));
     if (dw && db)
-        hipLaunchKernelGGL(dtail_bwd_w_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), dlogit, pooled, dw, db, N, C, accumulate);
+        hipLaunchKernelGGL(dtail_bwd_w_kernel, dim3((C + 63) / 64), dim3(256), 0, STREAM(stream), dlogit, pooled, dw, db, N, C, accumulate);
     MCGEN_LAUNCH_CHECK("dtail_bwd"); return 0;
 }
 

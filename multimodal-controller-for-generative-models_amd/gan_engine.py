@@ -399,7 +399,8 @@ class DiscriminatorEngine:
         n = x_nchw.shape[0]
         nsn = len(self.sn)
         sigma = torch.empty(nsn, dtype=torch.float32, device=fp.device)
-        ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sigma)
+        ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sigma,
+                          max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
         if train:
             for s in self.sn:
                 _bump(s.m.weight_u); _bump(s.m.weight_v)

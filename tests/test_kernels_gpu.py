@@ -337,7 +337,7 @@ def test_spectral_norm_kernels():
     # one training forward on CPU advances u, v and defines weight = W / sigma
     xs = [torch.randn(2, 3, 8, 8), torch.randn(2, 16, 8, 8), torch.randn(2, 16), torch.randn(2, 16, 4, 4)]
     outs = [m(x) for m, x in zip(sn, xs)]
-    ops.sn_power_iter(W, UV, ld, len(sn), True, sigma)
+    ops.sn_power_iter(W, UV, ld, len(sn), True, sigma, 24, 144)
     for i, m in enumerate(sn):
         wo_, uo_, vo_, r, c = layers[i]
         np.testing.assert_allclose(UV[uo_:uo_ + r].cpu(), m.weight_u.detach(), rtol=1e-4, atol=1e-6)
@@ -360,7 +360,7 @@ def test_spectral_norm_kernels():
     # eval mode: no iteration, same sigma formula
     sig2 = torch.zeros_like(sigma)
     UV2 = UV.clone()
-    ops.sn_power_iter(W, UV2, ld, len(sn), False, sig2)
+    ops.sn_power_iter(W, UV2, ld, len(sn), False, sig2, 24, 144)
     assert torch.equal(UV, UV2)
     np.testing.assert_allclose(sig2.cpu(), sigma.cpu(), rtol=1e-4)
 
