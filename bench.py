@@ -24,22 +24,24 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 import torch  # noqa: E402
 
-FLOP_PER_IMAGE = 44.25e9        # dense 2*MAC per image per iteration (5 D + 1 G)
+FLOP_PER_IMAGE = {'cifar10': 44.25e9,   # dense 2*MAC per image per iteration (5 D + 1 G)
+                  'coil100': 19.66e9}   # COIL100 as the reference runs it (32x32, G [512,256,128,64], D [64,...,512])
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
 
 
-def build_model(dtype, device):
+def build_model(dtype, device, data_name='CIFAR10'):
     import golden_util as gu
     from mcgen_amd import models
     from mcgen_amd.config import cfg, process_control
-    cfg.update(data_name='CIFAR10', model_name='mcgan', device=str(device))
+    cfg.update(data_name=data_name, model_name='mcgan', device=str(device))
     cfg['control'] = {'controller_rate': '0.5'}
     cfg.pop('classes_size', None)
     process_control()
     m = models.mcgan()
     # random-init weights of the reference architecture, identical on every rank (numpy PCG64 stream)
-    sd = gu.procedural_state(gu.mcgan_shapes(cfg['gan']['generator_hidden_size'],
-                                             cfg['gan']['discriminator_hidden_size'], 10), seed=1234, num_mode=10)
+    classes = cfg['classes_size']
+    sd = gu.procedural_state(gu.mcgan_shapes(cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'],
+                                             classes, cifar_layout=(data_name == 'CIFAR10')), seed=1234, num_mode=classes)
     m.load_state_dict(sd)
     return m.to(device).set_compute_dtype(dtype), sd
 
@@ -91,6 +93,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100'],
+                    help='cifar10 = the headline config (BASELINE configs[1]); coil100 = configs[2] as the reference runs it (32x32, 100 modes)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -113,18 +117,20 @@ def main():
     from mcgen_amd import ops
     from mcgen_amd.trainer import GraphedGANTrainer
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-    model, sd = build_model(dtype, dev)
+    data_name = {'cifar10': 'CIFAR10', 'coil100': 'COIL100'}[a.workload]
+    classes = 10 if a.workload == 'cifar10' else 100
+    model, sd = build_model(dtype, dev, data_name)
     if world > 1:
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     img = torch.rand(a.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1
-    lab = torch.randint(0, 10, (a.batch,), device=dev, generator=g)
+    lab = torch.randint(0, classes, (a.batch,), device=dev, generator=g)
     torch.manual_seed(100 + rank)
 
     log('model built')
-    tr = GraphedGANTrainer(model, 10, dist_group=group, world_size=world)
+    tr = GraphedGANTrainer(model, classes, dist_group=group, world_size=world)
     if not a.no_graph:
         tr.capture(img, lab, warmup=1)
         log('graphs captured')
@@ -159,20 +165,22 @@ def main():
         roofline = ops.profile_step(lambda: tr.eager_iteration(img, lab), PEAK_TFLOPS[a.dtype])
     log('roofline pass done')
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == 'cifar10':
         cpu = cpu_baseline(sd, a.batch)
 
     if rank == 0:
         out = {
-            'metric': 'images/sec (train step) MCGAN CIFAR-10 32x32', 'value': value, 'unit': 'images/s',
+            'metric': 'images/sec (train step) MCGAN CIFAR-10 32x32' if a.workload == 'cifar10' else 'images/sec (train step) MCGAN COIL100 32x32', 'value': value, 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': 'MCGAN CIFAR-10 32x32 control=0.5, G [256]*4, D [128]*4, 10 modes, '
-                                   f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
+            'config': {'workload': ('MCGAN CIFAR-10 32x32 control=0.5, G [256]*4, D [128]*4, 10 modes, ' if a.workload == 'cifar10'
+                                    else 'MCGAN COIL100 (32x32 as the reference resizes it) control=0.5, G [512,256,128,64], '
+                                         'D [64,128,256,512], 100 modes, ')
+                       + f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                        'graph_replay': not a.no_graph},
-            'model_flops_per_image': FLOP_PER_IMAGE,
-            'step_mfma_frac': value / world * FLOP_PER_IMAGE / (PEAK_TFLOPS[a.dtype] * 1e12),
+            'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
+            'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses,
             'roofline': roofline, 'cpu_baseline': cpu,
         }

@@ -135,6 +135,10 @@ int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int transpose);
 int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
                       int transpose, int row_perm, const float* sigma, float wscale, void* stream);
 
+/* forward-orientation image with every output row co multiplied by row_scale[co]
+ * (ZeroConv2d's exp(3*scale), mcglow.py:127-130; ActNorm.reverse folded into the inverse 1x1 conv, mcglow.py:53-55) */
+int mcgen_prep_weight_rows(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                           const float* row_scale, void* stream);
 /* the same for all layers of a network pass in ONE launch; sigma = sigma_base[sigma_idx] (idx < 0: none) */
 typedef struct {
     const float* w; void* image;
@@ -213,6 +217,34 @@ int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n
  * step is a device counter incremented by the call. */
 int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int64_t* step, void* stream);
+
+/* ---- MCGlow-specific kernels (reference: models/mcglow.py) ------------------------------------------------- */
+/* Block squeeze / unsqueeze (mcglow.py:221-223, 262-265): [N,H,W,C] <-> [N,H/2,W/2,4C], channel c*4 + 2*dh + dw.
+ * inverse = 0: x is the big tensor (pitch Cp_big), y the squeezed one (pitch Cp_small); inverse = 1: the other way. */
+int mcgen_glow_squeeze(const void* x, void* y, int dtype, int N, int H, int W, int C, int Cp_big, int Cp_small,
+                       int inverse, void* stream);
+/* per-channel (sum, sum of squares) over all pixels, written as `blocks` partial rows [blocks][2][Cp]
+ * (the layout of the conv epilogue's stats) */
+int mcgen_channel_stats(const void* x, int dtype, int64_t pixels, int Cp, float* partials, int blocks, void* stream);
+/* ActNorm.initialize (mcglow.py:32-39): loc = -mean, scale = 1 / (unbiased std + 1e-6) from such partials */
+int mcgen_actnorm_init(const float* partials, int tiles, int pitch, int C, double count, float* loc, float* scale, void* stream);
+/* ActNorm.forward as a conv prologue (mcglow.py:41-51): a = scale, b = scale * loc (zero beyond C) */
+int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b, void* stream);
+/* InvConv2dLU.calc_weight (mcglow.py:105-111): W = P (L o mask + I) (U o mask + diag(sign * exp(w_s))), and
+ * W^-1 (reverse, mcglow.py:113-116) when weight_inv != NULL; one workgroup, matrices in LDS, C <= 64 */
+int mcgen_invconv_weight(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
+                         int C, float* weight, float* weight_inv, void* stream);
+/* AffineCoupling.forward / reverse (mcglow.py:153-175) given the coupling network output h = [log_s | t]:
+ * forward: y_b = (x_b + t) * sigmoid(log_s + 2), logdet[n] (+)= sum log sigmoid(log_s + 2); reverse: x_b = y_b / s - t */
+int mcgen_glow_coupling(const void* x, const void* h, void* y, int dtype, float* logdet, int N, int HW, int C, int Cp,
+                        int reverse, int accumulate, void* stream);
+/* gaussian_log_p summed per sample / gaussian_sample (mcglow.py:16-21, 229-238, 253-262); prior = [mean | log_sd] */
+int mcgen_gaussian_logp(const void* z, int Cpz, int c0, const void* prior, int Cpp, int dtype, int N, int HW, int Cz,
+                        float* logp, int accumulate, void* stream);
+int mcgen_gaussian_sample(const void* eps, int Cpe, const void* prior, int Cpp, void* out, int Cpo, int c0, int dtype,
+                          int64_t pixels, int Cz, void* stream);
+/* dst[..., c0:c0+Cn] = src[..., s0:s0+Cn]   (split / concat of the multi-scale architecture) */
+int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, int Cpd, int c0, int dtype, int64_t pixels, int Cn, void* stream);
 
 #ifdef __cplusplus
 }

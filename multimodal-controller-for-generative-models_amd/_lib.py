@@ -61,6 +61,16 @@ SYMBOLS = {
     'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    'mcgen_prep_weight_rows': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'mcgen_glow_squeeze': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_channel_stats': (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
+    'mcgen_actnorm_init': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp]),
+    'mcgen_actnorm_affine': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'mcgen_invconv_weight': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'mcgen_glow_coupling': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_gaussian_logp': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'mcgen_gaussian_sample': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i64, _i, _vp]),
+    'mcgen_copy_channels': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i64, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

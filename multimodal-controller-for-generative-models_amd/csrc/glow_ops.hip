@@ -1,0 +1,297 @@
+// MCGlow-specific kernels (gfx950): squeeze / unsqueeze, channel statistics + ActNorm data-dependent
+// initialisation, LU-parameterised invertible 1x1 convolution weight (and its inverse), affine coupling
+// forward / reverse with per-sample log-determinants, Gaussian prior log-density / sampling.
+// The 3x3 / 1x1 convolutions of the coupling networks run on the fused convolution (conv_fused.hip) with the
+// ActNorm affine + ReLU + MultimodalController code as its prologue.
+// Reference: models/mcglow.py (line numbers cited per kernel in include/mcgen_hip.h).
+#include "mcgen_common.h"
+
+namespace {
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+inline int grid_for(size_t n, int block = 256, int cap = 4096) {
+    size_t b = (n + block - 1) / block; if (b < 1) b = 1; if (b > (size_t)cap) b = cap; return (int)b;
+}
+
+__device__ float block_sum_g(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ---- squeeze: [N, H, W, C] -> [N, H/2, W/2, 4C], channel c*4 + 2*dh + dw  (mcglow.py:221-223) -------------
+template <typename T>
+__global__ void squeeze_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Cpi, int Cpo, int inverse) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * Cpo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cpo); size_t t = i / Cpo;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho); const int n = (int)(t / Ho);
+        const int c = co >> 2, dh = (co >> 1) & 1, dw = co & 1;
+        const size_t big = (((size_t)n * H + 2 * ho + dh) * W + 2 * wo + dw) * Cpi + c;     // index in the unsqueezed tensor
+        if (!inverse) y[i] = (co < 4 * C) ? x[big] : Elem<T>::from_f(0.f);
+        else if (co < 4 * C) y[big] = x[i];                                                  // x squeezed -> y unsqueezed
+    }
+}
+template <typename T>
+__global__ void zero_pad_channels_kernel(T* __restrict__ y, size_t pixels, int C, int Cp) {
+    const size_t total = pixels * (Cp - C);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        y[(i / (Cp - C)) * Cp + C + i % (Cp - C)] = Elem<T>::from_f(0.f);
+}
+
+// ---- per-channel sum / sum of squares, partials in the conv-epilogue format [blocks][2][Cp] ------------------
+template <typename T>
+__global__ void channel_stats_kernel(const T* __restrict__ x, size_t pixels, int Cp, float* __restrict__ part, size_t ppb) {
+    const size_t p0 = blockIdx.x * ppb, p1 = (p0 + ppb < pixels) ? p0 + ppb : pixels;
+    for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (size_t p = p0; p < p1; ++p) { const float v = Elem<T>::to_f(x[p * Cp + c]); s1 += v; s2 += v * v; }
+        part[((size_t)blockIdx.x * 2 + 0) * Cp + c] = s1;
+        part[((size_t)blockIdx.x * 2 + 1) * Cp + c] = s2;
+    }
+}
+// ActNorm.initialize (mcglow.py:32-39): loc = -mean, scale = 1 / (unbiased std + 1e-6)
+__global__ void actnorm_init_kernel(const float* __restrict__ part, int tiles, int pitch, int C, double count,
+                                    float* loc, float* scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) { s1 += (double)part[((size_t)t * 2) * pitch + c]; s2 += (double)part[((size_t)t * 2 + 1) * pitch + c]; }
+    const double mean = s1 / count;
+    double var = (s2 - s1 * mean) / (count > 1.0 ? count - 1.0 : 1.0); if (var < 0.0) var = 0.0;
+    loc[c] = (float)(-mean);
+    scale[c] = (float)(1.0 / (sqrt(var) + 1e-6));
+}
+// prologue vectors of the op that consumes an ActNorm: y = s * (x + loc) = x * s + s * loc
+__global__ void actnorm_affine_kernel(const float* loc, const float* scale, int C, int Cp, float* a, float* b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    a[c] = c < C ? scale[c] : 0.f;
+    b[c] = c < C ? scale[c] * loc[c] : 0.f;
+}
+
+// ---- InvConv2dLU.calc_weight (mcglow.py:105-111) and its inverse, one workgroup, C <= 64 -----------------------
+// W = P (L o l_mask + I) (U o u_mask + diag(s_sign * exp(w_s)))
+__global__ void invconv_weight_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                      const float* __restrict__ ws, const float* __restrict__ ssign, int C,
+                                      float* __restrict__ W, float* __restrict__ Winv) {
+    extern __shared__ float sh[];
+    float* Lm = sh; float* Um = sh + C * C; float* A = sh + 2 * C * C; float* B = sh + 3 * C * C;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i % C;
+        Lm[i] = (r > c ? wl[i] : 0.f) + (r == c ? 1.f : 0.f);
+        Um[i] = (c > r ? wu[i] : 0.f) + (r == c ? ssign[r] * expf(ws[r]) : 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {          // A = L U
+        const int r = i / C, c = i % C;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s = fmaf(Lm[r * C + k], Um[k * C + c], s);
+        A[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {          // W = P A
+        const int r = i / C, c = i % C;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s = fmaf(wp[r * C + k], A[k * C + c], s);
+        B[i] = s; W[i] = s;
+    }
+    if (!Winv) return;
+    __syncthreads();
+    // Gauss-Jordan with partial pivoting on [B | I] -> [I | B^-1]; A is reused as the right-hand side
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) A[i] = (i / C == i % C) ? 1.f : 0.f;
+    __shared__ int piv;
+    for (int col = 0; col < C; ++col) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int best = col; float bv = fabsf(B[col * C + col]);
+            for (int r = col + 1; r < C; ++r) { const float v = fabsf(B[r * C + col]); if (v > bv) { bv = v; best = r; } }
+            piv = best;
+        }
+        __syncthreads();
+        if (piv != col)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                float t = B[col * C + c]; B[col * C + c] = B[piv * C + c]; B[piv * C + c] = t;
+                t = A[col * C + c]; A[col * C + c] = A[piv * C + c]; A[piv * C + c] = t;
+            }
+        __syncthreads();
+        const float d = 1.f / B[col * C + col];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { B[col * C + c] *= d; A[col * C + c] *= d; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+            const int r = i / C, c = i % C;
+            if (r != col) {
+                const float f = B[r * C + col];
+                if (c != col) B[i] -= f * B[col * C + c];
+                A[i] -= f * A[col * C + c];
+            }
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < C; r += blockDim.x) if (r != col) B[r * C + col] = 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) Winv[i] = A[i];
+}
+
+// ---- affine coupling (mcglow.py:153-175), one workgroup per sample --------------------------------------------
+// forward : y[:, :C/2] = x[:, :C/2];  s = sigmoid(h[:, :C/2] + 2);  y[:, C/2:] = (x[:, C/2:] + h[:, C/2:]) * s;
+//           logdet[n] (+)= sum log s
+// reverse : x[:, C/2:] = y[:, C/2:] / s - h[:, C/2:]
+template <typename T>
+__global__ void coupling_kernel(const T* __restrict__ x, const T* __restrict__ h, T* __restrict__ y, float* logdet,
+                                int HW, int C, int Cp, int reverse, int accumulate) {
+    __shared__ float red[32];
+    const int n = blockIdx.x, half = C / 2;
+    const size_t base = (size_t)n * HW * Cp;
+    float ld = 0.f;
+    for (int i = threadIdx.x; i < HW * half; i += blockDim.x) {
+        const int p = i / half, j = i % half;
+        const size_t o = base + (size_t)p * Cp;
+        const float log_s = Elem<T>::to_f(h[o + j]) + 2.f;
+        const float s = 1.f / (1.f + expf(-log_s));
+        const float t = Elem<T>::to_f(h[o + half + j]);
+        const float xb = Elem<T>::to_f(x[o + half + j]);
+        y[o + j] = x[o + j];
+        y[o + half + j] = Elem<T>::from_f(reverse ? xb / s - t : (xb + t) * s);
+        ld += logf(s);
+    }
+    for (int i = threadIdx.x; i < HW * (Cp - C); i += blockDim.x)       // keep the padded channels zero
+        y[base + (size_t)(i / (Cp - C)) * Cp + C + i % (Cp - C)] = Elem<T>::from_f(0.f);
+    if (logdet && !reverse) {
+        ld = block_sum_g(ld, red);
+        if (threadIdx.x == 0) logdet[n] = accumulate ? logdet[n] + ld : ld;
+    }
+}
+
+// ---- Gaussian prior (mcglow.py:16-21,229-238,253-262) -----------------------------------------------------------
+// logp[n] (+)= sum over channels [c0, c0+Cz) of z of log N(z; mean, exp(log_sd)), with (mean, log_sd) = the two
+// channel halves of `prior` (2*Cz channels).  sample: z = mean + exp(log_sd) * eps.
+template <typename T>
+__global__ void gaussian_logp_kernel(const T* __restrict__ z, int Cpz, int c0, const T* __restrict__ prior, int Cpp,
+                                     int HW, int Cz, float* logp, int accumulate) {
+    __shared__ float red[32];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW * Cz; i += blockDim.x) {
+        const int p = i / Cz, j = i % Cz;
+        const float zv = Elem<T>::to_f(z[((size_t)n * HW + p) * Cpz + c0 + j]);
+        const float mean = Elem<T>::to_f(prior[((size_t)n * HW + p) * Cpp + j]);
+        const float lsd = Elem<T>::to_f(prior[((size_t)n * HW + p) * Cpp + Cz + j]);
+        const float d = zv - mean;
+        acc += -0.9189385332046727f - lsd - 0.5f * d * d * expf(-2.f * lsd);
+    }
+    acc = block_sum_g(acc, red);
+    if (threadIdx.x == 0) logp[n] = accumulate ? logp[n] + acc : acc;
+}
+template <typename T>
+__global__ void gaussian_sample_kernel(const T* __restrict__ eps, int Cpe, const T* __restrict__ prior, int Cpp,
+                                       T* __restrict__ out, int Cpo, int c0, size_t pixels, int Cz) {
+    const size_t total = pixels * Cz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cz; const int j = (int)(i % Cz);
+        const float mean = Elem<T>::to_f(prior[p * Cpp + j]), lsd = Elem<T>::to_f(prior[p * Cpp + Cz + j]);
+        out[p * Cpo + c0 + j] = Elem<T>::from_f(mean + expf(lsd) * Elem<T>::to_f(eps[p * Cpe + j]));
+    }
+}
+// copy channels [0, Cn) of src into channels [c0, c0+Cn) of dst (split / concat of the multi-scale architecture)
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int Cps, int s0, T* __restrict__ dst, int Cpd, int c0,
+                                     size_t pixels, int Cn) {
+    const size_t total = pixels * Cn;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cn; const int j = (int)(i % Cn);
+        dst[p * Cpd + c0 + j] = src[p * Cps + s0 + j];
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    if (dtype == MCGEN_F32) { CALL_F32; } else if (dtype == MCGEN_BF16) { CALL_BF16; } \
+    else return mcgen_fail("unknown dtype %d", dtype)
+
+extern "C" int mcgen_glow_squeeze(const void* x, void* y, int dtype, int N, int H, int W, int C, int Cp_big, int Cp_small,
+                                  int inverse, void* stream) {
+    MCGEN_CHECK(x && y && H % 2 == 0 && W % 2 == 0 && Cp_big >= C && Cp_small >= 4 * C, "glow_squeeze: bad arguments");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * Cp_small;
+    if (inverse && Cp_big > C) {
+        const size_t px = (size_t)N * H * W;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(zero_pad_channels_kernel<float>, dim3(grid_for(px * (Cp_big - C))), dim3(256), 0, STREAM(stream), (float*)y, px, C, Cp_big),
+            hipLaunchKernelGGL(zero_pad_channels_kernel<bf16_t>, dim3(grid_for(px * (Cp_big - C))), dim3(256), 0, STREAM(stream), (bf16_t*)y, px, C, Cp_big));
+    }
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(squeeze_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, (float*)y, N, H, W, C, Cp_big, Cp_small, inverse),
+        hipLaunchKernelGGL(squeeze_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Cp_big, Cp_small, inverse));
+    MCGEN_LAUNCH_CHECK("glow_squeeze"); return 0;
+}
+
+extern "C" int mcgen_channel_stats(const void* x, int dtype, int64_t pixels, int Cp, float* partials, int blocks, void* stream) {
+    MCGEN_CHECK(x && partials && pixels > 0 && Cp > 0 && blocks > 0, "channel_stats: bad arguments");
+    const size_t ppb = ((size_t)pixels + blocks - 1) / blocks;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(channel_stats_kernel<float>, dim3(blocks), dim3(64), 0, STREAM(stream), (const float*)x, (size_t)pixels, Cp, partials, ppb),
+        hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3(blocks), dim3(64), 0, STREAM(stream), (const bf16_t*)x, (size_t)pixels, Cp, partials, ppb));
+    MCGEN_LAUNCH_CHECK("channel_stats"); return 0;
+}
+
+extern "C" int mcgen_actnorm_init(const float* partials, int tiles, int pitch, int C, double count, float* loc, float* scale, void* stream) {
+    MCGEN_CHECK(partials && loc && scale && tiles > 0 && pitch >= C && count > 0, "actnorm_init: bad arguments");
+    hipLaunchKernelGGL(actnorm_init_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, count, loc, scale);
+    MCGEN_LAUNCH_CHECK("actnorm_init"); return 0;
+}
+extern "C" int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b, void* stream) {
+    MCGEN_CHECK(loc && scale && a && b && Cp >= C, "actnorm_affine: bad arguments");
+    hipLaunchKernelGGL(actnorm_affine_kernel, dim3((Cp + 63) / 64), dim3(64), 0, STREAM(stream), loc, scale, C, Cp, a, b);
+    MCGEN_LAUNCH_CHECK("actnorm_affine"); return 0;
+}
+
+extern "C" int mcgen_invconv_weight(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
+                                    int C, float* weight, float* weight_inv, void* stream) {
+    MCGEN_CHECK(w_p && w_l && w_u && w_s && s_sign && weight && C > 0 && C <= 64, "invconv_weight: C must be in 1..64");
+    hipLaunchKernelGGL(invconv_weight_kernel, dim3(1), dim3(256), 4 * C * C * sizeof(float), STREAM(stream),
+                       w_p, w_l, w_u, w_s, s_sign, C, weight, weight_inv);
+    MCGEN_LAUNCH_CHECK("invconv_weight"); return 0;
+}
+
+extern "C" int mcgen_glow_coupling(const void* x, const void* h, void* y, int dtype, float* logdet, int N, int HW, int C, int Cp,
+                                   int reverse, int accumulate, void* stream) {
+    MCGEN_CHECK(x && h && y && C % 2 == 0 && Cp >= C, "glow_coupling: bad arguments");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(coupling_kernel<float>, dim3(N), dim3(256), 0, STREAM(stream), (const float*)x, (const float*)h, (float*)y, logdet, HW, C, Cp, reverse, accumulate),
+        hipLaunchKernelGGL(coupling_kernel<bf16_t>, dim3(N), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (const bf16_t*)h, (bf16_t*)y, logdet, HW, C, Cp, reverse, accumulate));
+    MCGEN_LAUNCH_CHECK("glow_coupling"); return 0;
+}
+
+extern "C" int mcgen_gaussian_logp(const void* z, int Cpz, int c0, const void* prior, int Cpp, int dtype, int N, int HW, int Cz,
+                                   float* logp, int accumulate, void* stream) {
+    MCGEN_CHECK(z && prior && logp && Cpp >= 2 * Cz && Cpz >= c0 + Cz, "gaussian_logp: bad arguments");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gaussian_logp_kernel<float>, dim3(N), dim3(256), 0, STREAM(stream), (const float*)z, Cpz, c0, (const float*)prior, Cpp, HW, Cz, logp, accumulate),
+        hipLaunchKernelGGL(gaussian_logp_kernel<bf16_t>, dim3(N), dim3(256), 0, STREAM(stream), (const bf16_t*)z, Cpz, c0, (const bf16_t*)prior, Cpp, HW, Cz, logp, accumulate));
+    MCGEN_LAUNCH_CHECK("gaussian_logp"); return 0;
+}
+extern "C" int mcgen_gaussian_sample(const void* eps, int Cpe, const void* prior, int Cpp, void* out, int Cpo, int c0, int dtype,
+                                     int64_t pixels, int Cz, void* stream) {
+    MCGEN_CHECK(eps && prior && out && Cpp >= 2 * Cz && Cpo >= c0 + Cz && Cpe >= Cz, "gaussian_sample: bad arguments");
+    const size_t total = (size_t)pixels * Cz;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gaussian_sample_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)eps, Cpe, (const float*)prior, Cpp, (float*)out, Cpo, c0, (size_t)pixels, Cz),
+        hipLaunchKernelGGL(gaussian_sample_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)eps, Cpe, (const bf16_t*)prior, Cpp, (bf16_t*)out, Cpo, c0, (size_t)pixels, Cz));
+    MCGEN_LAUNCH_CHECK("gaussian_sample"); return 0;
+}
+extern "C" int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, int Cpd, int c0, int dtype, int64_t pixels, int Cn, void* stream) {
+    MCGEN_CHECK(src && dst && Cps >= s0 + Cn && Cpd >= c0 + Cn, "copy_channels: bad arguments");
+    const size_t total = (size_t)pixels * Cn;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)src, Cps, s0, (float*)dst, Cpd, c0, (size_t)pixels, Cn),
+        hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)src, Cps, s0, (bf16_t*)dst, Cpd, c0, (size_t)pixels, Cn));
+    MCGEN_LAUNCH_CHECK("copy_channels"); return 0;
+}

@@ -44,7 +44,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 // ---- weight image ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ img, int Cout, int Cin, int KS,
-                                   int transpose, int row_perm, const float* __restrict__ sigma, float wscale) {
+                                   int transpose, int row_perm, const float* __restrict__ sigma, float wscale,
+                                   const float* __restrict__ row_scale) {
     const int ntap = KS * KS;
     const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
     const int rows_w = (rows + 15) / 16 * 16;
@@ -64,6 +65,7 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             const int kh = tap / KS, kw = tap % KS;
             const int mtap = transpose ? ((KS - 1 - kh) * KS + (KS - 1 - kw)) : tap;
             v = w[((size_t)co * Cin + ci) * ntap + mtap] * sc;
+            if (row_scale) v *= row_scale[co];
         }
         img[i] = Elem<T>::from_f(v);
     }
@@ -499,14 +501,24 @@ extern "C" int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int tr
     const int nchunk = (round_up(kdim, 8) + MCGEN_CK - 1) / MCGEN_CK;
     return (int64_t)nchunk * ksize * ksize * rows_w * MCGEN_CK;
 }
+extern "C" int mcgen_prep_weight_rows(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                                      const float* row_scale, void* stream) {
+    MCGEN_CHECK(w && image && row_scale && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "prep_weight_rows: bad arguments");
+    const size_t total = (size_t)mcgen_weight_image_elems(Cout, Cin, ksize, 0);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, 0, 1, nullptr, 1.f, row_scale),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, 0, 1, nullptr, 1.f, row_scale));
+    MCGEN_LAUNCH_CHECK("prep_weight_rows"); return 0;
+}
+
 extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
                                  int transpose, int row_perm, const float* sigma, float wscale, void* stream) {
     MCGEN_CHECK(w && image && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "prep_weight: bad arguments");
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "prep_weight: row_perm must divide Cout");
     const size_t total = (size_t)mcgen_weight_image_elems(Cout, Cin, ksize, transpose);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale),
-        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale));
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale, nullptr),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, transpose, row_perm, sigma, wscale, nullptr));
     MCGEN_LAUNCH_CHECK("prep_weight"); return 0;
 }
 

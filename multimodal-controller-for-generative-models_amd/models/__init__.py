@@ -1,2 +1,3 @@
 from .mcgan import mcgan, MCGAN  # noqa: F401
 from . import utils  # noqa: F401
+from .mcglow import mcglow, MCGlow  # noqa: F401

@@ -487,3 +487,92 @@ class CodeBatch:
             out.append(buf[off:off + n * d.C].view(n, d.C))
             off += n * d.C
         return out
+
+
+# ---- MCGlow kernels ---------------------------------------------------------------------------------------------
+def glow_squeeze(x: Tensor, c: int) -> Tensor:
+    """[N,H,W,Cp] (c logical channels) -> [N,H/2,W/2,pad8(4c)]  (mcglow.py:221-223)."""
+    n, h, w, cp = x.shape
+    y = torch.empty((n, h // 2, w // 2, pad8(4 * c)), dtype=x.dtype, device=x.device)
+    check(_lib.load().mcgen_glow_squeeze(_p(x), _p(y), _dt(x.dtype), n, h, w, c, cp, y.shape[-1], 0, _stream()), 'glow_squeeze')
+    return y
+
+
+def glow_unsqueeze(x: Tensor, c4: int) -> Tensor:
+    """[N,H,W,Cp] with c4 = 4c logical channels -> [N,2H,2W,pad8(c)]  (mcglow.py:262-265)."""
+    n, h, w, cp = x.shape
+    c = c4 // 4
+    y = torch.empty((n, 2 * h, 2 * w, pad8(c)), dtype=x.dtype, device=x.device)
+    check(_lib.load().mcgen_glow_squeeze(_p(x), _p(y), _dt(x.dtype), n, 2 * h, 2 * w, c, y.shape[-1], cp, 1, _stream()), 'glow_unsqueeze')
+    return y
+
+
+def channel_stats(x: Tensor, blocks: int = 64) -> Tensor:
+    cp = x.shape[-1]
+    pixels = x.numel() // cp
+    blocks = max(1, min(blocks, pixels))
+    part = torch.empty((blocks, 2, cp), dtype=torch.float32, device=x.device)
+    check(_lib.load().mcgen_channel_stats(_p(x), _dt(x.dtype), pixels, cp, _f32(part), blocks, _stream()), 'channel_stats')
+    return part
+
+
+def actnorm_init(partials: Tensor, count: int, loc: Tensor, scale: Tensor):
+    """ActNorm.initialize (mcglow.py:32-39) into the parameter tensors loc / scale ([1,C,1,1])."""
+    tiles, _, pitch = partials.shape
+    check(_lib.load().mcgen_actnorm_init(_f32(partials), tiles, pitch, loc.numel(), float(count), _f32(loc), _f32(scale),
+                                         _stream()), 'actnorm_init')
+
+
+def actnorm_affine(loc: Tensor, scale: Tensor, cp: int):
+    c = loc.numel()
+    ab = torch.empty((2, cp), dtype=torch.float32, device=loc.device)
+    check(_lib.load().mcgen_actnorm_affine(_f32(loc), _f32(scale), c, cp, ab[0].data_ptr(), ab[1].data_ptr(), _stream()),
+          'actnorm_affine')
+    return ab[0], ab[1]
+
+
+def invconv_weight(w_p, w_l, w_u, w_s, s_sign, inverse: bool = False):
+    c = w_s.numel()
+    w = torch.empty((c, c), dtype=torch.float32, device=w_s.device)
+    winv = torch.empty_like(w) if inverse else None
+    check(_lib.load().mcgen_invconv_weight(_f32(w_p), _f32(w_l), _f32(w_u), _f32(w_s), _f32(s_sign), c, _f32(w), _f32(winv),
+                                           _stream()), 'invconv_weight')
+    return w, winv
+
+
+def prep_weight_rows(w: Tensor, dtype: torch.dtype, row_scale: Tensor) -> Tensor:
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2] if w.dim() == 4 else 1
+    out = torch.empty(weight_image_elems(cout, cin, ks, False), dtype=dtype, device=w.device)
+    check(_lib.load().mcgen_prep_weight_rows(_f32(w.contiguous()), _p(out), _dt(dtype), cout, cin, ks, _f32(row_scale), _stream()),
+          'prep_weight_rows')
+    return out
+
+
+def glow_coupling(x: Tensor, h: Tensor, c: int, logdet: Optional[Tensor], reverse: bool = False, accumulate: bool = True) -> Tensor:
+    n, cp = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * cp)
+    assert h.shape == x.shape and h.dtype == x.dtype
+    y = torch.empty_like(x)
+    check(_lib.load().mcgen_glow_coupling(_p(x), _p(h), _p(y), _dt(x.dtype), _f32(logdet), n, hw, c, cp, int(reverse),
+                                          int(accumulate), _stream()), 'glow_coupling')
+    return y
+
+
+def gaussian_logp(z: Tensor, c0: int, prior: Tensor, cz: int, logp: Tensor, accumulate: bool = True):
+    n = z.shape[0]
+    hw = z.numel() // (n * z.shape[-1])
+    check(_lib.load().mcgen_gaussian_logp(_p(z), z.shape[-1], c0, _p(prior), prior.shape[-1], _dt(z.dtype), n, hw, cz,
+                                          _f32(logp), int(accumulate), _stream()), 'gaussian_logp')
+
+
+def gaussian_sample(eps: Tensor, prior: Tensor, out: Tensor, c0: int, cz: int):
+    pixels = eps.numel() // eps.shape[-1]
+    check(_lib.load().mcgen_gaussian_sample(_p(eps), eps.shape[-1], _p(prior), prior.shape[-1], _p(out), out.shape[-1], c0,
+                                            _dt(eps.dtype), pixels, cz, _stream()), 'gaussian_sample')
+
+
+def copy_channels(src: Tensor, s0: int, dst: Tensor, c0: int, cn: int):
+    pixels = src.numel() // src.shape[-1]
+    check(_lib.load().mcgen_copy_channels(_p(src), src.shape[-1], s0, _p(dst), dst.shape[-1], c0, _dt(src.dtype), pixels, cn,
+                                          _stream()), 'copy_channels')
