@@ -246,6 +246,26 @@ int mcgen_gaussian_sample(const void* eps, int Cpe, const void* prior, int Cpp, 
 /* dst[..., c0:c0+Cn] = src[..., s0:s0+Cn]   (split / concat of the multi-scale architecture) */
 int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, int Cpd, int c0, int dtype, int64_t pixels, int Cn, void* stream);
 
+/* ---- MCGlow backward (autograd of the same lines) ------------------------------------------------------------ */
+/* coupling backward: dv = [dy_a | dy_b * s], dh = [dy_b (v_b + t) s (1 - s) + g (1 - s) | dy_b * s], g = dL/dlogdet_n */
+int mcgen_glow_coupling_bwd(const void* v, const void* h, const void* dy, void* dv, void* dh, int dtype, float g,
+                            int64_t pixels, int C, int Cp, void* stream);
+/* prior backward: dz[..., d0:d0+Cz] (+)= -g (z - mean) e^{-2 lsd}; dprior = [+g (z - mean) e^{-2 lsd} | g (-1 + (z - mean)^2 e^{-2 lsd})] */
+int mcgen_gaussian_logp_bwd(const void* z, int Cpz, int c0, const void* prior, int Cpp, void* dz, int Cpd, int d0,
+                            void* dprior, int dtype, float g, int64_t pixels, int Cz, int accumulate_dz, void* stream);
+/* out[c] (+)= alpha * sum_p a[p, c] * b[p, c]   (ZeroConv2d scale gradient: 3 * sum out * dout) */
+int mcgen_prod_colsum(const void* a, int pitch_a, const void* b, int pitch_b, int dtype, int64_t pixels, int C,
+                      float* out, float alpha, int accumulate, float* workspace /* 64*C floats */, void* stream);
+/* ActNorm loc/scale gradients from dgrad-epilogue partials (sum d, sum d * (x + loc)); ld_coef = dL/dlogdet * N*H*W */
+int mcgen_actnorm_bwd(const float* partials, int tiles, int pitch, int C, const float* scale, float ld_coef,
+                      int input_side, float* dloc, float* dscale, int accumulate, void* stream);
+/* InvConv2dLU: (dw_l, dw_u, dw_s) from the gradient of the C x C weight (row pitch ldw) */
+int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
+                      const float* dW, int C, int ldw, float ld_coef, float* dw_l, float* dw_u, float* dw_s,
+                      int accumulate, void* stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) over one flat gradient buffer (train_vae.py:110) */
+int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* norm_out, float* workspace /* 256 floats */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,12 @@ SYMBOLS = {
     'mcgen_gaussian_logp': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'mcgen_gaussian_sample': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i64, _i, _vp]),
     'mcgen_copy_channels': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i64, _i, _vp]),
+    'mcgen_glow_coupling_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
+    'mcgen_gaussian_logp_bwd': (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _f, _i64, _i, _i, _vp]),
+    'mcgen_prod_colsum': (_i, [_vp, _i, _vp, _i, _i, _i64, _i, _vp, _f, _i, _vp, _vp]),
+    'mcgen_actnorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _vp]),
+    'mcgen_invconv_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    'mcgen_clip_grad_norm': (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

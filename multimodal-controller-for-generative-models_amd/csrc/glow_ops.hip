@@ -211,6 +211,149 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int Cps, int s0,
     }
 }
 
+
+// ---- backward pieces -------------------------------------------------------------------------------------------
+// Affine coupling backward.  Forward: y_a = v_a, y_b = (v_b + t) * s, s = sigmoid(log_s + 2), logdet_n += sum log s.
+// Given dy and g = dL/dlogdet_n (one scalar, the same for every sample):
+//   dv_a = dy_a (the coupling network's input gradient is added by its own dgrad launch), dv_b = dy_b * s,
+//   dt = dy_b * s,  dlog_s = dy_b * (v_b + t) * s * (1 - s) + g * (1 - s)
+template <typename T>
+__global__ void coupling_bwd_kernel(const T* __restrict__ v, const T* __restrict__ h, const T* __restrict__ dy,
+                                    T* __restrict__ dv, T* __restrict__ dh, float g, size_t pixels, int C, int Cp) {
+    const int half = C / 2;
+    const size_t total = pixels * Cp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        if (c >= C) { dv[i] = Elem<T>::from_f(0.f); dh[i] = Elem<T>::from_f(0.f); continue; }
+        if (c < half) {
+            const float log_s = Elem<T>::to_f(h[i]) + 2.f;
+            const float s = 1.f / (1.f + expf(-log_s));
+            const float t = Elem<T>::to_f(h[i + half]), vb = Elem<T>::to_f(v[i + half]), dyb = Elem<T>::to_f(dy[i + half]);
+            dv[i] = dy[i];
+            dh[i] = Elem<T>::from_f(dyb * (vb + t) * s * (1.f - s) + g * (1.f - s));
+        } else {
+            const float log_s = Elem<T>::to_f(h[i - half]) + 2.f;
+            const float s = 1.f / (1.f + expf(-log_s));
+            const float dyb = Elem<T>::to_f(dy[i]);
+            dv[i] = Elem<T>::from_f(dyb * s);
+            dh[i] = Elem<T>::from_f(dyb * s);
+        }
+    }
+}
+// Gaussian prior backward: logp_n = sum log N(z; mean, exp(lsd)); g = dL/dlogp_n.
+//   dz (+)= -g * (z - mean) * exp(-2 lsd);  dmean = +g * (z - mean) * exp(-2 lsd);  dlsd = g * (-1 + (z - mean)^2 exp(-2 lsd))
+template <typename T>
+__global__ void gaussian_logp_bwd_kernel(const T* __restrict__ z, int Cpz, int c0, const T* __restrict__ prior, int Cpp,
+                                         T* __restrict__ dz, int Cpd, int d0, T* __restrict__ dprior, float g,
+                                         size_t pixels, int Cz, int accumulate_dz) {
+    const size_t total = pixels * Cz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cz; const int j = (int)(i % Cz);
+        const float zv = Elem<T>::to_f(z[p * Cpz + c0 + j]);
+        const float mean = Elem<T>::to_f(prior[p * Cpp + j]), lsd = Elem<T>::to_f(prior[p * Cpp + Cz + j]);
+        const float e = expf(-2.f * lsd), d = zv - mean;
+        const float gz = -g * d * e;
+        T* o = dz + p * Cpd + d0 + j;
+        *o = Elem<T>::from_f(accumulate_dz ? Elem<T>::to_f(*o) + gz : gz);
+        dprior[p * Cpp + j] = Elem<T>::from_f(-gz);
+        dprior[p * Cpp + Cz + j] = Elem<T>::from_f(g * (-1.f + d * d * e));
+    }
+}
+// out[c] (+)= alpha * sum_p a[p, c] * b[p, c]   (two stages, fixed order)
+template <typename T>
+__global__ void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
+                                   float* __restrict__ ws, size_t ppb) {
+    const size_t p0 = blockIdx.x * ppb, p1 = (p0 + ppb < pixels) ? p0 + ppb : pixels;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (size_t p = p0; p < p1; ++p) s = fmaf(Elem<T>::to_f(a[p * pa + c]), Elem<T>::to_f(b[p * pb + c]), s);
+        ws[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void prod_colsum_stage2(const float* __restrict__ ws, int blocks, int C, float* out, float alpha, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += (double)ws[(size_t)b * C + c];
+    const float v = alpha * (float)s;
+    out[c] = accumulate ? out[c] + v : v;
+}
+// ActNorm parameter gradients from the (sum dx, sum dx * (x + loc)) partials of a dgrad epilogue, where
+// dx is the gradient w.r.t. the ActNorm INPUT (dx = scale * du):
+//   dloc = sum dx,   dscale = (1/scale) * sum dx * (x + loc) + ld_coef / scale      (ld_coef = g * N * H * W or 0)
+__global__ void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
+                                   float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) { s1 += (double)part[((size_t)t * 2) * pitch + c]; s2 += (double)part[((size_t)t * 2 + 1) * pitch + c]; }
+    const float sc = scale[c];
+    // input_side = 1: partials were taken on dx = scale * du;  0: on du itself
+    const float gl = input_side ? (float)s1 : (float)s1 * sc;
+    const float gs = (input_side ? (float)s2 / sc : (float)s2) + ld_coef / sc;
+    dloc[c] = accumulate ? dloc[c] + gl : gl;
+    dscale[c] = accumulate ? dscale[c] + gs : gs;
+}
+// InvConv2dLU parameter gradients from dW (gradient w.r.t. the C x C weight):  W = P L U,
+//   dL = P^T dW U^T (strictly lower part -> dw_l),  dU = (P L)^T dW (strictly upper -> dw_u,
+//   diagonal * sign * exp(w_s) + ld_coef -> dw_s)
+__global__ void invconv_bwd_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                   const float* __restrict__ ws, const float* __restrict__ ssign, const float* __restrict__ dW,
+                                   int C, int ldw, float ld_coef, float* dwl, float* dwu, float* dws, int accumulate) {
+    extern __shared__ float sh[];
+    float* Lm = sh; float* Um = sh + C * C; float* A = sh + 2 * C * C; float* B = sh + 3 * C * C;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i % C;
+        Lm[i] = (r > c ? wl[i] : 0.f) + (r == c ? 1.f : 0.f);
+        Um[i] = (c > r ? wu[i] : 0.f) + (r == c ? ssign[r] * expf(ws[r]) : 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {          // A = P^T dW
+        const int r = i / C, c = i % C;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s = fmaf(wp[k * C + r], dW[k * ldw + c], s);
+        A[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {          // dL = A U^T ; B = L^T A = dU
+        const int r = i / C, c = i % C;
+        float s = 0.f, u = 0.f;
+        for (int k = 0; k < C; ++k) { s = fmaf(A[r * C + k], Um[c * C + k], s); u = fmaf(Lm[k * C + r], A[k * C + c], u); }
+        if (r > c) dwl[i] = accumulate ? dwl[i] + s : s; else if (!accumulate) dwl[i] = 0.f;
+        if (c > r) dwu[i] = accumulate ? dwu[i] + u : u; else if (!accumulate) dwu[i] = 0.f;
+        B[i] = u;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < C; r += blockDim.x) {
+        const float v = B[r * C + r] * ssign[r] * expf(ws[r]) + ld_coef;
+        dws[r] = accumulate ? dws[r] + v : v;
+    }
+}
+// global L2 norm of a flat gradient buffer (clip_grad_norm_, train_vae.py:110) and the scaled copy
+__global__ void sqsum_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
+    s = block_sum_g(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void clip_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ part, int blocks, float max_norm,
+                                  float* norm_out) {
+    __shared__ float coef;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < blocks; ++b) s += (double)part[b];
+        const float nrm = (float)sqrt(s);
+        if (norm_out && blockIdx.x == 0) norm_out[0] = nrm;
+        const float c = max_norm / (nrm + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    __syncthreads();
+    const float c = coef;
+    if (c >= 1.f) return;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= c;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
@@ -294,4 +437,55 @@ extern "C" int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, 
         hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)src, Cps, s0, (float*)dst, Cpd, c0, (size_t)pixels, Cn),
         hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)src, Cps, s0, (bf16_t*)dst, Cpd, c0, (size_t)pixels, Cn));
     MCGEN_LAUNCH_CHECK("copy_channels"); return 0;
+}
+
+extern "C" int mcgen_glow_coupling_bwd(const void* v, const void* h, const void* dy, void* dv, void* dh, int dtype, float g,
+                                       int64_t pixels, int C, int Cp, void* stream) {
+    MCGEN_CHECK(v && h && dy && dv && dh && C % 2 == 0 && Cp >= C, "glow_coupling_bwd: bad arguments");
+    const size_t total = (size_t)pixels * Cp;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(coupling_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)v, (const float*)h, (const float*)dy, (float*)dv, (float*)dh, g, (size_t)pixels, C, Cp),
+        hipLaunchKernelGGL(coupling_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)v, (const bf16_t*)h, (const bf16_t*)dy, (bf16_t*)dv, (bf16_t*)dh, g, (size_t)pixels, C, Cp));
+    MCGEN_LAUNCH_CHECK("glow_coupling_bwd"); return 0;
+}
+extern "C" int mcgen_gaussian_logp_bwd(const void* z, int Cpz, int c0, const void* prior, int Cpp, void* dz, int Cpd, int d0,
+                                       void* dprior, int dtype, float g, int64_t pixels, int Cz, int accumulate_dz, void* stream) {
+    MCGEN_CHECK(z && prior && dz && dprior && Cpp >= 2 * Cz && Cpz >= c0 + Cz && Cpd >= d0 + Cz, "gaussian_logp_bwd: bad arguments");
+    const size_t total = (size_t)pixels * Cz;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gaussian_logp_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)z, Cpz, c0, (const float*)prior, Cpp, (float*)dz, Cpd, d0, (float*)dprior, g, (size_t)pixels, Cz, accumulate_dz),
+        hipLaunchKernelGGL(gaussian_logp_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)z, Cpz, c0, (const bf16_t*)prior, Cpp, (bf16_t*)dz, Cpd, d0, (bf16_t*)dprior, g, (size_t)pixels, Cz, accumulate_dz));
+    MCGEN_LAUNCH_CHECK("gaussian_logp_bwd"); return 0;
+}
+extern "C" int mcgen_prod_colsum(const void* a, int pitch_a, const void* b, int pitch_b, int dtype, int64_t pixels, int C,
+                                 float* out, float alpha, int accumulate, float* workspace, void* stream) {
+    MCGEN_CHECK(a && b && out && workspace && pixels > 0 && C > 0, "prod_colsum: bad arguments (workspace: 64*C floats)");
+    const int blocks = pixels < 64 ? (int)pixels : 64;
+    const size_t ppb = ((size_t)pixels + blocks - 1) / blocks;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prod_colsum_stage1<float>, dim3(blocks), dim3(64), 0, STREAM(stream), (const float*)a, pitch_a, (const float*)b, pitch_b, (size_t)pixels, C, workspace, ppb),
+        hipLaunchKernelGGL(prod_colsum_stage1<bf16_t>, dim3(blocks), dim3(64), 0, STREAM(stream), (const bf16_t*)a, pitch_a, (const bf16_t*)b, pitch_b, (size_t)pixels, C, workspace, ppb));
+    hipLaunchKernelGGL(prod_colsum_stage2, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), workspace, blocks, C, out, alpha, accumulate);
+    MCGEN_LAUNCH_CHECK("prod_colsum"); return 0;
+}
+extern "C" int mcgen_actnorm_bwd(const float* partials, int tiles, int pitch, int C, const float* scale, float ld_coef,
+                                 int input_side, float* dloc, float* dscale, int accumulate, void* stream) {
+    MCGEN_CHECK(partials && scale && dloc && dscale && tiles > 0 && pitch >= C, "actnorm_bwd: bad arguments");
+    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, scale, ld_coef, input_side, dloc, dscale, accumulate);
+    MCGEN_LAUNCH_CHECK("actnorm_bwd"); return 0;
+}
+extern "C" int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
+                                 const float* dW, int C, int ldw, float ld_coef, float* dw_l, float* dw_u, float* dw_s,
+                                 int accumulate, void* stream) {
+    MCGEN_CHECK(w_p && w_l && w_u && w_s && s_sign && dW && dw_l && dw_u && dw_s && C > 0 && C <= 64 && ldw >= C, "invconv_bwd: bad arguments");
+    hipLaunchKernelGGL(invconv_bwd_kernel, dim3(1), dim3(256), 4 * C * C * sizeof(float), STREAM(stream),
+                       w_p, w_l, w_u, w_s, s_sign, dW, C, ldw, ld_coef, dw_l, dw_u, dw_s, accumulate);
+    MCGEN_LAUNCH_CHECK("invconv_bwd"); return 0;
+}
+extern "C" int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* norm_out, float* workspace, void* stream) {
+    MCGEN_CHECK(g && workspace && n > 0 && max_norm > 0, "clip_grad_norm: bad arguments (workspace: 256 floats)");
+    const int blocks = 256;
+    hipLaunchKernelGGL(sqsum_kernel, dim3(blocks), dim3(256), 0, STREAM(stream), g, (size_t)n, workspace);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, STREAM(stream), g, (size_t)n, workspace, blocks, max_norm, norm_out);
+    MCGEN_LAUNCH_CHECK("clip_grad_norm"); return 0;
 }

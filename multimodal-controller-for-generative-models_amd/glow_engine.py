@@ -26,6 +26,7 @@ class GlowEngine:
     def __init__(self, model, dtype: torch.dtype = torch.float32):
         self.m = model
         self.dtype = dtype
+        self._gsink = None          # id(param) -> gradient tensor while an autograd backward is collecting
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _actnorm(self, an, x_stats_fn, count, train: bool, cp: int):
@@ -43,7 +44,7 @@ class GlowEngine:
             w = F.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
         return ops.prep_weight_rows(w, self.dtype, rs), zc.conv.bias.detach() * rs
 
-    def _coupling_net(self, cp_net, x: Tensor, c: int, codes, train: bool):
+    def _coupling_net(self, cp_net, x: Tensor, c: int, codes, train: bool, saved=None):
         """AffineCoupling.net on the first c/2 channels of x -> [log_s | t] (c channels)."""
         net = cp_net
         dt = self.dtype
@@ -64,9 +65,11 @@ class GlowEngine:
         a5, b5 = self._actnorm(an5, lambda: st2, count, train, hid)
         wz, bz = self._zero_conv_image(zc, hid)
         hz, _ = ops.conv_fused([Seg(h2, scale=a5, shift=b5, relu=True, code=codes[1])], wz, c, bias=bz, cy=cp)
+        if saved is not None:
+            saved.update(h1=h1, h2=h2, a1=a1, b1=b1, a5=a5, b5=b5)
         return hz
 
-    def _flow_forward(self, flow, x: Tensor, c: int, indicator: Tensor, logdet: Tensor, train: bool) -> Tensor:
+    def _flow_forward(self, flow, x: Tensor, c: int, indicator: Tensor, logdet: Tensor, train: bool, tape=None) -> Tensor:
         dt = self.dtype
         n, h, w, cp = x.shape
         a, b = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
@@ -78,7 +81,11 @@ class GlowEngine:
         logdet += (h * w) * (torch.log(torch.abs(flow.actnorm.scale.detach())).sum() + ic.w_s.detach().sum())
         net = flow.coupling.net
         codes = (net[3].code(indicator), net[7].code(indicator))
-        hz = self._coupling_net(net, out, c, codes, train)
+        rec = None if tape is None else dict(x=x, a=a, b=b, out=out, codes=codes)
+        hz = self._coupling_net(net, out, c, codes, train, rec)
+        if tape is not None:
+            rec['hz'] = hz
+            tape.append(rec)
         return ops.glow_coupling(out, hz, c, logdet, reverse=False, accumulate=True)
 
     def _flow_reverse(self, flow, y: Tensor, c: int, indicator: Tensor) -> Tensor:
@@ -98,7 +105,7 @@ class GlowEngine:
         return out
 
     # ---- forward: bits per dimension -----------------------------------------------------------------------------
-    def forward(self, img: Tensor, indicator: Tensor, noise: Tensor, train: bool):
+    def forward(self, img: Tensor, indicator: Tensor, noise: Tensor, train: bool, tape=None):
         m, dt = self.m, self.dtype
         n = img.shape[0]
         x0 = img * 0.5 + noise / 256                                   # mcglow.py:298-299
@@ -110,8 +117,9 @@ class GlowEngine:
         for blk in m.blocks:
             x = ops.glow_squeeze(x, c)
             c *= 4
+            brec = None if tape is None else dict(flows=[], c=c)
             for flow in blk.flows:
-                x = self._flow_forward(flow, x, c, indicator, logdet, train)
+                x = self._flow_forward(flow, x, c, indicator, logdet, train, None if tape is None else brec['flows'])
             nb, h, w, cp = x.shape
             if blk.split:
                 half = c // 2
@@ -123,16 +131,131 @@ class GlowEngine:
                 znew = torch.zeros((nb, h, w, pad8(half)), dtype=dt, device=x.device)
                 ops.copy_channels(x, half, znew, 0, half)
                 zs.append(ops.to_nchw(znew, half))
+                if tape is not None:
+                    brec.update(x=x, keep=keep, prior=prior)
                 x, c = keep, half
             else:
                 wz, bz = self._zero_conv_image(blk.prior, cp)
                 prior, _ = ops.conv_fused([Seg(torch.zeros_like(x))], wz, 2 * c, bias=bz)
                 ops.gaussian_logp(x, 0, prior, c, logp)
                 zs.append(ops.to_nchw(x, c))
+                if tape is not None:
+                    brec.update(x=x, prior=prior)
+            if tape is not None:
+                tape.append(brec)
         n_pixel = float(img[0].numel())
         loss = -(-math.log(256.) * n_pixel + logdet + logp) / (math.log(2.) * n_pixel)       # loss_fn, mcglow.py:283-293
         loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss) if train else loss[~torch.isnan(loss)]
         return loss.mean(), zs
+
+    # ---- backward: gradients of the mean bits/dim w.r.t. every parameter -------------------------------------------
+    # Autograd of the same reference lines, written out.  g0 = d loss / d (logdet_n | logp_n) = -1 / (N log2 n_pixel)
+    # (train-mode loss: NaN samples are replaced by 0 in the reference; a batch that produces NaNs is not handled here).
+    def _grad(self, p: Tensor) -> Tensor:
+        if self._gsink is not None:
+            g = self._gsink.get(id(p))
+            if g is None:
+                g = self._gsink[id(p)] = torch.zeros_like(p)
+            return g
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def _zero_conv_bwd(self, zc, seg_in, out: Tensor, dout: Tensor, cout: int, cin: int, need_dx: bool, res=None, **dgrad_kw):
+        """ZeroConv2d backward: out = (conv(A) + b) * exp(3 scale).  Returns (dA, stats) when need_dx."""
+        dt = self.dtype
+        rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
+        ops.prod_colsum(out, dout, cout, self._grad(zc.scale).view(-1), alpha=3.0)
+        gb = torch.empty(cout, dtype=torch.float32, device=dout.device)
+        if seg_in is not None:
+            cin_p = seg_in.x.shape[-1]
+            gw = torch.empty((cout, cin_p, 3, 3), dtype=torch.float32, device=dout.device)
+            ops.wgrad(seg_in, dout, cout, cin_p, gw, bias_grad=gb)
+            self._grad(zc.conv.weight).copy_(gw[:, :cin] * rs[:, None, None, None])
+        else:
+            self._grad(zc.conv.weight).zero_()
+            ops.colsum(dout, cout, gb)
+        self._grad(zc.conv.bias).copy_(gb * rs)
+        if not need_dx:
+            return None, None
+        wt = (zc.conv.weight.detach() * rs[:, None, None, None]).flip(2, 3).transpose(0, 1)       # [cin, cout, 3, 3]
+        wt = F.pad(wt, (0, 0, 0, 0, 0, dout.shape[-1] - cout)).contiguous()
+        return ops.conv_fused([Seg(dout)], ops.prep_weight(wt, dt), cin, res=res, **dgrad_kw)
+
+    def _flow_backward(self, flow, r, dy: Tensor, c: int, g0: float) -> Tensor:
+        dt = self.dtype
+        out, hz, x, codes = r['out'], r['hz'], r['x'], r['codes']
+        n, h, w, cp = out.shape
+        ld_coef = g0 * n * h * w
+        net = flow.coupling.net
+        conv0, an1, conv1, an5, zc = net[0].module, net[1].module, net[4].module, net[5].module, net[8].module
+        hid = conv0.out_channels
+        dev = out.device
+        ones = torch.ones(hid, dtype=torch.float32, device=dev)
+        dv, dhz = ops.glow_coupling_bwd(out, hz, dy, c, g0)
+        # ZeroConv2d <- MC <- ReLU <- ActNorm(5)
+        v5, st5 = self._zero_conv_bwd(zc, Seg(r['h2'], scale=r['a5'], shift=r['b5'], relu=True, code=codes[1]), hz, dhz, c, hid,
+                                      True, ocode=codes[1], gate_x=r['h2'], gscale=r['a5'], gshift=r['b5'],
+                                      gmean=-an5.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
+        ops.actnorm_bwd(st5, an5.scale.detach(), 0.0, False, self._grad(an5.loc), self._grad(an5.scale))
+        s5 = an5.scale.detach().reshape(-1)
+        # 1x1 conv <- MC <- ReLU <- ActNorm(1)
+        gw = torch.empty((hid, hid), dtype=torch.float32, device=dev)
+        gb = torch.empty(hid, dtype=torch.float32, device=dev)
+        ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid, gw, bias_grad=gb)
+        self._grad(conv1.weight).copy_((gw * s5[:, None]).view_as(conv1.weight))
+        self._grad(conv1.bias).copy_(gb * s5)
+        w1t = (conv1.weight.detach().reshape(hid, hid) * s5[:, None]).t().contiguous().reshape(hid, hid, 1, 1)
+        v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], ops.prep_weight(w1t, dt), hid, ocode=codes[0], gate_x=r['h1'],
+                                 gscale=r['a1'], gshift=r['b1'], gmean=-an1.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
+        ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
+        s1 = an1.scale.detach().reshape(-1)
+        # 3x3 conv on the first c/2 channels of v; its input gradient joins the direct coupling gradient dv
+        gw0 = torch.empty((hid, cp, 3, 3), dtype=torch.float32, device=dev)
+        gb0 = torch.empty(hid, dtype=torch.float32, device=dev)
+        ops.wgrad(Seg(out), v1, hid, cp, gw0, bias_grad=gb0)
+        self._grad(conv0.weight).copy_(gw0[:, :c // 2] * s1[:, None, None, None])
+        self._grad(conv0.bias).copy_(gb0 * s1)
+        w0t = (conv0.weight.detach() * s1[:, None, None, None]).flip(2, 3).transpose(0, 1)          # [c/2, hid, 3, 3]
+        w0t = F.pad(w0t, (0, 0, 0, 0, 0, 0, 0, c - c // 2)).contiguous()                            # rows >= c/2: zero
+        dvt, _ = ops.conv_fused([Seg(v1)], ops.prep_weight(w0t, dt), c, res=dv, cy=cp)
+        # invertible 1x1 conv <- ActNorm
+        an, ic = flow.actnorm, flow.invconv
+        gW = torch.empty((c, cp), dtype=torch.float32, device=dev)
+        ops.wgrad(Seg(x, ksize=1, scale=r['a'], shift=r['b']), dvt, c, cp, gW)
+        ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef,
+                        self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s))
+        s = an.scale.detach().reshape(-1)
+        wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
+        wt = F.pad((wmat * s[None, :]).t(), (0, cp - c)).contiguous().reshape(c, cp, 1, 1)          # [ci, co] = W[co, ci] * s[ci]
+        dx, st = ops.conv_fused([Seg(dvt, ksize=1)], ops.prep_weight(wt, dt), c, cy=cp, gate_x=x,
+                                gscale=torch.zeros(c, dtype=torch.float32, device=dev),
+                                gshift=torch.ones(c, dtype=torch.float32, device=dev),
+                                gmean=-an.loc.detach().reshape(-1), grstd=torch.ones(c, dtype=torch.float32, device=dev),
+                                stats_mode=2)
+        ops.actnorm_bwd(st, an.scale.detach(), ld_coef, True, self._grad(an.loc), self._grad(an.scale))
+        return dx
+
+    def backward(self, tape, n: int, n_pixel: float):
+        """Fill `.grad` of every parameter with d(mean bits/dim)/d(parameter) from the tape of one forward."""
+        m = self.m
+        g0 = -1.0 / (n * math.log(2.) * n_pixel)
+        dkeep = None
+        for blk, rec in reversed(list(zip(m.blocks, tape))):
+            x, c = rec['x'], rec['c']
+            dy = torch.zeros_like(x)
+            if blk.split:
+                half = c // 2
+                dprior = ops.gaussian_logp_bwd(x, half, rec['prior'], half, dy, half, g0, False)
+                dk, _ = self._zero_conv_bwd(blk.prior, Seg(rec['keep']), rec['prior'], dprior, c, half, True, res=dkeep)
+                ops.copy_channels(dk, 0, dy, 0, half)
+            else:
+                dprior = ops.gaussian_logp_bwd(x, 0, rec['prior'], c, dy, 0, g0, False)
+                self._zero_conv_bwd(blk.prior, None, rec['prior'], dprior, 2 * c, c, False)
+            for flow, frec in reversed(list(zip(blk.flows, rec['flows']))):
+                dy = self._flow_backward(flow, frec, dy, c, g0)
+            dkeep = ops.glow_unsqueeze(dy, c)
+        return dkeep
 
     # ---- reverse: reconstruction / sampling ------------------------------------------------------------------------
     def reverse(self, zs: List[Tensor], indicator: Tensor, reconstruct: bool) -> Tensor:

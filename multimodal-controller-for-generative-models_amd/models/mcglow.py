@@ -2,9 +2,9 @@
 1x1 convolution, affine coupling with MultimodalController-masked coupling networks, multi-scale blocks.
 
 The module tree carries the reference's parameter / buffer names (``state_dict`` compatible); the arithmetic
-runs in ``glow_engine.py`` on HIP kernels.  Built this round: the likelihood forward (incl. the
-data-dependent ActNorm initialisation), ``reverse`` and ``generate``.  NOT built yet: the backward pass
-(training on the GPU path) -- ``forward`` returns a loss without an autograd graph.
+runs in ``glow_engine.py`` on HIP kernels: the likelihood forward (incl. the data-dependent ActNorm
+initialisation), its backward (``output['loss'].backward()`` works through one ``autograd.Function`` that
+replays the engine's tape), ``reverse`` and ``generate``.
 """
 from __future__ import annotations
 
@@ -18,6 +18,32 @@ from ..config import cfg
 from ..glow_engine import GlowEngine
 from ..modules import MultimodalController, Wrapper
 from .utils import init_param
+
+
+class _GlowFn(torch.autograd.Function):
+    """loss = engine.forward(...); backward = engine.backward over the saved tape (one node for the whole model)."""
+
+    @staticmethod
+    def forward(ctx, engine, img, indicator, noise, train, holder, *params):
+        tape = []
+        loss, zs = engine.forward(img, indicator, noise, train, tape)
+        holder['z'] = zs
+        ctx.engine, ctx.tape, ctx.params = engine, tape, params
+        ctx.n, ctx.n_pixel = img.shape[0], float(img[0].numel())
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng = ctx.engine
+        sink = {}
+        eng._gsink = sink
+        try:
+            eng.backward(ctx.tape, ctx.n, ctx.n_pixel)
+        finally:
+            eng._gsink = None
+        ctx.tape = None
+        grads = tuple(sink[id(p)] * gloss if id(p) in sink else None for p in ctx.params)
+        return (None, None, None, None, None, None) + grads
 
 
 class ActNorm(nn.Module):
@@ -137,6 +163,11 @@ class MCGlow(nn.Module):
         drawn here unless `input['noise']` supplies it (parity runs)."""
         indicator = F.one_hot(input['label'], cfg['classes_size']).float()
         noise = input['noise'] if 'noise' in input else torch.rand_like(input['img'])
+        if torch.is_grad_enabled() and self.training:
+            holder = {}
+            params = [p for p in self.parameters() if p.requires_grad]
+            loss = _GlowFn.apply(self._engine(), input['img'], indicator, noise, True, holder, *params)
+            return {'loss': loss, 'z': holder['z']}
         loss, z = self._engine().forward(input['img'], indicator, noise, self.training)
         return {'loss': loss, 'z': z}
 

@@ -576,3 +576,49 @@ def copy_channels(src: Tensor, s0: int, dst: Tensor, c0: int, cn: int):
     pixels = src.numel() // src.shape[-1]
     check(_lib.load().mcgen_copy_channels(_p(src), src.shape[-1], s0, _p(dst), dst.shape[-1], c0, _dt(src.dtype), pixels, cn,
                                           _stream()), 'copy_channels')
+
+
+def glow_coupling_bwd(v: Tensor, h: Tensor, dy: Tensor, c: int, g: float):
+    dv, dh = torch.empty_like(v), torch.empty_like(v)
+    pixels = v.numel() // v.shape[-1]
+    check(_lib.load().mcgen_glow_coupling_bwd(_p(v), _p(h), _p(dy), _p(dv), _p(dh), _dt(v.dtype), float(g), pixels, c,
+                                              v.shape[-1], _stream()), 'glow_coupling_bwd')
+    return dv, dh
+
+
+def gaussian_logp_bwd(z: Tensor, c0: int, prior: Tensor, cz: int, dz: Tensor, d0: int, g: float, accumulate_dz: bool):
+    dprior = torch.zeros_like(prior)
+    pixels = z.numel() // z.shape[-1]
+    check(_lib.load().mcgen_gaussian_logp_bwd(_p(z), z.shape[-1], c0, _p(prior), prior.shape[-1], _p(dz), dz.shape[-1], d0,
+                                              _p(dprior), _dt(z.dtype), float(g), pixels, cz, int(accumulate_dz), _stream()),
+          'gaussian_logp_bwd')
+    return dprior
+
+
+def prod_colsum(a: Tensor, b: Tensor, c: int, out: Tensor, alpha: float = 1.0, accumulate: bool = False):
+    pixels = a.numel() // a.shape[-1]
+    ws = torch.empty(64 * c, dtype=torch.float32, device=a.device)
+    check(_lib.load().mcgen_prod_colsum(_p(a), a.shape[-1], _p(b), b.shape[-1], _dt(a.dtype), pixels, c, _f32(out), float(alpha),
+                                        int(accumulate), _f32(ws), _stream()), 'prod_colsum')
+
+
+def actnorm_bwd(partials: Tensor, scale: Tensor, ld_coef: float, input_side: bool, dloc: Tensor, dscale: Tensor,
+                accumulate: bool = False):
+    tiles, _, pitch = partials.shape
+    check(_lib.load().mcgen_actnorm_bwd(_f32(partials), tiles, pitch, scale.numel(), _f32(scale), float(ld_coef),
+                                        int(input_side), _f32(dloc), _f32(dscale), int(accumulate), _stream()), 'actnorm_bwd')
+
+
+def invconv_bwd(w_p, w_l, w_u, w_s, s_sign, dW: Tensor, ld_coef: float, dw_l, dw_u, dw_s, accumulate: bool = False):
+    c = w_s.numel()
+    check(_lib.load().mcgen_invconv_bwd(_f32(w_p), _f32(w_l), _f32(w_u), _f32(w_s), _f32(s_sign), _f32(dW), c, dW.shape[-1],
+                                        float(ld_coef), _f32(dw_l), _f32(dw_u), _f32(dw_s), int(accumulate), _stream()),
+          'invconv_bwd')
+
+
+def clip_grad_norm_(gflat: Tensor, max_norm: float) -> Tensor:
+    """torch.nn.utils.clip_grad_norm_ over one flat gradient buffer; returns the total norm (device scalar)."""
+    ws = torch.empty(256 + 1, dtype=torch.float32, device=gflat.device)
+    check(_lib.load().mcgen_clip_grad_norm(_f32(gflat), gflat.numel(), float(max_norm), ws[256:].data_ptr(), _f32(ws),
+                                           _stream()), 'clip_grad_norm')
+    return ws[256]

@@ -104,3 +104,84 @@ def test_mcglow_forward_init_and_reverse():
     gz = [torch.from_numpy(d[f'gen_z/{i}']).cuda() for i in range(3)]
     assert _rel(m.generate(lab, gz), d['generated']) < 1e-3
     assert [tuple(s) for s in m.make_z_shapes()] == [(2, 16, 16), (4, 8, 8), (16, 4, 4)]
+
+
+def test_glow_backward_kernels():
+    """coupling / prior backward kernels against torch autograd of the same formulas."""
+    from mcgen_amd import ops
+    g = torch.Generator().manual_seed(5)
+    c, n = 12, 4
+    v = torch.randn(n, c, 4, 4, generator=g, requires_grad=True)
+    h = torch.randn(n, c, 4, 4, generator=g, requires_grad=True)
+    dy = torch.randn(n, c, 4, 4, generator=g)
+    g0 = -0.37
+    log_s, t = h.chunk(2, 1)
+    s = torch.sigmoid(log_s + 2)
+    y = torch.cat([v[:, :c // 2], (v[:, c // 2:] + t) * s], 1)
+    ((y * dy).sum() + g0 * torch.log(s).sum()).backward()
+    f32 = torch.float32
+    dv, dh = ops.glow_coupling_bwd(ops.to_nhwc(v.detach().cuda(), f32), ops.to_nhwc(h.detach().cuda(), f32),
+                                   ops.to_nhwc(dy.cuda(), f32), c, g0)
+    assert _rel(ops.to_nchw(dv, c), v.grad) < 1e-5 and _rel(ops.to_nchw(dh, c), h.grad) < 1e-5
+    from oracle import mcglow_oracle as G
+    z = torch.randn(n, 6, 4, 4, generator=g, requires_grad=True)
+    prior = (torch.randn(n, 12, 4, 4, generator=g) * 0.3).requires_grad_(True)
+    mean, lsd = prior.chunk(2, 1)
+    (g0 * G.gaussian_log_p(z, mean, lsd).sum()).backward()
+    zt = ops.to_nhwc(z.detach().cuda(), f32)
+    dz = torch.zeros_like(zt)
+    dp = ops.gaussian_logp_bwd(zt, 0, ops.to_nhwc(prior.detach().cuda(), f32), 6, dz, 0, g0, False)
+    assert _rel(ops.to_nchw(dz, 6), z.grad) < 1e-5 and _rel(ops.to_nchw(dp, 12), prior.grad) < 1e-5
+    # prod_colsum / clip_grad_norm
+    a, b = torch.randn(700, 16, generator=g).cuda(), torch.randn(700, 16, generator=g).cuda()
+    out = torch.zeros(10, device='cuda')
+    ops.prod_colsum(a, b, 10, out, alpha=3.0)
+    assert _rel(out, 3 * (a * b).sum(0)[:10].cpu()) < 1e-5
+    gf = torch.randn(100003, generator=g).cuda()
+    ref = gf.clone()
+    nrm = ops.clip_grad_norm_(gf, 1.0)
+    assert abs(float(nrm) - float(ref.norm())) < 1e-2
+    assert _rel(gf, (ref / (ref.norm() + 1e-6)).cpu()) < 1e-5
+    small = ref * 1e-4
+    keep = small.clone()
+    ops.clip_grad_norm_(small, 1.0)
+    assert torch.equal(small, keep)
+
+
+def _oracle_grads(sd, img, lab, noise):
+    from oracle import mcglow_oracle as G
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(('w_p', 'u_mask', 'l_mask', 's_sign', 'l_eye', 'codebook'))
+               else v.clone()) for k, v in sd.items()}
+    out = G.forward(sdg, img, lab, 12, 2, 3, noise, train=True)
+    out['loss'].backward()
+    return float(out['loss'].detach()), {k: v.grad for k, v in sdg.items() if v.requires_grad and v.grad is not None}
+
+
+def test_mcglow_gradients_vs_oracle():
+    """d(bits/dim)/d(every parameter) from the HIP backward against autograd through the CPU oracle."""
+    d = gu.load_npz('mcglow_small.npz')
+    img, lab = torch.from_numpy(d['img']), torch.from_numpy(d['label'])
+    noise = torch.from_numpy(d['noise/0/0'])
+    init = gu.state_from_npz(d, 'sd_init/')
+    # perturb the zero-initialised ZeroConv2d weights so every path carries gradient
+    g = torch.Generator().manual_seed(11)
+    for k in init:
+        if '.conv.weight' in k or k.endswith('prior.scale') or k.endswith('8.module.scale'):
+            init[k] = init[k] + 0.02 * torch.randn(init[k].shape, generator=g)
+    loss_ref, gref = _oracle_grads(init, img, lab, noise)
+    m = _model(init)
+    m.train(True)
+    out = m({'img': img.cuda(), 'label': lab.cuda(), 'noise': noise.cuda()})
+    assert abs(float(out['loss']) - loss_ref) < 1e-4
+    out['loss'].backward()
+    named = dict(m.named_parameters())
+    assert set(gref) == set(named), set(gref) ^ set(named)
+    worst = 0.0
+    for k, gr in gref.items():
+        gg = named[k].grad
+        assert gg is not None, k
+        err = float((gg.cpu() - gr).abs().max())
+        tol = 2e-3 * float(gr.abs().max()) + 1e-6
+        assert err < tol, (k, err, tol)
+        worst = max(worst, err / tol)
+    print('worst err/tol', worst)
