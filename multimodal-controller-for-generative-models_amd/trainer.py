@@ -185,3 +185,48 @@ class GraphedGANTrainer(GANTrainer):
             self._allreduce(self.grad_g)
             self.g_ga.replay()
         return self.loss_d, self.loss_g
+
+
+class GlowTrainer:
+    """The loop body of train_glow.py:108-121 on the HIP path: zero_grad, likelihood forward (tape), backward,
+    clip_grad_norm_(parameters, 1), Adam(lr 3e-4) -- parameters and gradients each in one flat fp32 buffer,
+    so the clip and the optimizer are one launch each and a data-parallel run all-reduces one bucket."""
+
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), weight_decay=0.0, max_norm=1.0, dist_group=None, world_size=1):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.fs = FlatState(self.params)
+        flat = self.fs.ensure()
+        self.gflat = torch.zeros_like(flat)
+        self.opt = FusedAdam(self.fs, lr=lr, betas=betas, weight_decay=weight_decay)
+        self.max_norm = max_norm
+        self.group, self.world = dist_group, world_size
+        self.grad_norm = None
+
+    def _bind_grads(self):
+        self.fs.ensure()
+        for p, gv in zip(self.params, self.fs.views(self.gflat)):
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                p.grad = gv
+
+    def train_iteration(self, img, label, noise=None):
+        import torch.nn.functional as F
+        from .config import cfg
+        m = self.model
+        m.train(True)
+        eng = m._engine()
+        self._bind_grads()
+        self.gflat.zero_()
+        indicator = F.one_hot(label, cfg['classes_size']).float()
+        if noise is None:
+            noise = torch.rand_like(img)
+        tape = []
+        with torch.no_grad():
+            loss, _ = eng.forward(img, indicator, noise, True, tape)
+            eng.backward(tape, img.shape[0], float(img[0].numel()))
+            if self.world > 1:
+                from .dist import allreduce_mean_
+                allreduce_mean_(self.gflat, self.group, self.world)
+            self.grad_norm = ops.clip_grad_norm_(self.gflat, self.max_norm)
+            self.opt.step(self.gflat)
+        return loss
