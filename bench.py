@@ -86,6 +86,72 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+def bench_mcglow(a, dev, dtype, world, rank, group):
+    """Secondary workload: MCGlow CIFAR-10 train step (train_glow.py:108-121),
+    hidden 512, K=16, L=3, 10 modes: likelihood forward + backward + clip_grad_norm_(1) + Adam(3e-4)."""
+    import numpy as np
+    from mcgen_amd import models, ops
+    from mcgen_amd.config import cfg, process_control
+    from mcgen_amd.trainer import GlowTrainer
+    cfg.update(data_name='CIFAR10', model_name='mcglow', device=str(dev))
+    cfg['control'] = {'controller_rate': '0.5'}
+    cfg.pop('classes_size', None)
+    process_control()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = models.mcglow().to(dev).set_compute_dtype(dtype)
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    img = torch.rand(a.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    lab = torch.randint(0, 10, (a.batch,), device=dev, generator=g)
+    with torch.no_grad():
+        model.train(True)
+        model({'img': img, 'label': lab})                 # data-dependent ActNorm init (train_glow.py:60-67)
+    tr = GlowTrainer(model, dist_group=group, world_size=world)
+    if not a.no_graph:
+        tr.capture(img, lab)
+    for _ in range(a.warmup):
+        tr.train_iteration(img, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.train_iteration(img, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    value = a.batch * world * a.steps / dt
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        roofline = ops.profile_step(lambda: tr.train_iteration(img, lab, torch.rand_like(img)), PEAK_TFLOPS[a.dtype])
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (train step) MCGlow CIFAR-10 32x32', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'MCGlow CIFAR-10 32x32 control=0.5, hidden 512, K=16, L=3, 10 modes, batch {a.batch}/GPU, '
+                                   'forward + backward + clip_grad_norm_(1) + Adam (train_glow.py:108-121)',
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': not a.no_graph},
+            'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -93,7 +159,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100'],
+    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100', 'mcglow'],
                     help='cifar10 = the headline config (BASELINE configs[1]); coil100 = configs[2] as the reference runs it (32x32, 100 modes)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -117,6 +183,8 @@ def main():
     from mcgen_amd import ops
     from mcgen_amd.trainer import GraphedGANTrainer
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    if a.workload == 'mcglow':
+        return bench_mcglow(a, dev, dtype, world, rank, group)
     data_name = {'cifar10': 'CIFAR10', 'coil100': 'COIL100'}[a.workload]
     classes = 10 if a.workload == 'cifar10' else 100
     model, sd = build_model(dtype, dev, data_name)

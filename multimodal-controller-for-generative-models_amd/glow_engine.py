@@ -27,11 +27,16 @@ class GlowEngine:
         self.m = model
         self.dtype = dtype
         self._gsink = None          # id(param) -> gradient tensor while an autograd backward is collecting
+        self.assume_initialized = False   # set by a graph capture: skip the host read of ActNorm.initialized
+
+    def all_initialized(self) -> bool:
+        flags = [mod.initialized for mod in self.m.modules() if hasattr(mod, 'initialized')]
+        return bool(torch.stack([f.reshape(()) for f in flags]).min().item() != 0)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _actnorm(self, an, x_stats_fn, count, train: bool, cp: int):
         """Prologue vectors (a, b) of an ActNorm; runs the data-dependent init on the first training forward."""
-        if train and int(an.initialized) == 0:
+        if train and not self.assume_initialized and int(an.initialized) == 0:
             ops.actnorm_init(x_stats_fn(), count, an.loc.data, an.scale.data)
             an.initialized.fill_(1)
         return ops.actnorm_affine(an.loc.data, an.scale.data, cp)
@@ -53,12 +58,12 @@ class GlowEngine:
         conv0, an1, mc1, conv1, an5, mc2, zc = (net[0].module, net[1].module, net[3], net[4].module, net[5].module,
                                                  net[7], net[8].module)
         w0 = F.pad(conv0.weight.detach(), (0, 0, 0, 0, 0, cp - conv0.weight.shape[1]))      # zero over channels >= c/2
-        need1 = train and int(an1.initialized) == 0
+        need1 = train and not self.assume_initialized and int(an1.initialized) == 0
         h1, st1 = ops.conv_fused([Seg(x)], ops.prep_weight(w0, dt), conv0.out_channels, bias=conv0.bias,
                                  stats_mode=1 if need1 else 0)
         hid = conv0.out_channels
         a1, b1 = self._actnorm(an1, lambda: st1, count, train, hid)
-        need5 = train and int(an5.initialized) == 0
+        need5 = train and not self.assume_initialized and int(an5.initialized) == 0
         h2, st2 = ops.conv_fused([Seg(h1, ksize=1, scale=a1, shift=b1, relu=True, code=codes[0])],
                                  ops.prep_weight(conv1.weight.detach(), dt), hid, bias=conv1.bias,
                                  stats_mode=1 if need5 else 0)

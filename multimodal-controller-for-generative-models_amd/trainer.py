@@ -209,24 +209,73 @@ class GlowTrainer:
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
 
-    def train_iteration(self, img, label, noise=None):
-        import torch.nn.functional as F
+    def _compute(self, img, indicator, noise):
+        eng = self.model._engine()
+        self.gflat.zero_()
+        tape = []
+        loss, _ = eng.forward(img, indicator, noise, True, tape)
+        eng.backward(tape, img.shape[0], float(img[0].numel()))
+        return loss
+
+    def _apply(self):
+        self.grad_norm = ops.clip_grad_norm_(self.gflat, self.max_norm)
+        self.opt.step(self.gflat)
+
+    def _allreduce(self):
+        if self.world > 1:
+            from .dist import allreduce_mean_
+            allreduce_mean_(self.gflat, self.group, self.world)
+
+    def capture(self, img, label, warmup: int = 1):
+        """Capture forward+backward and clip+Adam as two HIP graphs (the gradient all-reduce of a multi-rank
+        run sits between the replays).  Requires every ActNorm to be initialised already (the data-dependent
+        init reads a device flag on the host, which a capture cannot do)."""
         from .config import cfg
         m = self.model
         m.train(True)
         eng = m._engine()
+        if not eng.all_initialized():
+            raise RuntimeError('GlowTrainer.capture: run the ActNorm initialisation forward first (train_glow.py:60-67)')
+        eng.assume_initialized = True
         self._bind_grads()
-        self.gflat.zero_()
+        self.s_img = img.clone()
+        self.s_ind = F.one_hot(label, cfg['classes_size']).float()
+        self.s_noise = torch.rand_like(img)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):
+                self._compute(self.s_img, self.s_ind, self.s_noise)
+                self._allreduce()
+                self._apply()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_c, self.g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(self.g_c):
+                self.s_noise.uniform_()
+                self.loss = self._compute(self.s_img, self.s_ind, self.s_noise)
+            with torch.cuda.graph(self.g_a, pool=self.g_c.pool()):
+                self._apply()
+        self._graphs = True
+
+    def train_iteration(self, img, label, noise=None):
+        from .config import cfg
+        if getattr(self, '_graphs', None) and noise is None:
+            self.s_img.copy_(img, non_blocking=True)
+            self.s_ind.copy_(F.one_hot(label, cfg['classes_size']).float(), non_blocking=True)
+            self.g_c.replay()
+            self._allreduce()
+            self.g_a.replay()
+            return self.loss
+        m = self.model
+        m.train(True)
+        self._bind_grads()
         indicator = F.one_hot(label, cfg['classes_size']).float()
         if noise is None:
             noise = torch.rand_like(img)
-        tape = []
         with torch.no_grad():
-            loss, _ = eng.forward(img, indicator, noise, True, tape)
-            eng.backward(tape, img.shape[0], float(img[0].numel()))
-            if self.world > 1:
-                from .dist import allreduce_mean_
-                allreduce_mean_(self.gflat, self.group, self.world)
-            self.grad_norm = ops.clip_grad_norm_(self.gflat, self.max_norm)
-            self.opt.step(self.gflat)
+            loss = self._compute(img, indicator, noise)
+            self._allreduce()
+            self._apply()
         return loss

@@ -209,3 +209,21 @@ def test_mcglow_two_training_steps_vs_reference():
         far += int((diff > 1e-5 + 1e-3 * v.abs()).sum())
     total = sum(v.numel() for v in fin.values() if v.dtype.is_floating_point)
     assert far < 0.02 * total, (far, total)
+
+
+def test_mcglow_graphed_trainer_tracks_eager():
+    """HIP-graph replay of the train step against the eager path: same data, independent dequantisation
+    noise (the graph draws its own), so losses agree to the noise's effect (< 2e-3 bits/dim here)."""
+    from mcgen_amd.trainer import GlowTrainer
+    d = gu.load_npz('mcglow_small.npz')
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    ma, mb = _model(gu.state_from_npz(d, 'sd_init/')), _model(gu.state_from_npz(d, 'sd_init/'))
+    ta, tb = GlowTrainer(ma), GlowTrainer(mb)
+    # capture runs warm-up iterations that update the weights; give the eager trainer the same number of steps
+    tb.capture(img, lab, warmup=1)
+    ta.train_iteration(img, lab)
+    la = [float(ta.train_iteration(img, lab)) for _ in range(3)]
+    lb = [float(tb.train_iteration(img, lab)) for _ in range(3)]
+    assert all(np.isfinite(la)) and all(np.isfinite(lb))
+    assert la[-1] < la[0] and lb[-1] < lb[0]
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 5e-3, (la, lb)
