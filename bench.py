@@ -82,21 +82,42 @@ def cpu_baseline(sd, batch, budget_s=40.0):
             'sample': f'1 iteration (5 D + 1 G updates) at batch {batch}, fp32, {dt:.1f} s'}
 
 
+def try_capture(capture, world, dev):
+    """HIP-graph capture with an all-ranks agreement: if any rank fails to capture, every rank runs eagerly
+    (the step is the same either way; replay only removes host launch cost)."""
+    ok = 1
+    try:
+        capture()
+    except Exception as e:                                   # noqa: BLE001 -- report and fall back
+        print(f'[bench] graph capture failed: {type(e).__name__}: {e}', file=sys.stderr, flush=True)
+        ok = 0
+        torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t)
+    return bool(ok)
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
 def bench_mcglow(a, dev, dtype, world, rank, group):
-    """Secondary workload: MCGlow CIFAR-10 train step (train_glow.py:108-121),
-    hidden 512, K=16, L=3, 10 modes: likelihood forward + backward + clip_grad_norm_(1) + Adam(3e-4)."""
+    """Secondary workload (BASELINE configs[3]): MCGlow train step (train_glow.py:108-121)
+    on Omniglot as the reference runs it ([1,32,32], 1623 modes) or CIFAR-10 ([3,32,32], 10 modes); hidden 512,
+    K=16, L=3: likelihood forward + backward + clip_grad_norm_(1) + Adam(3e-4)."""
     import numpy as np
     from mcgen_amd import models, ops
     from mcgen_amd.config import cfg, process_control
     from mcgen_amd.trainer import GlowTrainer
-    cfg.update(data_name='CIFAR10', model_name='mcglow', device=str(dev))
+    data_name = 'Omniglot' if a.workload == 'mcglow' else 'CIFAR10'
+    cfg.update(data_name=data_name, model_name='mcglow', device=str(dev))
     cfg['control'] = {'controller_rate': '0.5'}
     cfg.pop('classes_size', None)
     process_control()
+    classes, chans = cfg['classes_size'], cfg['data_shape'][0]
     np.random.seed(0)
     torch.manual_seed(0)
     model = models.mcglow().to(dev).set_compute_dtype(dtype)
@@ -105,14 +126,17 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
-    img = torch.rand(a.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1
-    lab = torch.randint(0, 10, (a.batch,), device=dev, generator=g)
+    img = torch.rand(a.batch, chans, 32, 32, device=dev, generator=g) * 2 - 1
+    lab = torch.randint(0, classes, (a.batch,), device=dev, generator=g)
     with torch.no_grad():
         model.train(True)
         model({'img': img, 'label': lab})                 # data-dependent ActNorm init (train_glow.py:60-67)
     tr = GlowTrainer(model, dist_group=group, world_size=world)
+    graphed = False
     if not a.no_graph:
-        tr.capture(img, lab)
+        graphed = try_capture(lambda: tr.capture(img, lab), world, dev)
+        if not graphed:
+            tr._graphs = None
     for _ in range(a.warmup):
         tr.train_iteration(img, lab)
     torch.cuda.synchronize()
@@ -140,12 +164,12 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
         roofline = ops.profile_step(lambda: tr.train_iteration(img, lab, torch.rand_like(img)), PEAK_TFLOPS[a.dtype])
     if rank == 0:
         print(json.dumps({
-            'metric': 'images/sec (train step) MCGlow CIFAR-10 32x32', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+            'metric': f'images/sec (train step) MCGlow {data_name} 32x32', 'value': value, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': f'MCGlow CIFAR-10 32x32 control=0.5, hidden 512, K=16, L=3, 10 modes, batch {a.batch}/GPU, '
+            'config': {'workload': f'MCGlow {data_name} [{chans},32,32] control=0.5, hidden 512, K=16, L=3, {classes} modes, batch {a.batch}/GPU, '
                                    'forward + backward + clip_grad_norm_(1) + Adam (train_glow.py:108-121)',
-                       'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': not a.no_graph},
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': graphed},
             'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
     if world > 1:
         import torch.distributed as dist
@@ -159,7 +183,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100', 'mcglow'],
+    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100', 'mcglow', 'mcglow-cifar10'],
                     help='cifar10 = the headline config (BASELINE configs[1]); coil100 = configs[2] as the reference runs it (32x32, 100 modes)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -183,7 +207,7 @@ def main():
     from mcgen_amd import ops
     from mcgen_amd.trainer import GraphedGANTrainer
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-    if a.workload == 'mcglow':
+    if a.workload.startswith('mcglow'):
         return bench_mcglow(a, dev, dtype, world, rank, group)
     data_name = {'cifar10': 'CIFAR10', 'coil100': 'COIL100'}[a.workload]
     classes = 10 if a.workload == 'cifar10' else 100
@@ -199,9 +223,12 @@ def main():
 
     log('model built')
     tr = GraphedGANTrainer(model, classes, dist_group=group, world_size=world)
+    graphed = False
     if not a.no_graph:
-        tr.capture(img, lab, warmup=1)
-        log('graphs captured')
+        graphed = try_capture(lambda: tr.capture(img, lab, warmup=1), world, dev)
+        if not graphed:
+            tr._graphs = None
+        log('graphs captured' if graphed else 'graph capture failed on some rank: running eagerly')
 
     def barrier():
         torch.cuda.synchronize()
@@ -246,7 +273,7 @@ def main():
                                          'D [64,128,256,512], 100 modes, ')
                        + f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}',
-                       'graph_replay': not a.no_graph},
+                       'graph_replay': graphed},
             'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses,

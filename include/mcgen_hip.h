@@ -255,7 +255,7 @@ int mcgen_gaussian_logp_bwd(const void* z, int Cpz, int c0, const void* prior, i
                             void* dprior, int dtype, float g, int64_t pixels, int Cz, int accumulate_dz, void* stream);
 /* out[c] (+)= alpha * sum_p a[p, c] * b[p, c]   (ZeroConv2d scale gradient: 3 * sum out * dout) */
 int mcgen_prod_colsum(const void* a, int pitch_a, const void* b, int pitch_b, int dtype, int64_t pixels, int C,
-                      float* out, float alpha, int accumulate, float* workspace /* 64*C floats */, void* stream);
+                      float* out, float alpha, int accumulate, float* workspace /* 256*C floats */, void* stream);
 /* ActNorm loc/scale gradients from dgrad-epilogue partials (sum d, sum d * (x + loc)); ld_coef = dL/dlogdet * N*H*W */
 int mcgen_actnorm_bwd(const float* partials, int tiles, int pitch, int C, const float* scale, float ld_coef,
                       int input_side, float* dloc, float* dscale, int accumulate, void* stream);

@@ -261,32 +261,49 @@ __global__ void gaussian_logp_bwd_kernel(const T* __restrict__ z, int Cpz, int c
 }
 // out[c] (+)= alpha * sum_p a[p, c] * b[p, c]   (two stages, fixed order)
 template <typename T>
-__global__ void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
-                                   float* __restrict__ ws, size_t ppb) {
+__global__ __launch_bounds__(256)
+void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
+                        float* __restrict__ ws, size_t ppb) {
+    __shared__ float sh[4][64];
     const size_t p0 = blockIdx.x * ppb, p1 = (p0 + ppb < pixels) ? p0 + ppb : pixels;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
         float s = 0.f;
-        for (size_t p = p0; p < p1; ++p) s = fmaf(Elem<T>::to_f(a[p * pa + c]), Elem<T>::to_f(b[p * pb + c]), s);
-        ws[(size_t)blockIdx.x * C + c] = s;
+        if (c < C)
+            for (size_t p = p0 + w; p < p1; p += 4) s = fmaf(Elem<T>::to_f(a[p * pa + c]), Elem<T>::to_f(b[p * pb + c]), s);
+        sh[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && c < C) ws[(size_t)blockIdx.x * C + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        __syncthreads();
     }
 }
 __global__ void prod_colsum_stage2(const float* __restrict__ ws, int blocks, int C, float* out, float alpha, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // one wave per channel
     if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += (double)ws[(size_t)b * C + c];
-    const float v = alpha * (float)s;
-    out[c] = accumulate ? out[c] + v : v;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int b = lane; b < blocks; b += 64) s += ws[(size_t)b * C + c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) { const float v = alpha * s; out[c] = accumulate ? out[c] + v : v; }
 }
 // ActNorm parameter gradients from the (sum dx, sum dx * (x + loc)) partials of a dgrad epilogue, where
 // dx is the gradient w.r.t. the ActNorm INPUT (dx = scale * du):
 //   dloc = sum dx,   dscale = (1/scale) * sum dx * (x + loc) + ld_coef / scale      (ld_coef = g * N * H * W or 0)
-__global__ void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
-                                   float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024)
+void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
+                        float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
+    __shared__ double sh[16][2][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles; ++t) { s1 += (double)part[((size_t)t * 2) * pitch + c]; s2 += (double)part[((size_t)t * 2 + 1) * pitch + c]; }
+    if (c < C)
+        for (int t = w; t < tiles; t += 16) { s1 += (double)part[((size_t)t * 2) * pitch + c]; s2 += (double)part[((size_t)t * 2 + 1) * pitch + c]; }
+    sh[w][0][lane] = s1; sh[w][1][lane] = s2;
+    __syncthreads();
+    if (w != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int i = 0; i < 16; ++i) { s1 += sh[i][0][lane]; s2 += sh[i][1][lane]; }
     const float sc = scale[c];
     // input_side = 1: partials were taken on dx = scale * du;  0: on du itself
     const float gl = input_side ? (float)s1 : (float)s1 * sc;
@@ -302,16 +319,18 @@ __global__ void invconv_bwd_kernel(const float* __restrict__ wp, const float* __
                                    int C, int ldw, float ld_coef, float* dwl, float* dwu, float* dws, int accumulate) {
     extern __shared__ float sh[];
     float* Lm = sh; float* Um = sh + C * C; float* A = sh + 2 * C * C; float* B = sh + 3 * C * C;
+    float* Pm = sh + 4 * C * C; float* G = sh + 5 * C * C;
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
         const int r = i / C, c = i % C;
         Lm[i] = (r > c ? wl[i] : 0.f) + (r == c ? 1.f : 0.f);
         Um[i] = (c > r ? wu[i] : 0.f) + (r == c ? ssign[r] * expf(ws[r]) : 0.f);
+        Pm[i] = wp[i]; G[i] = dW[r * ldw + c];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) {          // A = P^T dW
         const int r = i / C, c = i % C;
         float s = 0.f;
-        for (int k = 0; k < C; ++k) s = fmaf(wp[k * C + r], dW[k * ldw + c], s);
+        for (int k = 0; k < C; ++k) s = fmaf(Pm[k * C + r], G[k * C + c], s);
         A[i] = s;
     }
     __syncthreads();
@@ -459,26 +478,28 @@ extern "C" int mcgen_gaussian_logp_bwd(const void* z, int Cpz, int c0, const voi
 }
 extern "C" int mcgen_prod_colsum(const void* a, int pitch_a, const void* b, int pitch_b, int dtype, int64_t pixels, int C,
                                  float* out, float alpha, int accumulate, float* workspace, void* stream) {
-    MCGEN_CHECK(a && b && out && workspace && pixels > 0 && C > 0, "prod_colsum: bad arguments (workspace: 64*C floats)");
-    const int blocks = pixels < 64 ? (int)pixels : 64;
+    MCGEN_CHECK(a && b && out && workspace && pixels > 0 && C > 0, "prod_colsum: bad arguments (workspace: 256*C floats)");
+    const int blocks = pixels < 1024 ? (int)((pixels + 3) / 4) : 256;
     const size_t ppb = ((size_t)pixels + blocks - 1) / blocks;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(prod_colsum_stage1<float>, dim3(blocks), dim3(64), 0, STREAM(stream), (const float*)a, pitch_a, (const float*)b, pitch_b, (size_t)pixels, C, workspace, ppb),
-        hipLaunchKernelGGL(prod_colsum_stage1<bf16_t>, dim3(blocks), dim3(64), 0, STREAM(stream), (const bf16_t*)a, pitch_a, (const bf16_t*)b, pitch_b, (size_t)pixels, C, workspace, ppb));
-    hipLaunchKernelGGL(prod_colsum_stage2, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), workspace, blocks, C, out, alpha, accumulate);
+        hipLaunchKernelGGL(prod_colsum_stage1<float>, dim3(blocks), dim3(256), 0, STREAM(stream), (const float*)a, pitch_a, (const float*)b, pitch_b, (size_t)pixels, C, workspace, ppb),
+        hipLaunchKernelGGL(prod_colsum_stage1<bf16_t>, dim3(blocks), dim3(256), 0, STREAM(stream), (const bf16_t*)a, pitch_a, (const bf16_t*)b, pitch_b, (size_t)pixels, C, workspace, ppb));
+    hipLaunchKernelGGL(prod_colsum_stage2, dim3((C + 3) / 4), dim3(256), 0, STREAM(stream), workspace, blocks, C, out, alpha, accumulate);
     MCGEN_LAUNCH_CHECK("prod_colsum"); return 0;
 }
 extern "C" int mcgen_actnorm_bwd(const float* partials, int tiles, int pitch, int C, const float* scale, float ld_coef,
                                  int input_side, float* dloc, float* dscale, int accumulate, void* stream) {
     MCGEN_CHECK(partials && scale && dloc && dscale && tiles > 0 && pitch >= C, "actnorm_bwd: bad arguments");
-    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, scale, ld_coef, input_side, dloc, dscale, accumulate);
+    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM(stream), partials, tiles, pitch, C, scale, ld_coef, input_side, dloc, dscale, accumulate);
     MCGEN_LAUNCH_CHECK("actnorm_bwd"); return 0;
 }
 extern "C" int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
                                  const float* dW, int C, int ldw, float ld_coef, float* dw_l, float* dw_u, float* dw_s,
                                  int accumulate, void* stream) {
     MCGEN_CHECK(w_p && w_l && w_u && w_s && s_sign && dW && dw_l && dw_u && dw_s && C > 0 && C <= 64 && ldw >= C, "invconv_bwd: bad arguments");
-    hipLaunchKernelGGL(invconv_bwd_kernel, dim3(1), dim3(256), 4 * C * C * sizeof(float), STREAM(stream),
+    if (6 * C * C * sizeof(float) > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(invconv_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * sizeof(float));
+    hipLaunchKernelGGL(invconv_bwd_kernel, dim3(1), dim3(1024), 6 * C * C * sizeof(float), STREAM(stream),
                        w_p, w_l, w_u, w_s, s_sign, dW, C, ldw, ld_coef, dw_l, dw_u, dw_s, accumulate);
     MCGEN_LAUNCH_CHECK("invconv_bwd"); return 0;
 }

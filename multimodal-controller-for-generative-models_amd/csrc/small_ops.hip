@@ -112,7 +112,9 @@ __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % d.C), n = (int)(i / d.C);
         float s = 0.f;
-        for (int m = 0; m < d.M; ++m) s = fmaf(ind[(size_t)n * d.M + m], d.codebook[(size_t)m * d.C + c], s);
+        // zero indicator entries contribute exactly nothing (finite codebook): skip their codebook reads.
+        // With one-hot labels and 1623 modes (Omniglot) this turns a [N,M]x[M,C] product into a row gather.
+        for (int m = 0; m < d.M; ++m) { const float w = ind[(size_t)n * d.M + m]; if (w != 0.f) s = fmaf(w, d.codebook[(size_t)m * d.C + c], s); }
         code[i] = s;
     }
 }
@@ -122,7 +124,7 @@ __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __res
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C), n = (int)(i / C);
         float s = 0.f;
-        for (int m = 0; m < M; ++m) s = fmaf(ind[(size_t)n * M + m], cb[(size_t)m * C + c], s);
+        for (int m = 0; m < M; ++m) { const float w = ind[(size_t)n * M + m]; if (w != 0.f) s = fmaf(w, cb[(size_t)m * C + c], s); }
         code[i] = s;
     }
 }

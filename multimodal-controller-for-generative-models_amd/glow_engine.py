@@ -28,6 +28,14 @@ class GlowEngine:
         self.dtype = dtype
         self._gsink = None          # id(param) -> gradient tensor while an autograd backward is collecting
         self.assume_initialized = False   # set by a graph capture: skip the host read of ActNorm.initialized
+        self._const = {}
+
+    def _full(self, value: float, n: int, device) -> Tensor:
+        key = (value, n, str(device))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.full((n,), value, dtype=torch.float32, device=device)
+        return t
 
     def all_initialized(self) -> bool:
         flags = [mod.initialized for mod in self.m.modules() if hasattr(mod, 'initialized')]
@@ -74,7 +82,7 @@ class GlowEngine:
             saved.update(h1=h1, h2=h2, a1=a1, b1=b1, a5=a5, b5=b5)
         return hz
 
-    def _flow_forward(self, flow, x: Tensor, c: int, indicator: Tensor, logdet: Tensor, train: bool, tape=None) -> Tensor:
+    def _flow_forward(self, flow, x: Tensor, c: int, indicator: Tensor, logdet: Tensor, train: bool, tape=None, label=None) -> Tensor:
         dt = self.dtype
         n, h, w, cp = x.shape
         a, b = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
@@ -85,19 +93,25 @@ class GlowEngine:
         # parameter-only log-determinants: H*W * (sum log|scale| + sum w_s)   (mcglow.py:46-47,101)
         logdet += (h * w) * (torch.log(torch.abs(flow.actnorm.scale.detach())).sum() + ic.w_s.detach().sum())
         net = flow.coupling.net
-        codes = (net[3].code(indicator), net[7].code(indicator))
-        rec = None if tape is None else dict(x=x, a=a, b=b, out=out, codes=codes)
+        codes = self._codes(net, indicator, label)
+        rec = None if tape is None else dict(x=x, a=a, b=b, out=out, codes=codes, wmat=wmat)
         hz = self._coupling_net(net, out, c, codes, train, rec)
         if tape is not None:
             rec['hz'] = hz
             tape.append(rec)
         return ops.glow_coupling(out, hz, c, logdet, reverse=False, accumulate=True)
 
-    def _flow_reverse(self, flow, y: Tensor, c: int, indicator: Tensor) -> Tensor:
+    @staticmethod
+    def _codes(net, indicator, label):
+        if label is not None:
+            return net[3].code_of_labels(label), net[7].code_of_labels(label)
+        return net[3].code(indicator), net[7].code(indicator)
+
+    def _flow_reverse(self, flow, y: Tensor, c: int, indicator: Tensor, label=None) -> Tensor:
         dt = self.dtype
         cp = y.shape[-1]
         net = flow.coupling.net
-        codes = (net[3].code(indicator), net[7].code(indicator))
+        codes = self._codes(net, indicator, label)
         hz = self._coupling_net(net, y, c, codes, False)
         x = ops.glow_coupling(y, hz, c, None, reverse=True)
         ic = flow.invconv
@@ -110,7 +124,7 @@ class GlowEngine:
         return out
 
     # ---- forward: bits per dimension -----------------------------------------------------------------------------
-    def forward(self, img: Tensor, indicator: Tensor, noise: Tensor, train: bool, tape=None):
+    def forward(self, img: Tensor, indicator: Tensor, noise: Tensor, train: bool, tape=None, label=None):
         m, dt = self.m, self.dtype
         n = img.shape[0]
         x0 = img * 0.5 + noise / 256                                   # mcglow.py:298-299
@@ -124,7 +138,7 @@ class GlowEngine:
             c *= 4
             brec = None if tape is None else dict(flows=[], c=c)
             for flow in blk.flows:
-                x = self._flow_forward(flow, x, c, indicator, logdet, train, None if tape is None else brec['flows'])
+                x = self._flow_forward(flow, x, c, indicator, logdet, train, None if tape is None else brec['flows'], label)
             nb, h, w, cp = x.shape
             if blk.split:
                 half = c // 2
@@ -196,7 +210,7 @@ class GlowEngine:
         conv0, an1, conv1, an5, zc = net[0].module, net[1].module, net[4].module, net[5].module, net[8].module
         hid = conv0.out_channels
         dev = out.device
-        ones = torch.ones(hid, dtype=torch.float32, device=dev)
+        ones = self._full(1.0, hid, dev)
         dv, dhz = ops.glow_coupling_bwd(out, hz, dy, c, g0)
         # ZeroConv2d <- MC <- ReLU <- ActNorm(5)
         v5, st5 = self._zero_conv_bwd(zc, Seg(r['h2'], scale=r['a5'], shift=r['b5'], relu=True, code=codes[1]), hz, dhz, c, hid,
@@ -231,12 +245,11 @@ class GlowEngine:
         ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef,
                         self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s))
         s = an.scale.detach().reshape(-1)
-        wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
+        wmat = r['wmat']
         wt = F.pad((wmat * s[None, :]).t(), (0, cp - c)).contiguous().reshape(c, cp, 1, 1)          # [ci, co] = W[co, ci] * s[ci]
         dx, st = ops.conv_fused([Seg(dvt, ksize=1)], ops.prep_weight(wt, dt), c, cy=cp, gate_x=x,
-                                gscale=torch.zeros(c, dtype=torch.float32, device=dev),
-                                gshift=torch.ones(c, dtype=torch.float32, device=dev),
-                                gmean=-an.loc.detach().reshape(-1), grstd=torch.ones(c, dtype=torch.float32, device=dev),
+                                gscale=self._full(0.0, c, dev), gshift=self._full(1.0, c, dev),
+                                gmean=-an.loc.detach().reshape(-1), grstd=self._full(1.0, c, dev),
                                 stats_mode=2)
         ops.actnorm_bwd(st, an.scale.detach(), ld_coef, True, self._grad(an.loc), self._grad(an.scale))
         return dx
@@ -263,7 +276,7 @@ class GlowEngine:
         return dkeep
 
     # ---- reverse: reconstruction / sampling ------------------------------------------------------------------------
-    def reverse(self, zs: List[Tensor], indicator: Tensor, reconstruct: bool) -> Tensor:
+    def reverse(self, zs: List[Tensor], indicator: Tensor, reconstruct: bool, label=None) -> Tensor:
         m, dt = self.m, self.dtype
         L = len(m.blocks)
         x = None
@@ -291,6 +304,6 @@ class GlowEngine:
                     prior, _ = ops.conv_fused([Seg(torch.zeros_like(inp))], wz, 2 * c, bias=bz)
                     ops.gaussian_sample(eps, prior, inp, 0, c)
             for flow in reversed(list(blk.flows)):
-                inp = self._flow_reverse(flow, inp, c, indicator)
+                inp = self._flow_reverse(flow, inp, c, indicator, label)
             x = ops.glow_unsqueeze(inp, c)
         return torch.clamp(ops.to_nchw(x, m.data_shape[0]), -.5, .5) * 2

@@ -24,9 +24,9 @@ class _GlowFn(torch.autograd.Function):
     """loss = engine.forward(...); backward = engine.backward over the saved tape (one node for the whole model)."""
 
     @staticmethod
-    def forward(ctx, engine, img, indicator, noise, train, holder, *params):
+    def forward(ctx, engine, img, label, noise, train, holder, *params):
         tape = []
-        loss, zs = engine.forward(img, indicator, noise, train, tape)
+        loss, zs = engine.forward(img, None, noise, train, tape, label=label)
         holder['z'] = zs
         ctx.engine, ctx.tape, ctx.params = engine, tape, params
         ctx.n, ctx.n_pixel = img.shape[0], float(img[0].numel())
@@ -161,19 +161,24 @@ class MCGlow(nn.Module):
     def forward(self, input):
         """Negative log-likelihood in bits/dim (mcglow.py:283-312).  The dequantisation noise U(0,1)/256 is
         drawn here unless `input['noise']` supplies it (parity runs)."""
-        indicator = F.one_hot(input['label'], cfg['classes_size']).float()
+        label = self._check_label(input['label'])        # one_hot(label) @ codebook == codebook[label] (modules.py:73)
         noise = input['noise'] if 'noise' in input else torch.rand_like(input['img'])
         if torch.is_grad_enabled() and self.training:
             holder = {}
             params = [p for p in self.parameters() if p.requires_grad]
-            loss = _GlowFn.apply(self._engine(), input['img'], indicator, noise, True, holder, *params)
+            loss = _GlowFn.apply(self._engine(), input['img'], label, noise, True, holder, *params)
             return {'loss': loss, 'z': holder['z']}
-        loss, z = self._engine().forward(input['img'], indicator, noise, self.training)
+        loss, z = self._engine().forward(input['img'], None, noise, self.training, label=label)
         return {'loss': loss, 'z': z}
 
+    @staticmethod
+    def _check_label(label):
+        if label.dtype != torch.int64 or label.dim() != 1:
+            raise ValueError('Not valid label: expected an int64 vector of class indices')
+        return label
+
     def reverse(self, input):
-        indicator = F.one_hot(input['label'], cfg['classes_size']).float()
-        return {'img': self._engine().reverse(input['z'], indicator, bool(input['reconstruct']))}
+        return {'img': self._engine().reverse(input['z'], None, bool(input['reconstruct']), label=self._check_label(input['label']))}
 
     def make_z_shapes(self):
         c, h, w = self.data_shape

@@ -63,6 +63,11 @@ class MultimodalController(nn.Module):
         """[N, C] = indicator @ codebook, from the buffer as it is right now."""
         return ops.mc_code(indicator, self.codebook)
 
+    def code_of_labels(self, label: torch.Tensor) -> torch.Tensor:
+        """The same [N, C] code for one-hot indicators, as a row gather: one_hot(label) @ codebook == codebook[label]
+        exactly.  Used by the fused model paths, which see the labels before they are one-hot encoded."""
+        return self.codebook.index_select(0, label)
+
     def forward(self, input):
         # list protocol of the reference: [x, indicator, ...] -> [x * code, indicator, ...]
         x, indicator = input[0], input[1]

@@ -597,7 +597,7 @@ def gaussian_logp_bwd(z: Tensor, c0: int, prior: Tensor, cz: int, dz: Tensor, d0
 
 def prod_colsum(a: Tensor, b: Tensor, c: int, out: Tensor, alpha: float = 1.0, accumulate: bool = False):
     pixels = a.numel() // a.shape[-1]
-    ws = torch.empty(64 * c, dtype=torch.float32, device=a.device)
+    ws = torch.empty(256 * c, dtype=torch.float32, device=a.device)
     check(_lib.load().mcgen_prod_colsum(_p(a), a.shape[-1], _p(b), b.shape[-1], _dt(a.dtype), pixels, c, _f32(out), float(alpha),
                                         int(accumulate), _f32(ws), _stream()), 'prod_colsum')
 

@@ -24,6 +24,10 @@ import torch.nn.functional as F
 from . import ops
 from .gan_engine import FlatState, _bump
 
+# 'thread_local': other threads of the process (the RCCL watchdog of a multi-rank run polls events) may keep
+# making HIP calls while this thread captures; only this thread's illegal calls abort the capture.
+_CAPTURE_MODE = 'thread_local'
+
 
 class FusedAdam:
     """torch.optim.Adam semantics over one flat parameter buffer: one launch per step."""
@@ -155,16 +159,16 @@ class GraphedGANTrainer(GANTrainer):
         torch.cuda.synchronize()
         self.g_dc, self.g_da = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.g_gc, self.g_ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_dc):
+        with torch.cuda.graph(self.g_dc, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
             self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z)
         pool = self.g_dc.pool()
-        with torch.cuda.graph(self.g_da, pool=pool):
+        with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.d_apply()
-        with torch.cuda.graph(self.g_gc, pool=pool):
+        with torch.cuda.graph(self.g_gc, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
             self.loss_g = self.g_compute(self.s_ind, self.s_z)
-        with torch.cuda.graph(self.g_ga, pool=pool):
+        with torch.cuda.graph(self.g_ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.g_apply()
         self._graphs = True
 
@@ -209,11 +213,11 @@ class GlowTrainer:
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
 
-    def _compute(self, img, indicator, noise):
+    def _compute(self, img, label, noise):
         eng = self.model._engine()
         self.gflat.zero_()
         tape = []
-        loss, _ = eng.forward(img, indicator, noise, True, tape)
+        loss, _ = eng.forward(img, None, noise, True, tape, label=label)
         eng.backward(tape, img.shape[0], float(img[0].numel()))
         return loss
 
@@ -239,23 +243,23 @@ class GlowTrainer:
         eng.assume_initialized = True
         self._bind_grads()
         self.s_img = img.clone()
-        self.s_ind = F.one_hot(label, cfg['classes_size']).float()
+        self.s_lab = label.clone()
         self.s_noise = torch.rand_like(img)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(max(1, warmup)):
-                self._compute(self.s_img, self.s_ind, self.s_noise)
+                self._compute(self.s_img, self.s_lab, self.s_noise)
                 self._allreduce()
                 self._apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_c, self.g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.no_grad():
-            with torch.cuda.graph(self.g_c):
+            with torch.cuda.graph(self.g_c, capture_error_mode=_CAPTURE_MODE):
                 self.s_noise.uniform_()
-                self.loss = self._compute(self.s_img, self.s_ind, self.s_noise)
-            with torch.cuda.graph(self.g_a, pool=self.g_c.pool()):
+                self.loss = self._compute(self.s_img, self.s_lab, self.s_noise)
+            with torch.cuda.graph(self.g_a, pool=self.g_c.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._apply()
         self._graphs = True
 
@@ -263,7 +267,7 @@ class GlowTrainer:
         from .config import cfg
         if getattr(self, '_graphs', None) and noise is None:
             self.s_img.copy_(img, non_blocking=True)
-            self.s_ind.copy_(F.one_hot(label, cfg['classes_size']).float(), non_blocking=True)
+            self.s_lab.copy_(label, non_blocking=True)
             self.g_c.replay()
             self._allreduce()
             self.g_a.replay()
@@ -271,11 +275,10 @@ class GlowTrainer:
         m = self.model
         m.train(True)
         self._bind_grads()
-        indicator = F.one_hot(label, cfg['classes_size']).float()
         if noise is None:
             noise = torch.rand_like(img)
         with torch.no_grad():
-            loss = self._compute(img, indicator, noise)
+            loss = self._compute(img, label, noise)
             self._allreduce()
             self._apply()
         return loss
