@@ -266,6 +266,36 @@ int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float* w_u, cons
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) over one flat gradient buffer (train_vae.py:110) */
 int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* norm_out, float* workspace /* 256 floats */, void* stream);
 
+/* ---- MCPixelCNN (models/mcpixelcnn.py) -------------------------------------------------------------------------
+ * The (k/2+1) x k vertical and 1 x (k/2+1) horizontal stacks of the 3x3 layers are 3x3 convolutions with zero taps
+ * (mcpixelcnn.py:29-35,50-54: asymmetric kernel + crop == shifted taps) and run on mcgen_conv_fused; the 7x7 mask-A
+ * layer goes through im2col + the fused 1x1 convolution. */
+/* col[n,h,w, t*Cp + c] = x[n, h + t/KW - oh, w + t%KW - ow, c] (0 outside); col2im is its adjoint (gather form) */
+int mcgen_im2col(const void* x, void* col, int dtype, int N, int H, int W, int Cp, int KH, int KW, int oh, int ow, void* stream);
+int mcgen_col2im(const void* dcol, void* dx, int dtype, int N, int H, int W, int Cp, int KH, int KW, int oh, int ow,
+                 int accumulate, void* stream);
+/* MCGatedActivation.forward (mcpixelcnn.py:16-20): s = [a | b] with 2C channels (pitch 2C);
+ * out[.., C] = code * relu(a * scale + shift) * sigmoid(b), (scale, shift) = the BatchNorm affine of this batch */
+int mcgen_gated_fwd(const void* s, const float* scale, const float* shift, const float* code, void* out, int dtype,
+                    int N, int HW, int C, void* stream);
+/* its backward, pass 1: ds = [dz | db] and per-block partial sums (sum dz, sum dz * xhat) as [blocks][2][C] */
+int mcgen_gated_bwd_stats(const void* s, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          const float* code, const void* g, void* ds, float* partials, int blocks, int dtype,
+                          int N, int HW, int C, void* stream);
+/* pass 2, in place on ds[.., :C]: da = scale * (dz - (S1 + xhat * S2) / count); sums = [S1 | S2] from mcgen_bn_bwd_finalize */
+int mcgen_gated_bwd_apply(void* ds, const void* s, const float* sums, const float* scale, const float* mean,
+                          const float* rstd, double count, int dtype, int64_t pixels, int C, void* stream);
+/* horiz_resid tail (mcpixelcnn.py:37-40,57-60): y = (x * scale + shift) * code (+ res) */
+int mcgen_affine_code_res(const void* x, const float* scale, const float* shift, const float* code, const void* res,
+                          void* y, int dtype, int N, int HW, int C, void* stream);
+/* backward of that tail, pass 1: dz = g * code and the BatchNorm-backward partial sums over x */
+int mcgen_code_bn_stats(const void* g, const float* code, const void* x, const float* mean, const float* rstd,
+                        void* dz, float* partials, int blocks, int dtype, int N, int HW, int C, void* stream);
+/* F.cross_entropy(logits, codes) per pixel (mcpixelcnn.py:100): loss_rows[p] = logsumexp - logit[target];
+ * dlogits (optional) = (softmax - onehot) * gscale */
+int mcgen_cross_entropy(const void* logits, const int64_t* target, float* loss_rows, void* dlogits, float gscale,
+                        int dtype, int64_t pixels, int C, int Cp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

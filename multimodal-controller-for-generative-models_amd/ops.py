@@ -622,3 +622,92 @@ def clip_grad_norm_(gflat: Tensor, max_norm: float) -> Tensor:
     check(_lib.load().mcgen_clip_grad_norm(_f32(gflat), gflat.numel(), float(max_norm), ws[256:].data_ptr(), _f32(ws),
                                            _stream()), 'clip_grad_norm')
     return ws[256]
+
+
+# --------------------------------------------------------------------------- #
+# MCPixelCNN (models/mcpixelcnn.py)
+def im2col(x: Tensor, kh: int, kw: int, oh: int, ow: int) -> Tensor:
+    n, h, w, cp = x.shape
+    col = torch.empty((n, h, w, kh * kw * cp), dtype=x.dtype, device=x.device)
+    check(_lib.load().mcgen_im2col(_p(x), _p(col), _dt(x.dtype), n, h, w, cp, kh, kw, oh, ow, _stream()), 'im2col')
+    return col
+
+
+def col2im(dcol: Tensor, cp: int, kh: int, kw: int, oh: int, ow: int, out: Optional[Tensor] = None) -> Tensor:
+    n, h, w, _ = dcol.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty((n, h, w, cp), dtype=dcol.dtype, device=dcol.device)
+    check(_lib.load().mcgen_col2im(_p(dcol), _p(out), _dt(dcol.dtype), n, h, w, cp, kh, kw, oh, ow, int(acc), _stream()), 'col2im')
+    return out
+
+
+def gated_fwd(s: Tensor, scale: Tensor, shift: Tensor, code: Tensor) -> Tensor:
+    n, h, w, c2 = s.shape
+    c = c2 // 2
+    out = torch.empty((n, h, w, c), dtype=s.dtype, device=s.device)
+    check(_lib.load().mcgen_gated_fwd(_p(s), _f32(scale), _f32(shift), _f32(code), _p(out), _dt(s.dtype), n, h * w, c, _stream()),
+          'gated_fwd')
+    return out
+
+
+def _bwd_sums(partials: Tensor, c: int, dgamma: Optional[Tensor], dbeta: Optional[Tensor]) -> Tensor:
+    tiles, _, pitch = partials.shape
+    sums = torch.empty((2, c), dtype=torch.float32, device=partials.device)
+    check(_lib.load().mcgen_bn_bwd_finalize(_f32(partials), tiles, pitch, c, _f32(dgamma), _f32(dbeta), _f32(sums), 0, _stream()),
+          'bn_bwd_finalize')
+    return sums
+
+
+def gated_bwd(s: Tensor, scale, shift, mean, rstd, code: Tensor, g: Tensor, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+    """Backward of gated_fwd through the batch statistics: returns ds [.., 2C]; fills dgamma / dbeta."""
+    n, h, w, c2 = s.shape
+    c = c2 // 2
+    pixels = n * h * w
+    blocks = max(1, min(256, pixels // 16))
+    ds = torch.empty_like(s)
+    part = torch.empty((blocks, 2, c), dtype=torch.float32, device=s.device)
+    lib = _lib.load()
+    check(lib.mcgen_gated_bwd_stats(_p(s), _f32(scale), _f32(shift), _f32(mean), _f32(rstd), _f32(code), _p(g), _p(ds), _f32(part),
+                                    blocks, _dt(s.dtype), n, h * w, c, _stream()), 'gated_bwd_stats')
+    sums = _bwd_sums(part, c, dgamma, dbeta)
+    check(lib.mcgen_gated_bwd_apply(_p(ds), _p(s), _f32(sums), _f32(scale), _f32(mean), _f32(rstd), float(pixels), _dt(s.dtype),
+                                    pixels, c, _stream()), 'gated_bwd_apply')
+    return ds
+
+
+def affine_code_res(x: Tensor, scale, shift, code: Tensor, res: Optional[Tensor]) -> Tensor:
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().mcgen_affine_code_res(_p(x), _f32(scale), _f32(shift), _f32(code), _p(res), _p(y), _dt(x.dtype), n, h * w, c,
+                                            _stream()), 'affine_code_res')
+    return y
+
+
+def code_bn_bwd(g: Tensor, code: Tensor, x: Tensor, scale, mean, rstd, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+    """Backward of y = BN(x) * code w.r.t. x (training-mode BatchNorm); fills dgamma / dbeta."""
+    n, h, w, c = x.shape
+    pixels = n * h * w
+    blocks = max(1, min(256, pixels // 16))
+    dz = torch.empty_like(x)
+    part = torch.empty((blocks, 2, c), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.mcgen_code_bn_stats(_p(g), _f32(code), _p(x), _f32(mean), _f32(rstd), _p(dz), _f32(part), blocks, _dt(x.dtype),
+                                  n, h * w, c, _stream()), 'code_bn_stats')
+    sums = _bwd_sums(part, c, dgamma, dbeta)
+    dx = torch.empty_like(x)
+    check(lib.mcgen_bn_bwd_apply(_p(dz), _p(x), None, _p(dx), _dt(x.dtype), pixels, c, _f32(sums), float(pixels), _f32(scale),
+                                 _f32(mean), _f32(rstd), _stream()), 'bn_bwd_apply')
+    return dx
+
+
+def cross_entropy(logits: Tensor, target: Tensor, c: int, want_grad: bool):
+    """-> (loss_rows [pixels] fp32, dlogits or None); dlogits is the gradient of the MEAN loss."""
+    pixels = logits.numel() // logits.shape[-1]
+    rows = torch.empty(pixels, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    if target.dtype != torch.int64 or target.numel() != pixels:
+        raise _lib.McgenError('cross_entropy: target must be int64 with one entry per pixel')
+    check(_lib.load().mcgen_cross_entropy(_p(logits), target.contiguous().data_ptr(), _f32(rows), _p(dl), 1.0 / pixels,
+                                          _dt(logits.dtype), pixels, c, logits.shape[-1], _stream()), 'cross_entropy')
+    return rows, dl

@@ -191,10 +191,11 @@ class GraphedGANTrainer(GANTrainer):
         return self.loss_d, self.loss_g
 
 
-class GlowTrainer:
-    """The loop body of train_glow.py:108-121 on the HIP path: zero_grad, likelihood forward (tape), backward,
-    clip_grad_norm_(parameters, 1), Adam(lr 3e-4) -- parameters and gradients each in one flat fp32 buffer,
-    so the clip and the optimizer are one launch each and a data-parallel run all-reduces one bucket."""
+class _FlatTrainer:
+    """Loop body shared by train_glow.py:108-121 and train_pixelcnn.py:108-121: zero_grad, forward, backward,
+    clip_grad_norm_(parameters, 1), Adam(lr 3e-4) -- parameters and gradients each in one flat fp32 buffer, so the
+    clip and the optimizer are one launch each and a data-parallel run all-reduces one bucket.  `capture` records
+    forward+backward and clip+Adam as two HIP graphs; the all-reduce of a multi-rank run sits between the replays."""
 
     def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), weight_decay=0.0, max_norm=1.0, dist_group=None, world_size=1):
         self.model = model
@@ -206,6 +207,7 @@ class GlowTrainer:
         self.max_norm = max_norm
         self.group, self.world = dist_group, world_size
         self.grad_norm = None
+        self._graphs = None
 
     def _bind_grads(self):
         self.fs.ensure()
@@ -213,13 +215,11 @@ class GlowTrainer:
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
 
-    def _compute(self, img, label, noise):
-        eng = self.model._engine()
-        self.gflat.zero_()
-        tape = []
-        loss, _ = eng.forward(img, None, noise, True, tape, label=label)
-        eng.backward(tape, img.shape[0], float(img[0].numel()))
-        return loss
+    def _compute(self, *inputs):            # forward + backward into self.gflat; returns the loss
+        raise NotImplementedError
+
+    def _refresh(self):                     # in-graph refresh of per-step random inputs
+        pass
 
     def _apply(self):
         self.grad_norm = ops.clip_grad_norm_(self.gflat, self.max_norm)
@@ -230,26 +230,15 @@ class GlowTrainer:
             from .dist import allreduce_mean_
             allreduce_mean_(self.gflat, self.group, self.world)
 
-    def capture(self, img, label, warmup: int = 1):
-        """Capture forward+backward and clip+Adam as two HIP graphs (the gradient all-reduce of a multi-rank
-        run sits between the replays).  Requires every ActNorm to be initialised already (the data-dependent
-        init reads a device flag on the host, which a capture cannot do)."""
-        from .config import cfg
-        m = self.model
-        m.train(True)
-        eng = m._engine()
-        if not eng.all_initialized():
-            raise RuntimeError('GlowTrainer.capture: run the ActNorm initialisation forward first (train_glow.py:60-67)')
-        eng.assume_initialized = True
+    def _capture(self, statics, warmup: int):
+        self.model.train(True)
         self._bind_grads()
-        self.s_img = img.clone()
-        self.s_lab = label.clone()
-        self.s_noise = torch.rand_like(img)
+        self.statics = statics
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(max(1, warmup)):
-                self._compute(self.s_img, self.s_lab, self.s_noise)
+                self._compute(*statics)
                 self._allreduce()
                 self._apply()
         torch.cuda.current_stream().wait_stream(side)
@@ -257,28 +246,74 @@ class GlowTrainer:
         self.g_c, self.g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.no_grad():
             with torch.cuda.graph(self.g_c, capture_error_mode=_CAPTURE_MODE):
-                self.s_noise.uniform_()
-                self.loss = self._compute(self.s_img, self.s_lab, self.s_noise)
+                self._refresh()
+                self.loss = self._compute(*statics)
             with torch.cuda.graph(self.g_a, pool=self.g_c.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._apply()
         self._graphs = True
 
-    def train_iteration(self, img, label, noise=None):
-        from .config import cfg
-        if getattr(self, '_graphs', None) and noise is None:
-            self.s_img.copy_(img, non_blocking=True)
-            self.s_lab.copy_(label, non_blocking=True)
-            self.g_c.replay()
-            self._allreduce()
-            self.g_a.replay()
-            return self.loss
-        m = self.model
-        m.train(True)
+    def _replay(self, *inputs):
+        for s, v in zip(self.statics, inputs):
+            s.copy_(v, non_blocking=True)
+        self.g_c.replay()
+        self._allreduce()
+        self.g_a.replay()
+        return self.loss
+
+    def _eager(self, *inputs):
+        self.model.train(True)
         self._bind_grads()
-        if noise is None:
-            noise = torch.rand_like(img)
         with torch.no_grad():
-            loss = self._compute(img, label, noise)
+            loss = self._compute(*inputs)
             self._allreduce()
             self._apply()
         return loss
+
+
+class GlowTrainer(_FlatTrainer):
+    """train_glow.py:108-121 on the HIP path (see _FlatTrainer)."""
+
+    def _compute(self, img, label, noise):
+        eng = self.model._engine()
+        self.gflat.zero_()
+        tape = []
+        loss, _ = eng.forward(img, None, noise, True, tape, label=label)
+        eng.backward(tape, img.shape[0], float(img[0].numel()))
+        return loss
+
+    def _refresh(self):
+        self.statics[2].uniform_()
+
+    def capture(self, img, label, warmup: int = 1):
+        """Requires every ActNorm to be initialised already (the data-dependent init reads a device flag on the
+        host, which a capture cannot do)."""
+        eng = self.model._engine()
+        if not eng.all_initialized():
+            raise RuntimeError('GlowTrainer.capture: run the ActNorm initialisation forward first (train_glow.py:60-67)')
+        eng.assume_initialized = True
+        self._capture((img.clone(), label.clone(), torch.rand_like(img)), warmup)
+
+    def train_iteration(self, img, label, noise=None):
+        if self._graphs and noise is None:
+            return self._replay(img, label)
+        return self._eager(img, label, torch.rand_like(img) if noise is None else noise)
+
+
+class PixelCNNTrainer(_FlatTrainer):
+    """train_pixelcnn.py:108-121 on the HIP path: the code map comes from the (frozen) VQ-VAE encoder upstream."""
+
+    def _compute(self, codes, label):
+        eng = self.model._engine()
+        self.gflat.zero_()
+        tape = {}
+        loss, _, _ = eng.forward(codes, label, True, tape, want_grad=True)
+        eng.backward(tape)
+        return loss
+
+    def capture(self, codes, label, warmup: int = 1):
+        self._capture((codes.clone(), label.clone()), warmup)
+
+    def train_iteration(self, codes, label):
+        if self._graphs:
+            return self._replay(codes, label)
+        return self._eager(codes, label)

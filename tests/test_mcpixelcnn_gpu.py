@@ -1,0 +1,162 @@
+"""GPU parity of the MCPixelCNN kernels and of the model forward / backward / train step on the HIP path against
+the reference-generated fixture (tests/golden/mcpixelcnn_small.npz) and the CPU oracle.  fp32 compute."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(np.asarray(b)).float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _model(sd):
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    cfg.update(model_name='mcpixelcnn', device='cuda', classes_size=10, controller_rate=0.5, compute_dtype='float32')
+    cfg['pixelcnn'] = {'num_layer': 4, 'hidden_size': 16, 'num_embedding': 32}
+    m = models.mcpixelcnn()
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def test_pixelcnn_kernels():
+    from mcgen_amd import ops
+    g = torch.Generator().manual_seed(7)
+    f32 = torch.float32
+    # im2col / col2im against F.unfold semantics (taps (i - oh, j - ow)), via the adjoint identity as well
+    x = torch.randn(2, 8, 6, 6, generator=g)
+    xt = ops.to_nhwc(x.cuda(), f32)
+    col = ops.im2col(xt, 4, 7, 3, 3)                                       # [2, 6, 6, 28 * 8]
+    ref = F.pad(x, (3, 3, 3, 0)).unfold(2, 4, 1).unfold(3, 7, 1)           # [2, 8, 6, 6, 4, 7]
+    ref = ref.permute(0, 2, 3, 4, 5, 1).reshape(2, 6, 6, 28 * 8)
+    assert torch.equal(col.cpu(), ref)
+    dcol = torch.randn(col.shape, generator=g).cuda()
+    dx = ops.col2im(dcol, 8, 4, 7, 3, 3)
+    lhs = float((col * dcol).sum()); rhs = float((xt * dx).sum())
+    assert abs(lhs - rhs) < 1e-3 * abs(lhs)
+    # gated activation forward / backward through batch statistics vs autograd
+    n, c, hw = 4, 16, 8
+    s = torch.randn(n, 2 * c, hw, hw, generator=g, requires_grad=True)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    go = torch.randn(n, c, hw, hw, generator=g)
+    a, b = s.chunk(2, 1)
+    out = torch.relu(F.batch_norm(a, None, None, gamma, beta, True, 0.1, 1e-5)) * torch.sigmoid(b) * code[:, :, None, None]
+    (out * go).sum().backward()
+    st = ops.to_nhwc(s.detach().cuda(), f32)
+    mean = a.detach().mean((0, 2, 3)); var = a.detach().var((0, 2, 3), unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    sc = (gamma.detach() * rstd).cuda(); sh = (beta.detach() - mean * gamma.detach() * rstd).cuda()
+    o = ops.gated_fwd(st, sc, sh, code.cuda())
+    assert _rel(ops.to_nchw(o, c), out.detach()) < 1e-5
+    dg, db = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    ds = ops.gated_bwd(st, sc, sh, mean.cuda(), rstd.cuda(), code.cuda(), ops.to_nhwc(go.cuda(), f32), dg, db)
+    assert _rel(ops.to_nchw(ds, 2 * c), s.grad) < 2e-5
+    assert _rel(dg, gamma.grad) < 2e-5 and _rel(db, beta.grad) < 2e-5
+    # BN -> MC -> (+res) tail and its backward
+    x2 = torch.randn(n, c, hw, hw, generator=g, requires_grad=True)
+    res = torch.randn(n, c, hw, hw, generator=g)
+    gamma.grad = None; beta.grad = None
+    y = F.batch_norm(x2, None, None, gamma, beta, True, 0.1, 1e-5) * code[:, :, None, None] + res
+    (y * go).sum().backward()
+    mean = x2.detach().mean((0, 2, 3)); rstd = 1 / torch.sqrt(x2.detach().var((0, 2, 3), unbiased=False) + 1e-5)
+    sc = (gamma.detach() * rstd).cuda(); sh = (beta.detach() - mean * gamma.detach() * rstd).cuda()
+    x2t = ops.to_nhwc(x2.detach().cuda(), f32)
+    yt = ops.affine_code_res(x2t, sc, sh, code.cuda(), ops.to_nhwc(res.cuda(), f32))
+    assert _rel(ops.to_nchw(yt, c), y.detach()) < 1e-5
+    dx2 = ops.code_bn_bwd(ops.to_nhwc(go.cuda(), f32), code.cuda(), x2t, sc, mean.cuda(), rstd.cuda(), dg, db)
+    assert _rel(ops.to_nchw(dx2, c), x2.grad) < 2e-5 and _rel(dg, gamma.grad) < 2e-5 and _rel(db, beta.grad) < 2e-5
+    # cross-entropy + gradient
+    logits = (torch.randn(3, 20, 4, 4, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, 20, (3, 4, 4), generator=g)
+    loss = F.cross_entropy(logits, tgt)
+    loss.backward()
+    rows, dl = ops.cross_entropy(ops.to_nhwc(logits.detach().cuda(), f32), tgt.reshape(-1).cuda(), 20, True)
+    assert abs(float(rows.mean()) - float(loss)) < 1e-5
+    assert _rel(ops.to_nchw(dl, 20), logits.grad) < 1e-5
+
+
+def test_pixelcnn_forward_vs_reference():
+    d = gu.load_npz('mcpixelcnn_small.npz')
+    codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
+    m = _model(gu.state_from_npz(d))
+    m.train(True)
+    with torch.no_grad():
+        out = m({'img': codes, 'label': lab})
+    assert abs(float(out['loss']) - float(d['losses'][0])) < 1e-4
+    assert _rel(out['logits'], d['logits0']) < 2e-4
+    # mask 'A' zeroed the parameters in place (mcpixelcnn.py:43-45)
+    assert float(m.layers[0].vert_stack.weight[:, :, -1].abs().max()) == 0.0
+    assert float(m.layers[0].horiz_stack.weight[:, :, :, -1].abs().max()) == 0.0
+    assert int(m.layers[1].gate_v.bn.num_batches_tracked) == 1
+    m = _model(gu.state_from_npz(d, 'sd_final/'))
+    m.train(False)
+    with torch.no_grad():
+        out = m({'img': codes, 'label': lab})
+    assert _rel(out['logits'], d['logits_eval']) < 5e-4
+
+
+def _oracle_grads(sd, codes, lab):
+    from oracle import mcpixelcnn_oracle as O
+    skip = ('running_mean', 'running_var', 'num_batches_tracked', 'codebook')
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith(skip) else v.clone())
+           for k, v in sd.items()}
+    out = O.forward(sdg, codes, lab, 10, train=True)
+    out['loss'].backward()
+    return float(out['loss'].detach()), {k: v.grad for k, v in sdg.items() if v.requires_grad and v.grad is not None}
+
+
+def test_pixelcnn_gradients_vs_oracle():
+    d = gu.load_npz('mcpixelcnn_small.npz')
+    codes, lab = torch.from_numpy(d['codes']), torch.from_numpy(d['label'])
+    sd = gu.state_from_npz(d)
+    loss_ref, gref = _oracle_grads(sd, codes, lab)
+    m = _model(gu.state_from_npz(d))
+    m.train(True)
+    out = m({'img': codes.cuda(), 'label': lab.cuda()})
+    assert abs(float(out['loss'].detach()) - loss_ref) < 1e-4
+    out['loss'].backward()
+    named = dict(m.named_parameters())
+    assert set(gref) <= set(named)
+    for k, gr in gref.items():
+        gg = named[k].grad
+        assert gg is not None, k
+        err = float((gg.cpu() - gr).abs().max())
+        # conv biases that feed straight into a BatchNorm have an exactly-zero gradient: absolute floor
+        tol = 5e-4 * float(gr.abs().max()) + 2e-6
+        assert err < tol, (k, err, tol)
+    # parameters the oracle gives no gradient (last layer's unused vertical gate) get none or zero here
+    for k, p in named.items():
+        if k not in gref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+def test_pixelcnn_train_steps_vs_reference():
+    """train_pixelcnn.py loop body x3 (clip_grad_norm_ 1, Adam 3e-4) on the fixture: losses and final weights
+    (Adam's +-lr sign steps on rounding-noise gradients bound the weight difference by ~2*lr per step)."""
+    from mcgen_amd.trainer import PixelCNNTrainer
+    d = gu.load_npz('mcpixelcnn_small.npz')
+    codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
+    m = _model(gu.state_from_npz(d))
+    tr = PixelCNNTrainer(m)
+    losses = [float(tr.train_iteration(codes, lab)) for _ in range(3)]
+    assert abs(losses[0] - d['losses'][0]) < 1e-4, (losses, d['losses'])
+    assert max(abs(a - b) for a, b in zip(losses, d['losses'])) < 3e-3, (losses, d['losses'])
+    fin = gu.state_from_npz(d, 'sd_final/')
+    sd = m.state_dict()
+    for k, v in fin.items():
+        if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var')):
+            assert float((sd[k].cpu() - v).abs().max()) < 2e-3, k
+    # graph replay follows the eager path
+    m2 = _model(gu.state_from_npz(d))
+    t2 = PixelCNNTrainer(m2)
+    t2.capture(codes, lab, warmup=1)
+    l2 = [float(t2.train_iteration(codes, lab)) for _ in range(2)]
+    assert abs(l2[0] - losses[1]) < 3e-3 and abs(l2[1] - losses[2]) < 3e-3, (l2, losses)
