@@ -100,6 +100,23 @@ def try_capture(capture, world, dev):
     return bool(ok)
 
 
+def attach_traffic(roofline):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+    command (profiles/traffic.json, written by tools/profile_summary.py: FETCH_SIZE x2 + WRITE_SIZE); None when the
+    table has no entry for that kernel.  PMC counters cannot be collected from inside the timed process."""
+    if not roofline:
+        return roofline
+    try:
+        table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        e = table.get(roofline['kernel'])
+        if e:
+            roofline['traffic'] = e['bytes_per_launch']
+            roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)'
+    except Exception:
+        pass
+    return roofline
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -343,7 +360,7 @@ def main():
             'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses,
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': attach_traffic(roofline), 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turn the output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the bench command
+  profiles/<tag>_bench.json         the bench line printed under the profiler
+  profiles/<tag>_traffic.json       per bench-kernel-name HBM traffic per launch from the two PMC passes
+                                    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; KB -> bytes)
+  profiles/traffic.json             copy of the latest traffic table; bench.py reads it for roofline.traffic
+usage: tools/profile_summary.py <tag> [workload-suffix]"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bench_name(k: str):
+    """rocprof kernel symbol -> the name bench.py's roofline.by_kernel uses (None: not a conv/wgrad kernel)."""
+    m = re.search(r'conv_\w+?_kernelI(DF16b|f)Li(\d+)ELi(\d+)E', k)
+    if m:
+        return f'conv_fused<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)},{m.group(3)}>'
+    if 'wgrad_reduce' in k:
+        return None
+    m = re.search(r'wgrad_(?:pc_)?kernelI(DF16b|f)Li(\d+)E', k)
+    if m:
+        return f'wgrad<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)}>'
+    if 'wgrad_pc_kernel<' in k or 'wgrad_kernel<' in k:      # mis-demangled symbols: the 1x1 instantiations
+        return 'wgrad<bf16,1>'
+    return None
+
+
+def pmc(path, counter):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] != counter:
+                continue
+            n = bench_name(r['Kernel_Name'])
+            if n:
+                acc[n].append(float(r['Counter_Value']))
+    return acc
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
+    dst = os.path.join(ROOT, 'profiles')
+    shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+    for line in open(os.path.join(src, 'bench_trace.log')):
+        if line.startswith('{"metric"'):
+            open(os.path.join(dst, f'{tag}_bench.json'), 'w').write(line)
+    fetch = pmc(os.path.join(src, 'fetch', 'f_counter_collection.csv'), 'FETCH_SIZE')
+    write = pmc(os.path.join(src, 'write', 'w_counter_collection.csv'), 'WRITE_SIZE')
+    table = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, []), write.get(k, [])
+        fk = sum(f) / max(1, len(f)); wk = sum(w) / max(1, len(w))
+        table[k] = {'launches': len(f), 'fetch_size_kb': fk, 'write_size_kb': wk,
+                    'bytes_per_launch': (2.0 * fk + wk) * 1024.0,
+                    'note': 'FETCH_SIZE x2 (gfx950 half-count of wide reads) + WRITE_SIZE, averaged over the launches of one eager iteration'}
+    json.dump(table, open(os.path.join(dst, f'{tag}_traffic.json'), 'w'), indent=1)
+    json.dump(table, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+    for k, v in table.items():
+        print(f'{k:28s} n={v["launches"]:4d} fetch {v["fetch_size_kb"]:10.0f} KB  write {v["write_size_kb"]:10.0f} KB')
+
+
+if __name__ == '__main__':
+    main()
