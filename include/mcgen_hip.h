@@ -246,6 +246,20 @@ int mcgen_gaussian_sample(const void* eps, int Cpe, const void* prior, int Cpp, 
 /* dst[..., c0:c0+Cn] = src[..., s0:s0+Cn]   (split / concat of the multi-scale architecture) */
 int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, int Cpd, int c0, int dtype, int64_t pixels, int Cn, void* stream);
 
+/* every split-K reduction of one backward pass in one launch (the per-layer mcgen_wgrad_reduce calls, batched);
+ * slab size is derived from (Cin, ksize, Cout_w) as in mcgen_wgrad_slab_elems */
+#define MCGEN_WREDUCE_MAX 16
+typedef struct {
+    const float* slabs;       /* [splits][slab_elems]                       */
+    float*       grad;        /* [Cout][Cin][k][k] master layout             */
+    const float* bias_slabs;  /* [splits*4][Cout_w] or NULL                  */
+    float*       bias_grad;   /* [Cout] or NULL                              */
+    float*       bias_grad2;  /* optional second destination                 */
+    int32_t splits, Cout, Cin, ksize, Cout_w, row_perm, accumulate;
+    float   alpha;
+} mcgen_wreduce_t;
+int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void* stream);
+
 /* ---- MCGlow backward (autograd of the same lines) ------------------------------------------------------------ */
 /* coupling backward: dv = [dy_a | dy_b * s], dh = [dy_b (v_b + t) s (1 - s) + g (1 - s) | dy_b * s], g = dL/dlogdet_n */
 int mcgen_glow_coupling_bwd(const void* v, const void* h, const void* dy, void* dv, void* dh, int dtype, float g,

@@ -33,6 +33,13 @@ class Wgrad(C.Structure):
                 ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32), ('bias_slabs', C.c_void_p)]
 
 
+class WReduce(C.Structure):
+    _fields_ = [('slabs', C.c_void_p), ('grad', C.c_void_p), ('bias_slabs', C.c_void_p), ('bias_grad', C.c_void_p),
+                ('bias_grad2', C.c_void_p),
+                ('splits', C.c_int32), ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('Cout_w', C.c_int32),
+                ('row_perm', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float)]
+
+
 class Prep(C.Structure):
     _fields_ = [('w', C.c_void_p), ('image', C.c_void_p),
                 ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('transpose', C.c_int32),
@@ -85,6 +92,7 @@ SYMBOLS = {
     'mcgen_affine_code_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_code_bn_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
+    'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -380,10 +380,10 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 
 // Sums the split slabs in slab order (coalesced 16-byte reads, 4 splits in flight) and scatters into
 // the master layout.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
-                                    float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
-                                    int row_perm, float alpha, int accumulate,
-                                    const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
+__device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int splits, size_t slab_elems,
+                                           float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
+                                           int row_perm, float alpha, int accumulate,
+                                           const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
     const int ntap = KS * KS;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int Cc = row_perm > 1 ? Cout / row_perm : Cout;
@@ -429,6 +429,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
             }
         }
     }
+}
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
+                                    float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
+                                    int row_perm, float alpha, int accumulate,
+                                    const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
+    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2);
+}
+// All reductions of one backward pass in ONE launch: blockIdx.y picks the job, the job table travels by value
+// in the kernel arguments (graph-capture safe: no host table to keep alive).
+struct ReduceJobs { mcgen_wreduce_t j[MCGEN_WREDUCE_MAX]; };
+__global__ void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
+    const mcgen_wreduce_t& j = jobs.j[blockIdx.y];
+    const int nchunk = ((j.Cin + 7) / 8 * 8 + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK;
+    reduce_job(j.slabs, j.splits, slab_elems, j.grad, j.Cout, j.Cin, j.ksize, j.Cout_w, j.row_perm, j.alpha, j.accumulate,
+               j.bias_slabs, j.bias_grad, j.bias_grad2);
 }
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
@@ -527,5 +543,28 @@ extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, i
                        slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
                        bias_slabs, bias_grad, bias_grad2);
     MCGEN_LAUNCH_CHECK("wgrad_reduce");
+    return 0;
+}
+
+extern "C" int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "wgrad_reduce_batch: bad arguments");
+    for (int base = 0; base < n; base += MCGEN_WREDUCE_MAX) {
+        const int m = (n - base < MCGEN_WREDUCE_MAX) ? n - base : MCGEN_WREDUCE_MAX;
+        ReduceJobs t;
+        size_t most = 1;
+        for (int i = 0; i < m; ++i) {
+            const mcgen_wreduce_t& j = jobs[base + i];
+            MCGEN_CHECK(j.slabs && j.grad && j.splits > 0 && j.Cout > 0 && j.Cin > 0 && (j.ksize == 1 || j.ksize == 3) && j.Cout_w >= j.Cout,
+                        "wgrad_reduce_batch: bad job %d", base + i);
+            t.j[i] = j;
+            const int nchunk = (round_up(j.Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
+            const size_t v4 = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK / 4;
+            if (v4 > most) most = v4;
+        }
+        for (int i = m; i < MCGEN_WREDUCE_MAX; ++i) t.j[i] = t.j[0];
+        int blocks = (int)((most + 255) / 256); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks, m), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t);
+        MCGEN_LAUNCH_CHECK("wgrad_reduce_batch");
+    }
     return 0;
 }

@@ -245,6 +245,11 @@ class GeneratorEngine:
         dtn = ops.tanh_bwd(dout, out)
         y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
         c_img, c = head_conv.out_channels, head_conv.in_channels
+        with ops.deferred_reduces():
+            self._backward_body(ctx, gflat, acc, dtn, y, bnh, codeh, c_img, c, lin, res, head_bn, head_conv, n)
+
+    def _backward_body(self, ctx, gflat, acc, dtn, y, bnh, codeh, c_img, c, lin, res, head_bn, head_conv, n):
+        G = lambda p: self.flat_p.view_of(gflat, p)                           # noqa: E731
         # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
         seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
         ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc, bias_grad=G(head_conv.bias))
@@ -466,42 +471,43 @@ class DiscriminatorEngine:
         tl = self.sn_of[self.tail_lin]
         sg_t = sigma[tl.idx:tl.idx + 1]
         wl = self.tail_lin.weight_orig
-        dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
-                           T(wl).view(-1) if want_w else None, T(self.tail_lin.bias) if want_w else None)
-        for bi in reversed(range(1, len(self.res))):
-            b, bc = self.res[bi], ctx['blocks'][bi]
-            x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
-            c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
-            scm = self.sn_of[b.shortcut[1].module] if has_sc else None
-            a = 0.25 if pooled else 1.0
-            if want_w:
-                ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a,
-                          bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias) if has_sc else None)
+        with ops.deferred_reduces():          # all split-K reductions of this pass: one launch, before the SN fix-up
+            dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
+                               T(wl).view(-1) if want_w else None, T(self.tail_lin.bias) if want_w else None)
+            for bi in reversed(range(1, len(self.res))):
+                b, bc = self.res[bi], ctx['blocks'][bi]
+                x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
+                c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
+                scm = self.sn_of[b.shortcut[1].module] if has_sc else None
+                a = 0.25 if pooled else 1.0
+                if want_w:
+                    ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a,
+                              bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias) if has_sc else None)
+                    if has_sc:
+                        ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
+                dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
+                if want_w:
+                    ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
                 if has_sc:
-                    ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
-            dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
+                    res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1)
+                else:
+                    res = dy
+                dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
+            # FirstDisResBlock
+            b0, bc = self.res[0], ctx['blocks'][0]
+            c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
+            c1, code, img = bc['c1'], bc['code'], ctx['img']
             if want_w:
-                ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
-            if has_sc:
-                res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1)
-            else:
-                res = dy
-            dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
-        # FirstDisResBlock
-        b0, bc = self.res[0], ctx['blocks'][0]
-        c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
-        c1, code, img = bc['c1'], bc['code'], ctx['img']
-        if want_w:
-            ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25,
-                      bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias))
-            ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
-        dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)
-        if want_w:
-            ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
-        dimg = None
-        if need_input_grad:
-            dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
-            dimg = ops.to_nchw(dimg_t, c1m.cin)
+                ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25,
+                          bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias))
+                ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
+            dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)
+            if want_w:
+                ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
+            dimg = None
+            if need_input_grad:
+                dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
+                dimg = ops.to_nchw(dimg_t, c1m.cin)
         if want_w:
             # d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used; biases are moved as is
             ops.sn_grad_fix(gtmp, gflat, fp, uv, self._layers_dev, len(self.sn) + len(self.plain), sigma,

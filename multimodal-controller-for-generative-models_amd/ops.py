@@ -265,7 +265,8 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         blocks = ((pad16(cout) + 63) // 64) * nchunk
         # enough workgroups to fill the chip matters more than the slab traffic (measured: 8x8 layers lose
         # 20 % with 16 instead of 64 splits)
-        splits = max(1, min(m_tiles, (512 + blocks - 1) // blocks, 64))
+        target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL
+        splits = max(1, min(m_tiles, (target + blocks - 1) // blocks, 64))
     p.splits = splits
     lib = _lib.load()
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
@@ -281,9 +282,45 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
            lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
+    if _deferred is not None:
+        if not grad.is_contiguous():
+            raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
+        _deferred.append((slabs, grad, bias_slabs, bias_grad, bias_grad2, splits, cout, cin, seg.ksize, pad16(cout), row_perm,
+                          int(accumulate), float(alpha)))
+        return
     check(lib.mcgen_wgrad_reduce(_p(slabs), splits, _f32(grad), cout, cin, seg.ksize, pad16(cout), row_perm,
                                  float(alpha), int(accumulate), _p(bias_slabs), _f32(bias_grad), _f32(bias_grad2),
                                  _stream()), 'wgrad_reduce')
+
+
+_deferred = None
+_WG_TARGET = int(_os.environ.get('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
+_WG_TARGET_SMALL = int(_os.environ.get('MCGEN_WGRAD_TARGET_SMALL', '256'))
+_WG_BIG_TILES = int(_os.environ.get('MCGEN_WGRAD_BIG_TILES', '256'))
+
+
+class deferred_reduces:
+    """Within this context every ops.wgrad launches only its split-K kernel; the slab reductions of the whole pass
+    run as ONE table-driven launch on exit (a backward pass has ~10 of them, each too small to fill the chip)."""
+
+    def __enter__(self):
+        global _deferred
+        self._outer = _deferred
+        _deferred = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _deferred
+        jobs, _deferred = _deferred, self._outer
+        if et is None and jobs:
+            arr = (_lib.WReduce * len(jobs))()
+            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha) in zip(arr, jobs):
+                a.slabs, a.grad, a.bias_slabs = _p(slabs), _f32(grad), _p(bs)
+                a.bias_grad, a.bias_grad2 = _f32(bg) if bs is not None else None, _f32(bg2) if bs is not None else None
+                a.splits, a.Cout, a.Cin, a.ksize, a.Cout_w = splits, cout, cin, ks, cout_w
+                a.row_perm, a.accumulate, a.alpha = row_perm, acc, alpha
+            check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch')
+        return False
 
 
 def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
