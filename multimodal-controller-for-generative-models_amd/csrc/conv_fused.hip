@@ -1228,6 +1228,8 @@ static const CfgEntry* bf16_table(int* n) {
         {256, 128, 5, launch_dma<T, 256, 128, 4, 2, 3>}, {128, 128, 5, launch_dma<T, 128, 128, 2, 2, 3>},
         {64, 128, 5, launch_dma<T, 64, 128, 2, 2, 3>},   {64, 64, 5, launch_dma<T, 64, 64, 2, 2, 3>},
         {128, 16, 5, launch_dma<T, 128, 16, 4, 1, 3>},
+        {32, 64, 5, launch_dma<T, 32, 64, 1, 2, 3>},   {32, 128, 5, launch_dma<T, 32, 128, 1, 4, 3>},
+        {32, 64, 8, launch_dma<T, 32, 64, 2, 2, 3>},   {64, 32, 5, launch_dma<T, 64, 32, 2, 1, 3>},
         {64, 64, 6, launch_res<T, 64, 64, 2, 2, 8, 3>},   {64, 128, 6, launch_res<T, 64, 128, 2, 2, 8, 3>},
         {128, 128, 6, launch_res<T, 128, 128, 2, 2, 8, 3>}, {128, 16, 6, launch_res<T, 128, 16, 4, 1, 8, 3>},
         {64, 64, 7, launch_res<T, 64, 64, 2, 2, 8, 8>},   {64, 128, 7, launch_res<T, 64, 128, 2, 2, 4, 4>},

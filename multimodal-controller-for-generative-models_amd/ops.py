@@ -270,16 +270,24 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     p.splits = splits
     lib = _lib.load()
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
-    slabs = torch.empty((splits, elems), dtype=torch.float32, device=dy.device)
-    p.slabs = _p(slabs)
-    bias_slabs = None
-    if bias_grad is not None:
-        bias_slabs = torch.empty((splits * 4, pad16(cout)), dtype=torch.float32, device=dy.device)
-    p.bias_slabs = _p(bias_slabs)
-    _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>' + (
-        f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _os.environ.get('MCGEN_PROF_SHAPES') else ''),
-           2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
-           lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
+    # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
+    # already exist, and nothing reads its slabs before the pass's batched reduce, so it overlaps the
+    # input-gradient chain that continues on the main stream.
+    side = _side_stream(dy.device) if (_deferred is not None and _SIDE) else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        _side_keep.extend((seg.x, dy, seg.scale, seg.shift, seg.code))      # keep alive until the join
+    with (torch.cuda.stream(side) if side is not None else _nullctx()):
+        slabs = torch.empty((splits, elems), dtype=torch.float32, device=dy.device)
+        p.slabs = _p(slabs)
+        bias_slabs = None
+        if bias_grad is not None:
+            bias_slabs = torch.empty((splits * 4, pad16(cout)), dtype=torch.float32, device=dy.device)
+        p.bias_slabs = _p(bias_slabs)
+        _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>' + (
+            f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _os.environ.get('MCGEN_PROF_SHAPES') else ''),
+               2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
+               lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     if _deferred is not None:
@@ -294,6 +302,26 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
 
 
 _deferred = None
+_SIDE = _os.environ.get('MCGEN_SIDE_STREAM', '0') == '1'     # measured slower on MI355X (16.7 vs 15.7 ms/step): opt-in only
+_side_streams = {}
+_side_keep = []
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 _WG_TARGET = int(_os.environ.get('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
 _WG_TARGET_SMALL = int(_os.environ.get('MCGEN_WGRAD_TARGET_SMALL', '256'))
 _WG_BIG_TILES = int(_os.environ.get('MCGEN_WGRAD_BIG_TILES', '256'))
@@ -312,6 +340,11 @@ class deferred_reduces:
     def __exit__(self, et, ev, tb):
         global _deferred
         jobs, _deferred = _deferred, self._outer
+        if _SIDE and _side_keep:
+            for s in _side_streams.values():                 # join: the slabs are complete before they are reduced
+                torch.cuda.current_stream().wait_stream(s)
+            if self._outer is None:
+                _side_keep.clear()
         if et is None and jobs:
             arr = (_lib.WReduce * len(jobs))()
             for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha) in zip(arr, jobs):
