@@ -276,13 +276,19 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})')
+    # one rank per GPU; MCGEN_DIST_BACKEND=gloo lets several ranks share one card for a rehearsal of the N>1 path
+    backend = os.environ.get('MCGEN_DIST_BACKEND', 'nccl')
+    local = local % max(1, torch.cuda.device_count()) if backend != 'nccl' else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     from mcgen_amd import ops

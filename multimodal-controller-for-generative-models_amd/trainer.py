@@ -228,7 +228,7 @@ class _FlatTrainer:
     def _allreduce(self):
         if self.world > 1:
             from .dist import allreduce_mean_
-            allreduce_mean_(self.gflat, self.group, self.world)
+            allreduce_mean_(self.gflat, self.world, self.group)
 
     def _capture(self, statics, warmup: int):
         self.model.train(True)

@@ -1,0 +1,28 @@
+"""Rehearsal of bench.py's N>1 path on ONE card: two ranks under torch.distributed.run share cuda:0 and exchange
+gradients through gloo (MCGEN_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  Checks the launch
+contract (env rendezvous on 127.0.0.1, graph capture with a live process group, all-reduce between replays,
+max-over-ranks timing, one JSON line from rank 0) -- not performance."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('workload', ['mcpixelcnn', 'cifar10'])
+def test_bench_two_ranks_one_card(workload):
+    env = dict(os.environ, MCGEN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', workload, '--steps', '2',
+           '--warmup', '1', '--no-roofline', '--batch', '16']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 32 and out['value'] > 0
