@@ -284,10 +284,14 @@ int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* norm_out, f
  * The (k/2+1) x k vertical and 1 x (k/2+1) horizontal stacks of the 3x3 layers are 3x3 convolutions with zero taps
  * (mcpixelcnn.py:29-35,50-54: asymmetric kernel + crop == shifted taps) and run on mcgen_conv_fused; the 7x7 mask-A
  * layer goes through im2col + the fused 1x1 convolution. */
-/* col[n,h,w, t*Cp + c] = x[n, h + t/KW - oh, w + t%KW - ow, c] (0 outside); col2im is its adjoint (gather form) */
-int mcgen_im2col(const void* x, void* col, int dtype, int N, int H, int W, int Cp, int KH, int KW, int oh, int ow, void* stream);
+/* col[n,ho,wo, t*Cp + c] = X[n, ho*stride + t/KW - oh, wo*stride + t%KW - ow, c] (0 outside), [Ho,Wo] = [H,W]/stride,
+ * X = relu?(x*scale + shift) * code (all optional).  col2im is the adjoint in gather form (+ bias when not
+ * accumulating).  4x4 taps, stride 2, oh = ow = 1: im2col + 1x1 conv == nn.Conv2d(.., 4, 2, 1) (mcvae.py:40,45),
+ * 1x1 conv + col2im == nn.ConvTranspose2d(.., 4, 2, 1) (mcvae.py:89,95). */
+int mcgen_im2col(const void* x, void* col, int dtype, int N, int H, int W, int Cp, int KH, int KW, int oh, int ow,
+                 int stride, const float* scale, const float* shift, int relu, const float* code, void* stream);
 int mcgen_col2im(const void* dcol, void* dx, int dtype, int N, int H, int W, int Cp, int KH, int KW, int oh, int ow,
-                 int accumulate, void* stream);
+                 int stride, const float* bias, int C, int accumulate, void* stream);
 /* MCGatedActivation.forward (mcpixelcnn.py:16-20): s = [a | b] with 2C channels (pitch 2C);
  * out[.., C] = code * relu(a * scale + shift) * sigmoid(b), (scale, shift) = the BatchNorm affine of this batch */
 int mcgen_gated_fwd(const void* s, const float* scale, const float* shift, const float* code, void* out, int dtype,
@@ -299,12 +303,19 @@ int mcgen_gated_bwd_stats(const void* s, const float* scale, const float* shift,
 /* pass 2, in place on ds[.., :C]: da = scale * (dz - (S1 + xhat * S2) / count); sums = [S1 | S2] from mcgen_bn_bwd_finalize */
 int mcgen_gated_bwd_apply(void* ds, const void* s, const float* sums, const float* scale, const float* mean,
                           const float* rstd, double count, int dtype, int64_t pixels, int C, void* stream);
-/* horiz_resid tail (mcpixelcnn.py:37-40,57-60): y = (x * scale + shift) * code (+ res) */
+/* BN -> (ReLU) -> MC -> (+res) -> (ReLU) tails: y = post_relu?( pre_relu?(x*scale + shift) * code + res )
+ * (mcpixelcnn.py:37-40,57-60 horiz_resid; mcvae.py:17-35 ResBlock; mcvae.py:40-48,86-92 stage activations) */
 int mcgen_affine_code_res(const void* x, const float* scale, const float* shift, const float* code, const void* res,
-                          void* y, int dtype, int N, int HW, int C, void* stream);
-/* backward of that tail, pass 1: dz = g * code and the BatchNorm-backward partial sums over x */
+                          void* y, int dtype, int N, int HW, int C, int pre_relu, int post_relu, void* stream);
+/* backward of such a tail, pass 1: g' = g * [y_post > 0] (if y_post; also written to g_gated = the residual's gradient),
+ * dz = g' * code * [x*scale + shift > 0 if pre_relu], and the BatchNorm-backward partial sums of dz over x */
 int mcgen_code_bn_stats(const void* g, const float* code, const void* x, const float* mean, const float* rstd,
-                        void* dz, float* partials, int blocks, int dtype, int N, int HW, int C, void* stream);
+                        void* dz, float* partials, int blocks, int dtype, int N, int HW, int C,
+                        const float* scale, const float* shift, int pre_relu, const void* y_post, void* g_gated, void* stream);
+/* VAE reconstruction term (mcvae.py:10-11): recon = sigmoid(logits), partials[b] = block sums of BCE(recon, target),
+ * dlogits (optional) = (recon - target) * gscale; target fp32 in the logits' NHWC pitch */
+int mcgen_bce_logits(const void* logits, const float* target, void* recon, void* dlogits, float* partials, int blocks,
+                     float gscale, int dtype, int64_t pixels, int C, int Cp, void* stream);
 /* F.cross_entropy(logits, codes) per pixel (mcpixelcnn.py:100): loss_rows[p] = logsumexp - logit[target];
  * dlogits (optional) = (softmax - onehot) * gscale */
 int mcgen_cross_entropy(const void* logits, const int64_t* target, float* loss_rows, void* dlogits, float gscale,

@@ -84,13 +84,14 @@ SYMBOLS = {
     'mcgen_actnorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _vp]),
     'mcgen_invconv_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     'mcgen_clip_grad_norm': (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
-    'mcgen_im2col': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'mcgen_col2im': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_im2col': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    'mcgen_col2im': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'mcgen_bce_logits': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_gated_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_gated_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_gated_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i64, _i, _vp]),
-    'mcgen_affine_code_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'mcgen_code_bn_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_affine_code_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_code_bn_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),

@@ -696,19 +696,27 @@ def clip_grad_norm_(gflat: Tensor, max_norm: float) -> Tensor:
 
 # --------------------------------------------------------------------------- #
 # MCPixelCNN (models/mcpixelcnn.py)
-def im2col(x: Tensor, kh: int, kw: int, oh: int, ow: int) -> Tensor:
+def im2col(x: Tensor, kh: int, kw: int, oh: int, ow: int, stride: int = 1, scale: Optional[Tensor] = None,
+           shift: Optional[Tensor] = None, relu: bool = False, code: Optional[Tensor] = None) -> Tensor:
+    """[N,H,W,Cp] -> [N,H/stride,W/stride,kh*kw*Cp] of the (optionally activated) input; see mcgen_im2col."""
     n, h, w, cp = x.shape
-    col = torch.empty((n, h, w, kh * kw * cp), dtype=x.dtype, device=x.device)
-    check(_lib.load().mcgen_im2col(_p(x), _p(col), _dt(x.dtype), n, h, w, cp, kh, kw, oh, ow, _stream()), 'im2col')
+    col = torch.empty((n, h // stride, w // stride, kh * kw * cp), dtype=x.dtype, device=x.device)
+    if code is not None and tuple(code.shape) != (n, cp):
+        raise _lib.McgenError(f'im2col: code must be {(n, cp)}')
+    check(_lib.load().mcgen_im2col(_p(x), _p(col), _dt(x.dtype), n, h, w, cp, kh, kw, oh, ow, stride, _f32(scale), _f32(shift),
+                                   int(relu), _f32(code), _stream()), 'im2col')
     return col
 
 
-def col2im(dcol: Tensor, cp: int, kh: int, kw: int, oh: int, ow: int, out: Optional[Tensor] = None) -> Tensor:
-    n, h, w, _ = dcol.shape
+def col2im(dcol: Tensor, cp: int, kh: int, kw: int, oh: int, ow: int, stride: int = 1, bias: Optional[Tensor] = None,
+           out: Optional[Tensor] = None) -> Tensor:
+    """Adjoint of im2col: [N,Ho,Wo,kh*kw*cp] -> [N,Ho*stride,Wo*stride,cp] (+ bias); accumulates into `out` if given."""
+    n, ho, wo, _ = dcol.shape
     acc = out is not None
     if out is None:
-        out = torch.empty((n, h, w, cp), dtype=dcol.dtype, device=dcol.device)
-    check(_lib.load().mcgen_col2im(_p(dcol), _p(out), _dt(dcol.dtype), n, h, w, cp, kh, kw, oh, ow, int(acc), _stream()), 'col2im')
+        out = torch.empty((n, ho * stride, wo * stride, cp), dtype=dcol.dtype, device=dcol.device)
+    check(_lib.load().mcgen_col2im(_p(dcol), _p(out), _dt(dcol.dtype), n, ho * stride, wo * stride, cp, kh, kw, oh, ow, stride,
+                                   _f32(bias), bias.numel() if bias is not None else 0, int(acc), _stream()), 'col2im')
     return out
 
 
@@ -746,29 +754,53 @@ def gated_bwd(s: Tensor, scale, shift, mean, rstd, code: Tensor, g: Tensor, dgam
     return ds
 
 
-def affine_code_res(x: Tensor, scale, shift, code: Tensor, res: Optional[Tensor]) -> Tensor:
-    n, h, w, c = x.shape
+def affine_code_res(x: Tensor, scale, shift, code: Optional[Tensor], res: Optional[Tensor], pre_relu: bool = False,
+                    post_relu: bool = False) -> Tensor:
+    """y = post_relu?( pre_relu?(x*scale + shift) * code + res ); x is [N, ..., C], code [N, C]."""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
     y = torch.empty_like(x)
-    check(_lib.load().mcgen_affine_code_res(_p(x), _f32(scale), _f32(shift), _f32(code), _p(res), _p(y), _dt(x.dtype), n, h * w, c,
-                                            _stream()), 'affine_code_res')
+    check(_lib.load().mcgen_affine_code_res(_p(x), _f32(scale), _f32(shift), _f32(code), _p(res), _p(y), _dt(x.dtype), n, hw, c,
+                                            int(pre_relu), int(post_relu), _stream()), 'affine_code_res')
     return y
 
 
-def code_bn_bwd(g: Tensor, code: Tensor, x: Tensor, scale, mean, rstd, dgamma: Tensor, dbeta: Tensor) -> Tensor:
-    """Backward of y = BN(x) * code w.r.t. x (training-mode BatchNorm); fills dgamma / dbeta."""
-    n, h, w, c = x.shape
-    pixels = n * h * w
+def code_bn_bwd(g: Tensor, code: Optional[Tensor], x: Tensor, scale, mean, rstd, dgamma: Tensor, dbeta: Tensor,
+                shift=None, pre_relu: bool = False, y_post: Optional[Tensor] = None, want_gated: bool = False):
+    """Backward of y = post_relu?( pre_relu?(BN(x)) * code + res ) w.r.t. x (training-mode BatchNorm); fills
+    dgamma / dbeta.  Returns dx, or (dx, g * [y_post > 0]) when want_gated (the residual's gradient)."""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    pixels = n * hw
     blocks = max(1, min(256, pixels // 16))
     dz = torch.empty_like(x)
+    gated = torch.empty_like(x) if (want_gated and y_post is not None) else None
     part = torch.empty((blocks, 2, c), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     check(lib.mcgen_code_bn_stats(_p(g), _f32(code), _p(x), _f32(mean), _f32(rstd), _p(dz), _f32(part), blocks, _dt(x.dtype),
-                                  n, h * w, c, _stream()), 'code_bn_stats')
+                                  n, hw, c, _f32(scale), _f32(shift), int(pre_relu), _p(y_post), _p(gated), _stream()),
+          'code_bn_stats')
     sums = _bwd_sums(part, c, dgamma, dbeta)
     dx = torch.empty_like(x)
     check(lib.mcgen_bn_bwd_apply(_p(dz), _p(x), None, _p(dx), _dt(x.dtype), pixels, c, _f32(sums), float(pixels), _f32(scale),
                                  _f32(mean), _f32(rstd), _stream()), 'bn_bwd_apply')
+    if want_gated:
+        return dx, (gated if gated is not None else g)
     return dx
+
+
+def bce_logits(logits: Tensor, target: Tensor, c: int, gscale: float, want_grad: bool):
+    """-> (recon = sigmoid(logits), sum of BCE(recon, target) as a device scalar, dlogits or None)."""
+    pixels = logits.numel() // logits.shape[-1]
+    if target.shape != logits.shape or target.dtype != torch.float32:
+        raise _lib.McgenError('bce_logits: target must be fp32 in the logits\' NHWC shape')
+    blocks = max(1, min(1024, (logits.numel() + 255) // 256))
+    part = torch.empty(blocks, dtype=torch.float32, device=logits.device)
+    recon = torch.empty_like(logits)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(_lib.load().mcgen_bce_logits(_p(logits), _f32(target), _p(recon), _p(dl), _f32(part), blocks, float(gscale),
+                                       _dt(logits.dtype), pixels, c, logits.shape[-1], _stream()), 'bce_logits')
+    return recon, part.double().sum().float(), dl
 
 
 def cross_entropy(logits: Tensor, target: Tensor, c: int, want_grad: bool):

@@ -317,3 +317,30 @@ class PixelCNNTrainer(_FlatTrainer):
         if self._graphs:
             return self._replay(codes, label)
         return self._eager(codes, label)
+
+
+class VAETrainer(_FlatTrainer):
+    """train_vae.py:98-126 on the HIP path (config 1 of the reference runs this model on the CPU; this is the same
+    loop body on the GPU kernels)."""
+
+    def _compute(self, img, label, eps):
+        eng = self.model._engine()
+        self.gflat.zero_()
+        tape = []
+        out = eng.forward(img, label, True, eps, tape, want_grad=True)
+        eng.backward(tape, label)
+        return out['loss']
+
+    def _refresh(self):
+        self.statics[2].normal_()
+
+    def capture(self, img, label, warmup: int = 1):
+        eps = torch.randn(img.shape[0], self.model.latent_size, device=img.device)
+        self._capture((img.clone(), label.clone(), eps), warmup)
+
+    def train_iteration(self, img, label, eps=None):
+        if self._graphs and eps is None:
+            return self._replay(img, label)
+        if eps is None:
+            eps = torch.randn(img.shape[0], self.model.latent_size, device=img.device)
+        return self._eager(img, label, eps)
