@@ -193,6 +193,71 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
         dist.destroy_process_group()
 
 
+def bench_mcvae(a, dev, dtype, world, rank, group):
+    """Secondary workload (BASELINE configs[0] -- which the reference runs on the CPU at batch 32):
+    MCVAE CIFAR-10 train step (train_vae.py:98-126), hidden [64,128,256], latent 128, 10 modes, on the HIP path."""
+    from mcgen_amd import models, ops
+    from mcgen_amd.config import cfg, process_control
+    from mcgen_amd.trainer import VAETrainer
+    cfg.update(data_name='CIFAR10', model_name='mcvae', device=str(dev))
+    cfg['control'] = {'controller_rate': '0.5'}
+    cfg.pop('classes_size', None)
+    process_control()
+    torch.manual_seed(0)
+    model = models.mcvae().to(dev).set_compute_dtype(dtype)
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    img = torch.rand(a.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    lab = torch.randint(0, cfg['classes_size'], (a.batch,), device=dev, generator=g)
+    tr = VAETrainer(model, dist_group=group, world_size=world)
+    graphed = False
+    if not a.no_graph:
+        graphed = try_capture(lambda: tr.capture(img, lab), world, dev)
+        if not graphed:
+            tr._graphs = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.train_iteration(img, lab)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.train_iteration(img, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    value = a.batch * world * a.steps / dt
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        eps = torch.randn(a.batch, model.latent_size, device=dev)
+        roofline = ops.profile_step(lambda: tr._eager(img, lab, eps), PEAK_TFLOPS[a.dtype])
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (train step) MCVAE CIFAR-10 32x32', 'value': value, 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'MCVAE CIFAR-10 32x32 control=0.5, hidden [64,128,256], latent 128, 10 modes, batch {a.batch}/GPU, '
+                                   'forward + backward + clip_grad_norm_(1) + Adam (train_vae.py:98-126)',
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': graphed},
+            'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def bench_mcpixelcnn(a, dev, dtype, world, rank, group):
     """Secondary workload (BASELINE configs[4]): MCPixelCNN CIFAR-10 train step
     (train_pixelcnn.py:108-121) on synthetic VQ-VAE code maps U{0..511} [B,8,8]; 15 layers, hidden 128, 10 modes."""
@@ -264,7 +329,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100', 'mcglow', 'mcglow-cifar10', 'mcpixelcnn'],
+    ap.add_argument('--workload', default='cifar10', choices=['cifar10', 'coil100', 'mcglow', 'mcglow-cifar10', 'mcpixelcnn', 'mcvae'],
                     help='cifar10 = the headline config (BASELINE configs[1]); coil100 = configs[2] as the reference runs it (32x32, 100 modes)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -296,6 +361,8 @@ def main():
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     if a.workload == 'mcpixelcnn':
         return bench_mcpixelcnn(a, dev, dtype, world, rank, group)
+    if a.workload == 'mcvae':
+        return bench_mcvae(a, dev, dtype, world, rank, group)
     if a.workload.startswith('mcglow'):
         return bench_mcglow(a, dev, dtype, world, rank, group)
     data_name = {'cifar10': 'CIFAR10', 'coil100': 'COIL100'}[a.workload]

@@ -130,3 +130,34 @@ def test_mcvae_train_steps_vs_reference():
     t2.capture(img, lab, warmup=1)
     l2 = [float(t2.train_iteration(img, lab)) for _ in range(3)]
     assert all(np.isfinite(l2)) and abs(l2[0] - losses[1]) < 2e-2
+
+
+def test_mcvae_config0_full_size():
+    """BASELINE.json configs[0] (MCVAE CIFAR-10, hidden [64,128,256], latent 128, batch 32) on the HIP path:
+    two optimizer steps against the reference's losses / digests (procedural weights, see golden_util)."""
+    import ast
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    from mcgen_amd.trainer import VAETrainer
+    d = gu.load_npz('mcvae_full_digest.npz')
+    shapes = {k: ast.literal_eval(v) for k, v in zip(d['shape_keys'].tolist(), d['shape_vals'].tolist())}
+    sd = gu.procedural_state_generic(shapes, seed=4321)
+    cfg.update(model_name='mcvae', data_name='CIFAR10', device='cuda', classes_size=10, controller_rate=0.5,
+               data_shape=[3, 32, 32], compute_dtype='float32')
+    cfg['vae'] = {'hidden_size': [64, 128, 256], 'latent_size': 128, 'num_res_block': 2, 'embedding_size': 32}
+    m = models.mcvae()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert sum(p.numel() for p in m.parameters()) == 7628931
+    img, lab = gu.synthetic_batch(32, 10, seed=1)
+    img, lab = img.cuda(), lab.cuda()
+    m.train(True)
+    with torch.no_grad():
+        first = m({'img': img, 'label': lab, 'eps': torch.from_numpy(d['noise/0/0']).cuda()})
+    assert abs(float(first['loss']) - float(d['losses'][0])) < 1e-5
+    np.testing.assert_allclose(gu.checksum(first['mu'].cpu()), d['mu0_digest'], rtol=1e-4, atol=1e-3)
+    assert _rel(first['img'][:4, :, ::4, ::4], d['img0_sample']) < 5e-4
+    m.load_state_dict(sd)                                        # the probe forward moved the BN running statistics
+    tr = VAETrainer(m.cuda())
+    losses = [float(tr.train_iteration(img, lab, torch.from_numpy(d[f'noise/{s}/0']).cuda())) for s in range(2)]
+    assert abs(losses[0] - d['losses'][0]) < 1e-5 and abs(losses[1] - d['losses'][1]) < 2e-3, (losses, d['losses'])
