@@ -321,6 +321,10 @@ int mcgen_bce_logits(const void* logits, const float* target, void* recon, void*
 int mcgen_cross_entropy(const void* logits, const int64_t* target, float* loss_rows, void* dlogits, float gscale,
                         int dtype, int64_t pixels, int C, int Cp, void* stream);
 
+/* nearest-code search of VectorQuantization.forward (modules.py:20-25): idx[p] = argmin_c x[p, c] (first minimum);
+ * x = |e_c|^2 - 2 <f_p, e_c> comes from one fused 1x1 convolution over the codebook */
+int mcgen_argmin_channels(const void* x, int64_t* idx, int dtype, int64_t pixels, int C, int Cp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

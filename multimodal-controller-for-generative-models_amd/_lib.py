@@ -86,6 +86,7 @@ SYMBOLS = {
     'mcgen_clip_grad_norm': (_i, [_vp, _i64, _f, _vp, _vp, _vp]),
     'mcgen_im2col': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'mcgen_col2im': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'mcgen_argmin_channels': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
     'mcgen_bce_logits': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_gated_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_gated_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -314,6 +314,22 @@ void ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
         }
     }
 }
+// ---- arg-min over channels (VectorQuantization's nearest code, modules.py:25): one wave per pixel, first minimum wins ---
+template <typename T>
+__global__ __launch_bounds__(256)
+void argmin_kernel(const T* __restrict__ x, int64_t* __restrict__ idx, size_t pixels, int C, int Cp) {
+    const int lane = threadIdx.x & 63;
+    const size_t p = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= pixels) return;
+    const T* row = x + p * Cp;
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) { const float v = Elem<T>::to_f(row[c]); if (v < best) { best = v; bi = c; } }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) idx[p] = bi;
+}
 }  // namespace
 
 #define DISPATCH_T(dtype, F32, BF16) \
@@ -412,4 +428,12 @@ extern "C" int mcgen_bce_logits(const void* logits, const float* target, void* r
         hipLaunchKernelGGL(bce_kernel<float>, dim3(blocks), dim3(256), 0, STREAM(stream), (const float*)logits, target, (float*)recon, (float*)dlogits, partials, gscale, (size_t)pixels, C, Cp),
         hipLaunchKernelGGL(bce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, STREAM(stream), (const bf16_t*)logits, target, (bf16_t*)recon, (bf16_t*)dlogits, partials, gscale, (size_t)pixels, C, Cp));
     MCGEN_LAUNCH_CHECK("bce_logits"); return 0;
+}
+extern "C" int mcgen_argmin_channels(const void* x, int64_t* idx, int dtype, int64_t pixels, int C, int Cp, void* stream) {
+    MCGEN_CHECK(x && idx && pixels > 0 && C > 0 && Cp >= C, "argmin_channels: bad arguments");
+    const int blocks = (int)((pixels + 3) / 4);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(argmin_kernel<float>, dim3(blocks), dim3(256), 0, STREAM(stream), (const float*)x, idx, (size_t)pixels, C, Cp),
+        hipLaunchKernelGGL(argmin_kernel<bf16_t>, dim3(blocks), dim3(256), 0, STREAM(stream), (const bf16_t*)x, idx, (size_t)pixels, C, Cp));
+    MCGEN_LAUNCH_CHECK("argmin_channels"); return 0;
 }

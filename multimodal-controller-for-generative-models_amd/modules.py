@@ -88,3 +88,32 @@ class Wrapper(nn.Module):
 
     def forward(self, input):
         return [self.module(input[0]), *input[1:]]
+
+
+class VectorQuantization(nn.Module):
+    """modules.py:6-46 -- the EMA codebook of the VQ-VAE.  Buffers as in the reference (``embedding`` [D, K],
+    ``cluster_size`` [K], ``embedding_mean`` [D, K]).  The HIP path implements the inference side (nearest code +
+    gather), which is what runs in front of MCPixelCNN (train_pixelcnn.py:111-113); the EMA update of a VQ-VAE
+    training run is not built."""
+
+    def __init__(self, embedding_size, num_embedding, decay=0.99, eps=1e-5):
+        super().__init__()
+        self.embedding_size, self.num_embedding, self.decay, self.eps = embedding_size, num_embedding, decay, eps
+        embedding = torch.randn(embedding_size, num_embedding)
+        self.register_buffer('embedding', embedding)
+        self.register_buffer('cluster_size', torch.zeros(num_embedding))
+        self.register_buffer('embedding_mean', embedding.clone())
+
+    def embedding_code(self, embedding_ind: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.embedding(embedding_ind, self.embedding.transpose(0, 1))
+
+    def nearest(self, feat_nhwc: torch.Tensor) -> torch.Tensor:
+        """[N, H, W, D] fp32 features -> int64 code indices [N, H, W]: argmin_k |f - e_k|^2 = argmin_k (|e_k|^2 - 2 f.e_k),
+        one fused 1x1 convolution over the codebook + the arg-min kernel."""
+        if self.training:
+            raise NotImplementedError('VectorQuantization: only the inference path (frozen codebook) is built')
+        e = self.embedding                                                   # [D, K]
+        w = (-2.0 * e.t()).contiguous().reshape(self.num_embedding, self.embedding_size, 1, 1)
+        dist, _ = ops.conv_fused([ops.Seg(feat_nhwc, ksize=1)], ops.prep_weight(w, feat_nhwc.dtype), self.num_embedding,
+                                 bias=e.pow(2).sum(0))
+        return ops.argmin_channels(dist, self.num_embedding)

@@ -813,3 +813,11 @@ def cross_entropy(logits: Tensor, target: Tensor, c: int, want_grad: bool):
     check(_lib.load().mcgen_cross_entropy(_p(logits), target.contiguous().data_ptr(), _f32(rows), _p(dl), 1.0 / pixels,
                                           _dt(logits.dtype), pixels, c, logits.shape[-1], _stream()), 'cross_entropy')
     return rows, dl
+
+
+def argmin_channels(x: Tensor, c: int) -> Tensor:
+    """idx[...] = argmin over the first c channels of x[..., Cp] (int64)."""
+    pixels = x.numel() // x.shape[-1]
+    idx = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    check(_lib.load().mcgen_argmin_channels(_p(x), idx.data_ptr(), _dt(x.dtype), pixels, c, x.shape[-1], _stream()), 'argmin_channels')
+    return idx

@@ -7,7 +7,8 @@ import it, and only as the checker.  The product path (the package
 never imports this package and raises if its HIP library is missing.
 
 Modules: ``mcgan_oracle`` (headline model + train step), ``mcvae_oracle``,
-``mcglow_oracle``, ``mcpixelcnn_oracle``.
+``mcglow_oracle``, ``mcpixelcnn_oracle``, ``vqvae_oracle`` (8(f) rank 1: the frozen
+VQ-VAE encode / decode_code in front of MCPixelCNN).
 
 Parity status: PINNED.  The reference publishes no golden vectors (SURVEY.md
 section 4), so the oracle is pinned by vectors produced by importing the

@@ -160,3 +160,38 @@ def test_pixelcnn_train_steps_vs_reference():
     t2.capture(codes, lab, warmup=1)
     l2 = [float(t2.train_iteration(codes, lab)) for _ in range(2)]
     assert abs(l2[0] - losses[1]) < 3e-3 and abs(l2[1] - losses[2]) < 3e-3, (l2, losses)
+
+
+def test_vqvae_encode_decode_code():
+    """The frozen VQ-VAE in front of MCPixelCNN (train_pixelcnn.py:111-113) on the HIP path vs the reference fixture:
+    code map (exact wherever the reference's own arg-min margin is above rounding noise), quantised features,
+    commitment MSE, decode_code; then the pipeline images -> codes -> MCPixelCNN loss runs end to end."""
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    d = gu.load_npz('vqvae_small.npz')
+    cfg.update(model_name='vqvae', device='cuda', data_shape=[3, 32, 32], compute_dtype='float32')
+    cfg['vqvae'] = {'hidden_size': [16, 16], 'num_res_block': 2, 'embedding_size': 8, 'num_embedding': 64, 'vq_commit': 0.25}
+    ae = models.vqvae()
+    ae.load_state_dict(gu.state_from_npz(d))
+    ae = ae.cuda()
+    ae.train(False)
+    img = torch.from_numpy(d['img']).cuda()
+    q, diff, code = ae.encode(img)
+    assert code.dtype == torch.int64 and tuple(code.shape) == (4, 8, 8)
+    decisive = torch.from_numpy(d['dist_margin'] > 1e-4).view(4, 8, 8)
+    assert torch.equal(code.cpu()[decisive], torch.from_numpy(d['code'])[decisive])
+    assert float((code.cpu() == torch.from_numpy(d['code'])).float().mean()) > 0.97
+    same = (code.cpu() == torch.from_numpy(d['code']))[:, None].expand(-1, 8, -1, -1).transpose(2, 3)
+    assert float((q.cpu() - torch.from_numpy(d['encoded']))[same].abs().max()) < 1e-6
+    assert abs(float(diff) - float(d['vq_loss'])) < 1e-3 * float(d['vq_loss']) + 1e-6
+    dec = ae.decode_code(torch.from_numpy(d['code']).cuda())
+    assert _rel(dec, d['decoded']) < 2e-4
+    with pytest.raises(NotImplementedError):
+        ae.train(True).encode(img)
+    # end to end: the code maps feed MCPixelCNN (32 codes in the PixelCNN fixture model: fold the 64 codes onto them)
+    pd = gu.load_npz('mcpixelcnn_small.npz')
+    pm = _model(gu.state_from_npz(pd))
+    pm.train(True)
+    with torch.no_grad():
+        out = pm({'img': code % 32, 'label': torch.zeros(4, dtype=torch.int64, device='cuda')})
+    assert np.isfinite(float(out['loss']))

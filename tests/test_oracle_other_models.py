@@ -123,3 +123,22 @@ def test_mcglow_small():
         _close(rec, d['reconstructed'], rtol=1e-3, atol=1e-3, what='reverse(reconstruct)')
         gz = [torch.from_numpy(d[f'gen_z/{i}']) for i in range(L)]
         _close(G.reverse(sdf, gz, lab, 12, K, L, reconstruct=False), d['generated'], rtol=1e-3, atol=1e-3, what='generate')
+
+
+def test_vqvae_encode_and_decode_code():
+    """The frozen VQ-VAE in front of MCPixelCNN: encoder output, code map, quantised tensor,
+    decode_code against the reference-generated fixture.  Codes must agree wherever the reference's own arg-min
+    margin is above rounding noise."""
+    from oracle import vqvae_oracle as Q
+    d = gu.load_npz('vqvae_small.npz')
+    sd = gu.state_from_npz(d)
+    img = torch.from_numpy(d['img'])
+    with torch.no_grad():
+        x = Q.encoder(sd, img, 2, 2)
+        _close(x, d['enc_out'], what='encoder output')
+        q, mse, code, _ = Q.encode(sd, img, 2, 2)
+        decisive = torch.from_numpy(d['dist_margin'] > 1e-4).view(code.shape)
+        assert torch.equal(code[decisive], torch.from_numpy(d['code'])[decisive])
+        assert float(decisive.float().mean()) > 0.9
+        np.testing.assert_allclose(float(mse), float(d['vq_loss']), rtol=1e-4)
+        _close(Q.decode_code(sd, torch.from_numpy(d['code']), 2, 2), d['decoded'], what='decode_code')

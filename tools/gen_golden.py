@@ -415,6 +415,43 @@ def fx_mcglow_small():
     save('mcglow_small.npz', **arrays)
 
 
+def fx_vqvae_small():
+    """VQ-VAE (the frozen auto-encoder in front of MCPixelCNN, train_pixelcnn.py:111-113), reduced: hidden [16, 16],
+    64 codes of size 8, B=4.  Two training-mode forwards move the BN running statistics and the EMA codebook off
+    their initial values; then the eval-mode encode (encoder output, code map, quantised tensor) and decode_code."""
+    import models
+    cfg['model_name'] = 'vqvae'; cfg['device'] = 'cpu'; cfg['data_shape'] = [3, 32, 32]
+    cfg['vqvae'] = {'hidden_size': [16, 16], 'num_res_block': 2, 'embedding_size': 8, 'num_embedding': 64, 'vq_commit': 0.25}
+    torch.manual_seed(0)
+    model = models.vqvae(); model.train(True)
+    img, _ = gu.synthetic_batch(4, 10, seed=61)
+    with torch.no_grad():
+        for _ in range(2):
+            model({'img': img.clone()})
+    model.train(False)
+    with torch.no_grad():
+        # a random-init encoder maps everything next to one code; spread the codebook over the encoder's outputs
+        # (the codebook is state, i.e. an input of this fixture) so that the arg-min is exercised
+        flat0 = model.encoder(img).transpose(1, -1).contiguous().view(-1, 8)
+        gsel = torch.Generator().manual_seed(62)
+        model.quantizer.embedding.copy_((flat0[::4] + 0.02 * torch.randn(64, 8, generator=gsel)).t())
+    arrays = np_state(model.state_dict(), 'sd/')
+    arrays['img'] = img.numpy()
+    with torch.no_grad():
+        x = model.encoder(img)
+        encoded, vq_loss, code = model.encode(img)
+        arrays['enc_out'] = x.numpy(); arrays['encoded'] = encoded.numpy(); arrays['code'] = code.numpy()
+        arrays['vq_loss'] = np.array(vq_loss.item())
+        arrays['decoded'] = model.decode_code(code).numpy()
+        flat = x.transpose(1, -1).contiguous().view(-1, 8)
+        emb = model.quantizer.embedding
+        dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ emb + emb.pow(2).sum(0, keepdim=True)
+        top2 = dist.topk(2, dim=1, largest=False).values
+        arrays['dist_margin'] = (top2[:, 1] - top2[:, 0]).numpy()          # how decisive each argmin is
+    save('vqvae_small.npz', **arrays)
+
+
+FIXTURES.update(vqvae=fx_vqvae_small)
 FIXTURES.update(mcvae_small=fx_mcvae_small, mcvae_full=fx_mcvae_full, mcpixelcnn=fx_mcpixelcnn_small, mcglow=fx_mcglow_small)
 
 if __name__ == '__main__':
