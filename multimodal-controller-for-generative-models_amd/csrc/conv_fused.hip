@@ -1063,9 +1063,11 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     // barrier ("dma3" form, mode 5) wins on every shape; big tiles only where there are enough pixels to
     // fill 256 CUs
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
+    static const int m128 = getenv("MCGEN_CONV_M128") ? atoi(getenv("MCGEN_CONV_M128")) : 5;
+    static const int m128w = getenv("MCGEN_CONV_M128W") ? atoi(getenv("MCGEN_CONV_M128W")) : 5;
     if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 5};
-    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
-    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, 5};
+    if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, m128};
+    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, m128w};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
     int small_mode = 5;
     if (const char* e = getenv("MCGEN_CONV_SMALL")) small_mode = atoi(e);       // tuning override for the 64x64 fallback

@@ -152,3 +152,41 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize('fixture, model_name, extra', [
+    ('mcglow_small.npz', 'mcglow', {'classes_size': 12, 'data_shape': [1, 32, 32],
+                                    'glow': {'hidden_size': 32, 'K': 2, 'L': 3, 'affine': True, 'conv_lu': True}}),
+    ('mcpixelcnn_small.npz', 'mcpixelcnn', {'classes_size': 10, 'pixelcnn': {'num_layer': 4, 'hidden_size': 16, 'num_embedding': 32}}),
+    ('mcvae_small.npz', 'mcvae', {'classes_size': 10, 'data_shape': [3, 32, 32],
+                                  'vae': {'hidden_size': [8, 16, 32], 'latent_size': 16, 'num_res_block': 2, 'embedding_size': 32}}),
+    ('vqvae_small.npz', 'vqvae', {'data_shape': [3, 32, 32],
+                                  'vqvae': {'hidden_size': [16, 16], 'num_res_block': 2, 'embedding_size': 8, 'num_embedding': 64,
+                                            'vq_commit': 0.25}}),
+])
+def test_other_model_trees_load_reference_state_dicts(fixture, model_name, extra):
+    """MCGlow / MCPixelCNN / MCVAE / VQ-VAE module trees carry exactly the reference's state_dict keys and shapes
+    (the fixtures store state dicts saved by the reference itself), so reference checkpoints load unchanged."""
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    cfg.update(model_name=model_name, device='cpu', controller_rate=0.5)
+    cfg.update(extra)
+    np.random.seed(0)
+    m = getattr(models, model_name)()
+    ref = gu.state_from_npz(gu.load_npz(fixture))
+    own = m.state_dict()
+    assert set(own) == set(ref), set(own) ^ set(ref)
+    for k, v in ref.items():
+        assert tuple(own[k].shape) == tuple(v.shape) and own[k].dtype == v.dtype, k
+    m.load_state_dict(ref)                                   # strict
+    # and the fused paths refuse CPU tensors instead of silently running something else
+    from mcgen_amd._lib import McgenError
+    with pytest.raises((McgenError, RuntimeError, NotImplementedError)):
+        if model_name == 'mcglow':
+            m({'img': torch.zeros(2, 1, 32, 32), 'label': torch.zeros(2, dtype=torch.int64)})
+        elif model_name == 'mcpixelcnn':
+            m({'img': torch.zeros(2, 8, 8, dtype=torch.int64), 'label': torch.zeros(2, dtype=torch.int64)})
+        elif model_name == 'mcvae':
+            m({'img': torch.zeros(2, 3, 32, 32), 'label': torch.zeros(2, dtype=torch.int64)})
+        else:
+            m.train(False).encode(torch.zeros(2, 3, 32, 32))
