@@ -209,7 +209,10 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
 // the tile, so the workgroup is split by role: waves 4-7 (producers) stage tile i+1 into the idle LDS
 // buffers while waves 0-3 (consumers) run the transposing reads + MFMAs of tile i; one barrier per tile.
 // VALU and MFMA issue from different waves of a SIMD overlap, which the single-role kernel cannot do.
-template <typename T, int KS, int LGW>
+// NCH > 1 (1x1 convolutions only): the workgroup owns NCH consecutive 32-channel chunks of the input, staged side by
+// side and walked like taps, so one staged dy tile feeds NCH times as many MFMAs (a 1x1 weight gradient is a plain
+// GEMM whose 64 x 32 output tile would otherwise re-read dy Cin/32 times: measured 132 TFLOP/s at 512 x 512).
+template <typename T, int KS, int LGW, int NCH>
 __global__ __launch_bounds__(2 * WG_NT, 2)
 void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     using E = Elem<T>;
@@ -217,16 +220,19 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     using TR = WgTraits<T>;
     using KF = KFrag<T>;
     constexpr int ESZ = E::BYTES, APITCH = TR::APITCH, DPITCH = TR::DPITCH;
+    static_assert(NCH == 1 || KS == 1, "chunk groups are for 1x1 convolutions");
     constexpr int NTAP = KS * KS;
+    constexpr int NV = NTAP * NCH;                    // accumulator planes: taps, or chunks of a 1x1 group
     constexpr int NCF = WG_BCO / 32;
-    constexpr int NI = (WG_BM * 9 + WG_NT - 1) / WG_NT;
+    constexpr int NI = (KS == 1) ? (WG_BM * 4 + WG_NT - 1) / WG_NT : (WG_BM * 9 + WG_NT - 1) / WG_NT;
     constexpr int W = 1 << LGW, halo = KS >> 1, PC = W + 2 * halo;
     constexpr int KSTEPS = WG_BM / 32;
     constexpr int D_BYTES = WG_BM * DPITCH;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ldsA0 = smem;                       // [2][a_bytes]
-    char* const ldsD0 = smem + 2 * a_bytes;         // [2][D_BYTES]
+    const int a_tile = a_bytes * NCH;               // one tile's windows: NCH chunk regions of a_bytes
+    char* const ldsA0 = smem;                       // [2][a_tile]
+    char* const ldsD0 = smem + 2 * a_tile;          // [2][D_BYTES]
 
     const int tid = threadIdx.x;
     const bool producer = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
@@ -236,7 +242,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const int H = p.H, N = p.N;
     const int co0 = blockIdx.x * WG_BCO;
     const int q = blockIdx.y;
-    const int c0 = q * MCGEN_CK;
+    const int c0 = q * NCH * MCGEN_CK;
     const mcgen_seg_t sg = p.seg;
     const char* dy = reinterpret_cast<const char*>(p.dy);
     const int Hd = p.dy_ups ? (H >> 1) : H, Wd = p.dy_ups ? (W >> 1) : W;
@@ -255,14 +261,15 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
         // of the tile after it are already in flight (prefetch distance of two tiles).
         struct TileRegs {
             int src[NI], nn[NI];
-            typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw;
+            typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw[NCH];
             u32x4 d[DITEMS];
         };
         auto fetch = [&](int i, TileRegs& r) {
             const int tile = blockIdx.z + i * gridDim.z;
             const Geo g = make_geo(WG_BM, tile, H, W);
             stager.bind_into(sg, g, N, H, W, r.src, r.nn);
-            stager.load_ext(sg, c0, r.src, r.raw);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) stager.load_ext(sg, c0 + ch * MCGEN_CK, r.src, r.raw[ch]);
 #pragma unroll
             for (int k = 0; k < DITEMS; ++k) {
                 const int it = rtid + k * WG_NT;
@@ -279,7 +286,9 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
             }
         };
         auto commit = [&](int i, const TileRegs& r) {
-            stager.write_ext(sg, c0, r.src, r.nn, r.raw, ldsA0 + (i & 1) * a_bytes);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                stager.write_ext(sg, c0 + ch * MCGEN_CK, r.src, r.nn, r.raw[ch], ldsA0 + (i & 1) * a_tile + ch * a_bytes);
             char* ldsD = ldsD0 + (i & 1) * D_BYTES;
 #pragma unroll
             for (int k = 0; k < DITEMS; ++k) {
@@ -304,9 +313,9 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     }
 
     // ---- consumers ---------------------------------------------------------------------------------------
-    f32x4 acc[NTAP][NCF];
+    f32x4 acc[NV][NCF];
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
@@ -330,7 +339,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     }
     for (int i = 0; i < cnt; ++i) {
         __syncthreads();
-        const char* ldsA = ldsA0 + (i & 1) * a_bytes;
+        const char* ldsA = ldsA0 + (i & 1) * a_tile;
         const char* ldsD = ldsD0 + (i & 1) * D_BYTES;
         if (do_bias) {
             const int col = rtid & 63, part = rtid >> 6;
@@ -347,8 +356,9 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 #pragma unroll
             for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KF::read(ldsD, oD, cf * 16 * ESZ);
 #pragma unroll
-            for (int j = 0; j < NTAP; ++j) {
-                const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;
+            for (int j = 0; j < NV; ++j) {
+                // 3x3: tap offset inside the halo window (compile-time); 1x1 chunk group: the chunk's region
+                const int tapoff = (NCH == 1) ? ((j / KS) * PC + (j % KS)) * APITCH : j * a_bytes;
                 const typename M::frag afrag = KF::read(ldsA, oA, tapoff);
 #pragma unroll
                 for (int cf = 0; cf < NCF; ++cf) M::run(dfrag[cf], afrag, acc[j][cf]);
@@ -361,15 +371,18 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
     float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int col = wb * 16 + l15;
+        // plane j is tap j of chunk q (3x3) or the single tap of chunk q*NCH + j (1x1 chunk group)
+        const int qc = (NCH == 1) ? q : q * NCH + j, tp = (NCH == 1) ? j : 0;
+        if (qc >= nchunk) continue;
 #pragma unroll
         for (int cf = 0; cf < NCF; ++cf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + (wa * NCF + cf) * 16 + lg * 4 + r;
                 if (co < p.Cout_w)
-                    out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r];
+                    out[(((size_t)qc * NTAP + tp) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r];
             }
     }
     if (do_bias) {
@@ -461,9 +474,28 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
     // the role split only pays when a workgroup walks several tiles (staging of tile i+1 overlaps tile i)
     const bool pc = mode ? (mode[0] == '1') : (m_tiles >= 4 * p->splits);
+    if constexpr (KS == 1) {
+        // 1x1: chunk groups of 4 when there are enough chunks (see wgrad_pc_kernel)
+        constexpr int NCH = 4;
+        const char* g = getenv("MCGEN_WGRAD_GROUP");
+        const int lds4 = 2 * NCH * a_bytes + 2 * WG_BM * TR::DPITCH;     // bf16: 136 KB; fp32 does not fit -> plain path
+        if (pc && wgrad_chunks(p) >= NCH && lds4 <= 160 * 1024 && !(g && g[0] == '0')) {
+            auto kern4 = wgrad_pc_kernel<T, 1, LGW, NCH>;
+            static bool raised4 = false;
+            if (lds4 > 64 * 1024 && !raised4) {
+                raised4 = true;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+                if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
+            }
+            dim3 grid4((p->Cout_w + WG_BCO - 1) / WG_BCO, (wgrad_chunks(p) + NCH - 1) / NCH, p->splits);
+            hipLaunchKernelGGL(kern4, grid4, dim3(2 * WG_NT), lds4, st, *p, a_bytes, m_tiles);
+            MCGEN_LAUNCH_CHECK("wgrad(pc, chunk groups)");
+            return 0;
+        }
+    }
     if (pc) {
         const int lds2 = 2 * a_bytes + 2 * WG_BM * TR::DPITCH;
-        auto kern2 = wgrad_pc_kernel<T, KS, LGW>;
+        auto kern2 = wgrad_pc_kernel<T, KS, LGW, 1>;
         static bool raised2 = false;
         if (lds2 > 64 * 1024 && !raised2) {
             raised2 = true;

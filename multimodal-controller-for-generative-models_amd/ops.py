@@ -262,7 +262,8 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     m_tiles = (n * h * w + 127) // 128
     nchunk = (seg.x.shape[-1] + 31) // 32
     if splits is None:
-        blocks = ((pad16(cout) + 63) // 64) * nchunk
+        # 1x1 gradients with >= 4 chunks run as chunk groups of 4 (wgrad.hip): a quarter of the workgroups per split
+        blocks = ((pad16(cout) + 63) // 64) * ((nchunk + 3) // 4 if (seg.ksize == 1 and nchunk >= 4 and dtype == torch.bfloat16) else nchunk)
         # enough workgroups to fill the chip matters more than the slab traffic (measured: 8x8 layers lose
         # 20 % with 16 instead of 64 splits)
         target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL

@@ -211,6 +211,8 @@ WG_CASES = [
     (7, 4, 24, 16, 3, False, False),
     (2, 32, 8, 32, 3, False, False),
     (16, 1, 128, 64, 1, False, False),
+    (8, 16, 160, 80, 1, False, False),      # 1x1 with 5 chunks: one chunk group of 4 + a ragged one (producer/consumer path)
+    (8, 16, 256, 48, 1, True, False),
 ]
 
 
