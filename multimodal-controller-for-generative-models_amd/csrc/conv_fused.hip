@@ -1053,7 +1053,16 @@ struct TilePick { int BM, BN, pipe; };
 // MCGEN_CONV_CFG="BM,BN,PIPE" overrides the choice for bf16 launches with Cout_w > 16 (tuning runs).
 static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     const long M = (long)p->N * p->H * p->W;
-    if (p->Cout_w <= 16) return {128, 16, dtype == MCGEN_BF16 ? 5 : 0};
+    if (p->Cout_w <= 16) {
+        // skinny-N convolutions (Glow's ZeroConv2d and the input gradients of the coupling nets, image heads) are a
+        // serial chain over K: with few pixels, 64-pixel tiles double the workgroups that overlap each other's
+        // staging latency (measured: MCGlow step -5 %); large maps keep 128 (MCGAN's 32x32 head)
+        int bm16 = (M <= 32768) ? 64 : 128;
+        if (const char* e = getenv("MCGEN_CONV_BM16")) bm16 = atoi(e);
+        const int HW16 = p->H * p->W;
+        if (dtype == MCGEN_BF16 && bm16 != 128 && ((bm16 >= 2 * p->W) || HW16 <= bm16)) return {bm16, 16, 5};
+        return {128, 16, dtype == MCGEN_BF16 ? 5 : 0};
+    }
     if (dtype == MCGEN_F32) return (M <= 16384 || p->Cout_w <= 64) ? TilePick{64, 64, 0} : TilePick{128, 128, 0};
     int env_bm = 0, env_bn = 0, env_pipe = 0;
     if (const char* e = getenv("MCGEN_CONV_CFG")) {
@@ -1071,7 +1080,10 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, m128};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, m128w};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
-    int small_mode = 11;                      // 64x64 tile on 8 waves (4x2): measured 16 % faster than 4 waves on 8x8 maps
+    // The 8-wave forms of this tile (modes 10 / 11) are ~15 % faster on 8x8 maps and bit-identical in their outputs,
+    // but their BatchNorm partial sums round differently and the bf16 full-size digest run then drifts 0.1 in the
+    // second-iteration G loss (tools/digest_probe.py) -- not understood yet, so the 4-wave form stays the default.
+    int small_mode = 5;
     if (const char* e = getenv("MCGEN_CONV_SMALL")) small_mode = atoi(e);       // tuning override for the 64x64 fallback
     return {64, 64, small_mode};
 }
@@ -1234,6 +1246,8 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 16, 5, launch_dma<T, 128, 16, 4, 1, 3>},
         {32, 64, 5, launch_dma<T, 32, 64, 1, 2, 3>},   {32, 128, 5, launch_dma<T, 32, 128, 1, 4, 3>},
         {32, 64, 8, launch_dma<T, 32, 64, 2, 2, 3>},   {64, 32, 5, launch_dma<T, 64, 32, 2, 1, 3>},
+        {64, 16, 5, launch_dma<T, 64, 16, 4, 1, 3>},   {32, 16, 5, launch_dma<T, 32, 16, 2, 1, 3>},
+        {64, 16, 9, launch_dma<T, 64, 16, 2, 1, 3>},   {256, 16, 5, launch_dma<T, 256, 16, 8, 1, 3>},
         {64, 64, 9, launch_dma<T, 64, 64, 4, 4, 3>},   {64, 64, 10, launch_dma<T, 64, 64, 2, 4, 3>},
         {64, 64, 11, launch_dma<T, 64, 64, 4, 2, 3>},  {64, 128, 9, launch_dma<T, 64, 128, 4, 4, 3>},
         {64, 128, 10, launch_dma<T, 64, 128, 2, 4, 3>},

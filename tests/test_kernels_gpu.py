@@ -213,6 +213,7 @@ WG_CASES = [
     (16, 1, 128, 64, 1, False, False),
     (8, 16, 160, 80, 1, False, False),      # 1x1 with 5 chunks: one chunk group of 4 + a ragged one (producer/consumer path)
     (8, 16, 256, 48, 1, True, False),
+    (8, 16, 128, 128, 1, False, True),      # D shortcut: 1x1 chunk group with the pooled (dy_ups) gradient
 ]
 
 
