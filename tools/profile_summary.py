@@ -27,8 +27,10 @@ def bench_name(k: str):
     m = re.search(r'wgrad_(?:pc_)?kernelI(DF16b|f)Li(\d+)E', k)
     if m:
         return f'wgrad<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)}>'
-    if 'wgrad_pc_kernel<' in k or 'wgrad_kernel<' in k:      # mis-demangled symbols: the 1x1 instantiations
-        return 'wgrad<bf16,1>'
+    if 'wgrad_pc_kernel<' in k or 'wgrad_kernel<' in k:
+        # rocprofv3 mis-demangles some __bf16 instantiations; observed forms (checked against VGPR counts: 3x3 kernels
+        # hold 72 accumulators): '<bool _Accum, int, ELi, ...>' = a 3x3 instantiation, '<bool _Accum, int, E, LGW[, NCH]>' = 1x1
+        return 'wgrad<bf16,3>' if 'ELi' in k else 'wgrad<bf16,1>'
     return None
 
 
