@@ -875,6 +875,168 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "cp" form (chunk-pipelined), for the tiles of small maps ---------------------------------------------------
+// On 8x8 / 16x16 maps (and for skinny-N convolutions) a workgroup's MFMA work per 32-channel chunk is a fraction of a
+// microsecond, so the forms above are a serial chain of exposed round trips: stage the window, wait, DMA a tap group,
+// wait, ...  Here one STEP = all tap units of a chunk (the 9 taps of a 3x3 chunk, or up to 8 chunks of a 1x1 segment):
+// while step k runs its MFMAs, step k+1's weight tiles are already streaming into the other half of an LDS ring by
+// LDS-DMA and its input window is in flight to registers.  Per step: one s_waitcnt vmcnt(0), the prologue + LDS
+// store of the window from registers, two barriers, no wait inside the tap loop.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_cp_kernel(const mcgen_conv_t p, const int a_bytes, const int subw) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+    constexpr int NW = WM * WN;
+    constexpr int KB = (C::BBYTES + 1023) / 1024;            // 1 KB DMA pieces per weight tile
+    constexpr int UMAX = 9, NQ1 = 8;                          // tap units per step; chunks per step of a 1x1 segment
+    constexpr int HALF = UMAX * C::BBYTES;
+    constexpr int NI3 = C::NI, NI1 = (BM * 4 + NT - 1) / NT;
+    constexpr int DPW = (UMAX * KB + NW - 1) / NW;            // DMA instructions per wave per step (upper bound)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    // weight tiles blk0 .. blk0+U-1 -> ring half `half`; (unit, piece) pairs are dealt round-robin to the waves
+    auto dma_issue = [&](int blk0, int U, int half) {
+        char* base = ldsB0 + half * HALF;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int up = wave + i * NW;
+            if (up < U * KB) {
+                const int u = up / KB, kb = up % KB;
+                const int row = kb * RPP + lane / UPR, pu = lane % UPR;
+                const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+                const int lgrp = grp ^ (3 * ((row >> 3) & 1));
+                const bool ok = (row < BN) && (cout0 + row < p.Cout_w);
+                const char* src = wimg + (size_t)(blk0 + u) * wblock_bytes +
+                                  (ok ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : pu * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + u * C::BBYTES + kb * 1024), 16, 0, 0);
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
+
+    int half = 0, blk_seg = 0;                                 // ring half of the step being consumed; first tile of the segment
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        auto mma_unit = [&](const char* ldsAu, const char* ldsBu) {
+            typename M::frag af[FM], wf[FN];
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) af[fm] = *reinterpret_cast<const typename M::frag*>(ldsAu + a_base[fm]);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsBu + w_row_off[fn]);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+        };
+        if (ntap == 9) {
+            PatchStager<T, NT, NI3, APITCH> st;
+            st.setup(sg, g, N, H, W, tid);
+            typename PatchStager<T, NT, NI3, APITCH>::raw_t raw;
+            dma_issue(blk_seg, 9, half);
+            st.load(sg, 0, raw);
+#pragma unroll 1
+            for (int q = 0; q < nchunk; ++q) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // the previous step's readers are done with the window
+                st.write(sg, q * MCGEN_CK, raw, ldsA);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // window + every wave's weight pieces are visible
+                if (q + 1 < nchunk) {
+                    dma_issue(blk_seg + (q + 1) * 9, 9, half ^ 1);
+                    st.load(sg, (q + 1) * MCGEN_CK, raw);
+                }
+                const char* ldsB = ldsB0 + half * HALF;
+#pragma unroll
+                for (int u = 0; u < 9; ++u)
+                    mma_unit(ldsA + ((u / 3) * PC + (u % 3)) * APITCH, ldsB + u * C::BBYTES);
+                half ^= 1;
+            }
+        } else {
+            PatchStager<T, NT, NI1, APITCH> st;
+            st.setup(sg, g, N, H, W, tid);
+            typename PatchStager<T, NT, NI1, APITCH>::raw_t raw[NQ1];
+            auto load_step = [&](int q0, int nq) {
+#pragma unroll
+                for (int j = 0; j < NQ1; ++j)
+                    if (j < nq) st.load(sg, (q0 + j) * MCGEN_CK, raw[j]);
+            };
+            int nq = nchunk < NQ1 ? nchunk : NQ1;
+            dma_issue(blk_seg, nq, half);
+            load_step(0, nq);
+#pragma unroll 1
+            for (int q0 = 0; q0 < nchunk; q0 += NQ1) {
+                nq = (nchunk - q0) < NQ1 ? (nchunk - q0) : NQ1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int j = 0; j < NQ1; ++j)
+                    if (j < nq) st.write(sg, (q0 + j) * MCGEN_CK, raw[j], ldsA + j * subw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int qn = q0 + NQ1;
+                if (qn < nchunk) {
+                    const int nn = (nchunk - qn) < NQ1 ? (nchunk - qn) : NQ1;
+                    dma_issue(blk_seg + qn, nn, half ^ 1);
+                    load_step(qn, nn);
+                }
+                const char* ldsB = ldsB0 + half * HALF;
+#pragma unroll
+                for (int u = 0; u < NQ1; ++u)
+                    if (u < nq) mma_unit(ldsA + u * subw, ldsB + u * C::BBYTES);
+                half ^= 1;
+            }
+        }
+        blk_seg += nchunk * ntap;
+        __builtin_amdgcn_s_barrier();                          // segment change: the window is re-staged with another geometry
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- "res" form: whole input window resident --------------------------------------------------------------
 // For layers with few pixels (8x8, 16x16 maps) a workgroup's MFMA time is a few microseconds, so every
 // exposed global round trip shows.  Here ALL channels of the tile's input window are staged once (all
@@ -1060,8 +1222,11 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
         int bm16 = (M <= 32768) ? 64 : 128;
         if (const char* e = getenv("MCGEN_CONV_BM16")) bm16 = atoi(e);
         const int HW16 = p->H * p->W;
-        if (dtype == MCGEN_BF16 && bm16 != 128 && ((bm16 >= 2 * p->W) || HW16 <= bm16)) return {bm16, 16, 5};
-        return {128, 16, dtype == MCGEN_BF16 ? 5 : 0};
+        // the chunk-pipelined form (12) wins on these K-deep, latency-bound launches (-15..20 %); elsewhere the extra LDS of
+        // its two-step weight ring costs more occupancy than the prefetch gains (measured), so dma3 stays
+        static const int mode16 = getenv("MCGEN_CONV_MODE16") ? atoi(getenv("MCGEN_CONV_MODE16")) : 12;
+        if (dtype == MCGEN_BF16 && bm16 != 128 && ((bm16 >= 2 * p->W) || HW16 <= bm16)) return {bm16, 16, mode16};
+        return {128, 16, dtype == MCGEN_BF16 ? mode16 : 0};
     }
     if (dtype == MCGEN_F32) return (M <= 16384 || p->Cout_w <= 64) ? TilePick{64, 64, 0} : TilePick{128, 128, 0};
     int env_bm = 0, env_bn = 0, env_pipe = 0;
@@ -1177,6 +1342,40 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cp(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)((Mtot + BM - 1) / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP1 = mcgen_patch_pixels(BM, p->H, p->W, 1);
+    const int subw = round_up(PP1 * C::APITCH, 32);                 // one chunk's window of a 1x1 segment
+    int a_bytes = 0;
+    for (int s = 0; s < p->nseg; ++s) {
+        const int ks = p->seg[s].ksize;
+        const int PP = mcgen_patch_pixels(BM, p->H, p->W, ks);
+        MCGEN_CHECK(PP * 4 <= (ks == 3 ? C::NI : (BM * 4 + C::NT - 1) / C::NT) * C::NT, "conv_fused(cp): patch of %d pixels exceeds the staging plan", PP);
+        const int need = (ks == 3) ? PP * C::APITCH : 8 * subw;
+        if (need > a_bytes) a_bytes = need;
+    }
+    a_bytes = round_up(a_bytes, 1024);
+    int lds = a_bytes + 2 * 9 * C::BBYTES;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(cp): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_cp_kernel<T, BM, BN, WM, WN>;
+    static int raised = 0;
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+        raised = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes, subw);
+    MCGEN_LAUNCH_CHECK("conv_fused(cp)");
+    return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NQ, int RB>
 static int launch_res(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
@@ -1246,6 +1445,9 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 16, 5, launch_dma<T, 128, 16, 4, 1, 3>},
         {32, 64, 5, launch_dma<T, 32, 64, 1, 2, 3>},   {32, 128, 5, launch_dma<T, 32, 128, 1, 4, 3>},
         {32, 64, 8, launch_dma<T, 32, 64, 2, 2, 3>},   {64, 32, 5, launch_dma<T, 64, 32, 2, 1, 3>},
+        {64, 64, 12, launch_cp<T, 64, 64, 2, 2>},
+        {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},      {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
+        {32, 64, 12, launch_cp<T, 32, 64, 1, 2>},
         {64, 16, 5, launch_dma<T, 64, 16, 4, 1, 3>},   {32, 16, 5, launch_dma<T, 32, 16, 2, 1, 3>},
         {64, 16, 9, launch_dma<T, 64, 16, 2, 1, 3>},   {256, 16, 5, launch_dma<T, 256, 16, 8, 1, 3>},
         {64, 64, 9, launch_dma<T, 64, 64, 4, 4, 3>},   {64, 64, 10, launch_dma<T, 64, 64, 2, 4, 3>},

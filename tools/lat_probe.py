@@ -36,6 +36,9 @@ def probe(h, cin, cout, ks=3, code=True, res=True, reps=40):
     print(f'h={h:2d} cin={cin:4d} cout={cout:4d} k={ks} code={int(code)} res={int(res)}: {us:7.2f} us  {fl / us * 1e-6:7.1f} TFLOP/s', flush=True)
 
 
+if os.environ.get('PROBE_1X1'):
+    probe(8, 512, 512, ks=1, res=False); probe(4, 512, 512, ks=1, res=False); probe(8, 128, 128, ks=1); probe(8, 128, 512, ks=1); probe(8, 512, 128, ks=1)
+    sys.exit(0)
 if os.environ.get('PROBE_SKINNY'):
     probe(16, 512, 8); probe(8, 512, 16); probe(4, 512, 16); probe(16, 512, 16, code=True, res=False)
     sys.exit(0)
