@@ -195,3 +195,21 @@ def test_vqvae_encode_decode_code():
     with torch.no_grad():
         out = pm({'img': code % 32, 'label': torch.zeros(4, dtype=torch.int64, device='cuda')})
     assert np.isfinite(float(out['loss']))
+
+
+def test_pixelcnn_bf16_tracks_fp32():
+    """bf16 compute (the throughput build) on the fixture: loss within 2e-2 of the fp32 reference, logits within 5 % of
+    their range, three training steps follow the reference losses."""
+    from mcgen_amd.trainer import PixelCNNTrainer
+    d = gu.load_npz('mcpixelcnn_small.npz')
+    codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
+    m = _model(gu.state_from_npz(d)).set_compute_dtype(torch.bfloat16)
+    m.train(True)
+    with torch.no_grad():
+        out = m({'img': codes, 'label': lab})
+    assert abs(float(out['loss']) - float(d['losses'][0])) < 2e-2
+    assert _rel(out['logits'], d['logits0']) < 5e-2
+    m = _model(gu.state_from_npz(d)).set_compute_dtype(torch.bfloat16)
+    tr = PixelCNNTrainer(m)
+    losses = [float(tr.train_iteration(codes, lab)) for _ in range(3)]
+    assert max(abs(a - b) for a, b in zip(losses, d['losses'])) < 5e-2, (losses, d['losses'])

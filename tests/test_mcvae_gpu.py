@@ -161,3 +161,21 @@ def test_mcvae_config0_full_size():
     tr = VAETrainer(m.cuda())
     losses = [float(tr.train_iteration(img, lab, torch.from_numpy(d[f'noise/{s}/0']).cuda())) for s in range(2)]
     assert abs(losses[0] - d['losses'][0]) < 1e-5 and abs(losses[1] - d['losses'][1]) < 2e-3, (losses, d['losses'])
+
+
+def test_mcvae_bf16_tracks_fp32():
+    """bf16 compute (the throughput build) on the fixture: loss within 1e-2 of the fp32 reference, reconstruction within
+    3 % of its range, three training steps follow the reference losses."""
+    from mcgen_amd.trainer import VAETrainer
+    d = gu.load_npz('mcvae_small.npz')
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    m = _model(gu.state_from_npz(d)).set_compute_dtype(torch.bfloat16)
+    m.train(True)
+    with torch.no_grad():
+        out = m({'img': img, 'label': lab, 'eps': torch.from_numpy(d['noise/0/0']).cuda()})
+    assert abs(float(out['loss']) - float(d['losses'][0])) < 1e-2
+    assert _rel(out['img'], d['img0']) < 3e-2
+    m = _model(gu.state_from_npz(d)).set_compute_dtype(torch.bfloat16)
+    tr = VAETrainer(m)
+    losses = [float(tr.train_iteration(img, lab, torch.from_numpy(d[f'noise/{s}/0']).cuda())) for s in range(3)]
+    assert max(abs(a - b) for a, b in zip(losses, d['losses'])) < 2e-2, (losses, d['losses'])
