@@ -188,7 +188,7 @@ int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int pitch, float
  * if do_iter: v = normalize(W^T u), u = normalize(W v) (eps 1e-12, in place); sigma[l] = u.(W v). */
 typedef struct { int64_t w_off, u_off, v_off; int32_t rows, cols; } mcgen_sn_layer_t;
 int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
-                        int do_iter, float* sigma, float* workspace /* nlayers * (8*max_cols + max_rows) floats */,
+                        int do_iter, float* sigma, float* workspace /* nlayers * (32*max_cols + max_rows) floats */,
                         int max_rows, int max_cols, void* stream);
 /* gradient through W/sigma:  dst (+)= (g - <g, W/sigma> u v^T) / sigma per layer, where g (at g_src + w_off)
  * is the gradient w.r.t. the normalised weight; u, v, sigma are the values the FORWARD used (the caller

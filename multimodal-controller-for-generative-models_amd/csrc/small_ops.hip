@@ -114,7 +114,13 @@ __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_
         float s = 0.f;
         // zero indicator entries contribute exactly nothing (finite codebook): skip their codebook reads.
         // With one-hot labels and 1623 modes (Omniglot) this turns a [N,M]x[M,C] product into a row gather.
-        for (int m = 0; m < d.M; ++m) { const float w = ind[(size_t)n * d.M + m]; if (w != 0.f) s = fmaf(w, d.codebook[(size_t)m * d.C + c], s); }
+        if (d.M <= 32) {
+            // few modes: unconditional loads pipeline; the data-dependent skip below serialises them
+#pragma unroll 4
+            for (int m = 0; m < d.M; ++m) s = fmaf(ind[(size_t)n * d.M + m], d.codebook[(size_t)m * d.C + c], s);
+        } else {
+            for (int m = 0; m < d.M; ++m) { const float w = ind[(size_t)n * d.M + m]; if (w != 0.f) s = fmaf(w, d.codebook[(size_t)m * d.C + c], s); }
+        }
         code[i] = s;
     }
 }
@@ -260,7 +266,7 @@ __device__ float block_sum(float v, float* red) {
 //   k2  v = normalize(sum_s partial)                                             (grid: layers)
 //   k3  t[i] = W[i][:] . v                                                       (grid: layers x RS, wave per row)
 //   k4  u = t / max(|t|, eps), sigma = u . t     (no iteration: sigma = u_old . t) (grid: layers)
-constexpr int SN_RS = 8;
+constexpr int SN_RS = 32;
 __global__ void sn_k1_wtu(const float* __restrict__ wb, const float* __restrict__ uvb,
                           const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws, int ws_stride) {
     const mcgen_sn_layer_t L = layers[blockIdx.x];
@@ -533,7 +539,7 @@ extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, con
 }
 extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream) {
     MCGEN_CHECK(indicator && descs_dev && code_base && n > 0 && N > 0, "mc_code_batch: bad arguments");
-    hipLaunchKernelGGL(mc_code_batch_kernel, dim3(8, n), dim3(256), 0, STREAM(stream), indicator, descs_dev, code_base, N);
+    hipLaunchKernelGGL(mc_code_batch_kernel, dim3(32, n), dim3(256), 0, STREAM(stream), indicator, descs_dev, code_base, N);
     MCGEN_LAUNCH_CHECK("mc_code_batch"); return 0;
 }
 
@@ -599,7 +605,7 @@ extern "C" int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int p
 extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                    int do_iter, float* sigma, float* workspace, int max_rows, int max_cols, void* stream) {
     MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0 && max_rows > 0 && max_cols > 0,
-                "sn_power_iter: bad arguments (workspace: nlayers * (8 * max_cols + max_rows) floats)");
+                "sn_power_iter: bad arguments (workspace: nlayers * (32 * max_cols + max_rows) floats)");
     MCGEN_CHECK(max_cols * 4 <= 60 * 1024, "sn_power_iter: layers wider than 15360 columns are not supported");
     const int t_off = SN_RS * max_cols, ws_stride = t_off + max_rows;
     if (do_iter) {

@@ -460,7 +460,7 @@ def sn_layers_tensor(layers, device) -> Tensor:
 
 def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, do_iter: bool, sigma: Tensor,
                   max_rows: int, max_cols: int):
-    ws = torch.empty(nlayers * (8 * max_cols + max_rows), dtype=torch.float32, device=w_base.device)
+    ws = torch.empty(nlayers * (32 * max_cols + max_rows), dtype=torch.float32, device=w_base.device)
     check(_lib.load().mcgen_sn_power_iter(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, int(do_iter),
                                           _f32(sigma), _f32(ws), max_rows, max_cols, _stream()), 'sn_power_iter')
 
