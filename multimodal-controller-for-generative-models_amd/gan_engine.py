@@ -85,6 +85,15 @@ class _BN:
     __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
 
+_pending_counters: List[Tensor] = []
+
+
+def _flush_counters():
+    if _pending_counters:
+        torch._foreach_add_(_pending_counters, 1)
+        _pending_counters.clear()
+
+
 def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: bool, fold: int = 1) -> _BN:
     s = _BN()
     s.count = count
@@ -93,7 +102,7 @@ def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: 
         s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
                                                            bn.running_var, mom, bn.eps, fold=fold)
         _bump(bn.running_mean); _bump(bn.running_var)
-        bn.num_batches_tracked.add_(1)
+        _pending_counters.append(bn.num_batches_tracked)      # bumped together at the end of the forward (one launch)
     else:
         s.scale, s.shift = ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         s.mean, s.rstd = None, None
@@ -226,6 +235,7 @@ class GeneratorEngine:
         seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
         out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
+        _flush_counters()
         return ops.to_nchw(out, head_conv.out_channels), ctx
 
     # ---- backward ----------------------------------------------------------------------------------
