@@ -408,10 +408,8 @@ class DiscriminatorEngine:
             self._build_preps()
 
     # ---- forward ---------------------------------------------------------------------------------
-    def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
-        dt = self.dtype
+    def _power_iter(self, train: bool):
         fp, fuv = self._ensure_flat()
-        n = x_nchw.shape[0]
         nsn = len(self.sn)
         sigma = torch.empty(nsn, dtype=torch.float32, device=fp.device)
         ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sigma,
@@ -419,20 +417,79 @@ class DiscriminatorEngine:
         if train:
             for s in self.sn:
                 _bump(s.m.weight_u); _bump(s.m.weight_v)
-        ctx = {'n': n, 'sigma': sigma, 'uv': fuv.clone(), 'blocks': []}   # torch's hook clones u, v too
+        return sigma, fuv.clone()                              # torch's hook clones u, v too
+
+    def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
+        sigma, uv = self._power_iter(train)
+        codes = self._codes.run(indicator)
+        ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None}
+        return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
+
+    def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor):
+        """D(real) and D(fake) of one discriminator update (train_gan.py:144-150) as ONE pass over the 2N batch.
+        The two forwards of the reference differ only in the spectral-norm state (each runs its own power iteration,
+        which depends on the weights alone): conv(x; W / sigma_2) = (sigma_1 / sigma_2) * conv(x; W / sigma_1), so the
+        fake half runs on the first pass's weight images with sigma_1 / sigma_2 folded into its per-sample
+        MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input)."""
+        n = real_nchw.shape[0]
+        sigma1, uv1 = self._power_iter(True)
+        sigma2, uv2 = self._power_iter(True)
+        ratio = sigma1 / sigma2
+        ind2 = torch.cat([indicator, indicator])
+        codes = self._codes.run(ind2)                          # [2N, C] each; both halves equal
+        uses = self._code_uses()
+        scaled = {}
+        by_width: Dict[int, list] = {}
+        for u in uses:
+            w = codes[u[0]].shape[1] if u[0] is not None else 8
+            by_width.setdefault(w, []).append(u)
+        dev = real_nchw.device
+        for w, us in by_width.items():
+            base = torch.stack([codes[mc_i] if mc_i is not None else torch.ones(2 * n, w, device=dev) for mc_i, _ in us])
+            idx = torch.tensor([sn for _, sn in us], device=dev) if (w, len(us)) not in self._use_idx else self._use_idx[(w, len(us))]
+            self._use_idx[(w, len(us))] = idx
+            r = ratio.index_select(0, idx)                                            # [U]
+            scale = torch.cat([torch.ones(len(us), n, device=dev), r[:, None].expand(-1, n)], 1).unsqueeze(-1)
+            out = base * scale
+            for k, u in enumerate(us):
+                scaled[u] = out[k]
+        x = torch.cat([real_nchw.detach(), fake_nchw.detach()])
+        ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
+               'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
+        return self._forward_body(x, ctx, lambda mc_i, sn_idx: scaled[(mc_i, sn_idx)])
+
+    def _code_uses(self):
+        """(MC index or None for the image, SN layer index) of every convolution input of the network."""
+        if getattr(self, '_uses', None) is None:
+            b0 = self.res[0]
+            c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
+            uses = [(None, c1m.idx), (None, scm.idx), (0, c2m.idx)]
+            for i, b in enumerate(self.res[1:], start=1):
+                c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
+                uses += [(2 * i - 1, c1m.idx), (2 * i, c2m.idx)]
+                if len(b.shortcut) > 0:
+                    uses.append((2 * i - 1, self.sn_of[b.shortcut[1].module].idx))
+            uses.append((len(self._codes.mcs) - 1, self.sn_of[self.tail_lin].idx))
+            self._uses = uses
+            self._use_idx = {}
+        return self._uses
+
+    def _forward_body(self, x_nchw: Tensor, ctx, code_of):
+        dt = self.dtype
+        n = x_nchw.shape[0]
+        sigma = ctx['sigma']
         self._ensure_preps()
         self._prep_fwd.run(sigma)                 # every W / sigma image of this pass in one launch
-        codes = self._codes.run(indicator)
         I = self.img
         img = ops.to_nhwc(x_nchw.detach().contiguous(), dt)
         ctx['img'] = img
         # --- FirstDisResBlock (mcgan.py:72-93)
         b0 = self.res[0]
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
-        code = codes[0]
         co = c1m.cout
-        c1, _ = ops.conv_fused([Seg(img)], I['0.c1'], co, bias=c1m.m.bias)
-        sc, _ = ops.conv_fused([Seg(img, ksize=1)], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
+        c1, _ = ops.conv_fused([Seg(img, code=code_of(None, c1m.idx))], I['0.c1'], co, bias=c1m.m.bias)
+        sc, _ = ops.conv_fused([Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
+        code = code_of(0, c2m.idx)
         y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], I['0.c2'], co, bias=c2m.m.bias,
                               pool=True, alpha=0.25, res=sc)
         ctx['blocks'].append({'c1': c1, 'code': code})
@@ -442,21 +499,23 @@ class DiscriminatorEngine:
             c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
             has_sc = len(b.shortcut) > 0
             pooled = len(b.conv) == 7
-            code1, code2 = codes[2 * i - 1], codes[2 * i]
+            code1, code2 = code_of(2 * i - 1, c1m.idx), code_of(2 * i, c2m.idx)
+            code1s = None
             c1, _ = ops.conv_fused([Seg(x, code=code1, relu=True)], I[f'{i}.c1'], c1m.cout, bias=c1m.m.bias)
             if has_sc:
                 scm = self.sn_of[b.shortcut[1].module]
+                code1s = code_of(2 * i - 1, scm.idx)
                 bias = c2m.m.bias.detach() + scm.m.bias.detach()
-                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1)], I[f'{i}.c2s'], c2m.cout,
+                y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1s)], I[f'{i}.c2s'], c2m.cout,
                                       bias=bias, pool=pooled, alpha=0.25 if pooled else 1.0)
             else:
                 y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True)], I[f'{i}.c2'], c2m.cout,
                                       bias=c2m.m.bias, res=x)
-            ctx['blocks'].append({'x': x, 'c1': c1, 'code1': code1, 'code2': code2, 'pooled': pooled, 'has_sc': has_sc})
+            ctx['blocks'].append({'x': x, 'c1': c1, 'code1': code1, 'code1s': code1s, 'code2': code2, 'pooled': pooled, 'has_sc': has_sc})
             x = y
         # --- tail: ReLU -> MC -> global sum pool -> SN linear (mcgan.py:158-165)
         tl = self.sn_of[self.tail_lin]
-        codet = codes[-1]
+        codet = code_of(len(self._codes.mcs) - 1, tl.idx)
         logit, pooled_feat = ops.dtail_fwd(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
                                            sigma[tl.idx:tl.idx + 1])
         ctx.update(xt=x, codet=codet, pooled=pooled_feat)
@@ -466,14 +525,28 @@ class DiscriminatorEngine:
     def backward(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
         """dlogit [N] fp32.  Parameter gradients (w.r.t. weight_orig and the biases) are written or
         added into `gflat` (flat, laid out like ``flat_p``; None skips them, e.g. in the generator
-        step); returns d(input image) as NCHW fp32, or None."""
+        step); returns d(input image) as NCHW fp32, or None.
+        For a `forward_pair` context dlogit is [2N] (real half, fake half): input gradients run once over the 2N
+        batch (sigma_1 / sigma_2 rides in the output codes), weight gradients are taken per half, because each half
+        owns its spectral-norm state (u, v, sigma) in the fix-up from d/d(W/sigma) to d/d(weight_orig)."""
         dt = self.dtype
         fp, _ = self._ensure_flat()
         sigma, uv = ctx['sigma'], ctx['uv']
+        pair = ctx['pair']
         want_w = gflat is not None
-        # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first
-        gtmp = torch.empty_like(fp) if want_w else None
-        T = (lambda p: self.flat_p.view_of(gtmp, p)) if want_w else None       # noqa: E731
+        codes = ctx['codes']                       # unscaled codes of every MC (weight gradients see the true conv input)
+        nmc = len(self._codes.mcs)
+        # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first: one buffer per pass
+        if pair is None:
+            passes = [(slice(None), torch.empty_like(fp) if want_w else None)]
+        else:
+            passes = [(slice(0, pair['n']), torch.empty_like(fp)), (slice(pair['n'], 2 * pair['n']), torch.empty_like(fp))]
+
+        def wgrad_all(seg_fn, dy, cout, cin, param, bias=None, bias2=None, **kw):
+            for sl, gtmp in passes:
+                T = lambda p: self.flat_p.view_of(gtmp, p)                         # noqa: E731
+                ops.wgrad(seg_fn(sl), dy[sl], cout, cin, T(param), bias_grad=T(bias) if bias is not None else None,
+                          bias_grad2=T(bias2) if bias2 is not None else None, **kw)
 
         self._ensure_preps()
         self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
@@ -482,24 +555,40 @@ class DiscriminatorEngine:
         sg_t = sigma[tl.idx:tl.idx + 1]
         wl = self.tail_lin.weight_orig
         with ops.deferred_reduces():          # all split-K reductions of this pass: one launch, before the SN fix-up
-            dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
-                               T(wl).view(-1) if want_w else None, T(self.tail_lin.bias) if want_w else None)
+            if pair is None:
+                gt = passes[0][1]
+                dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
+                                   self.flat_p.view_of(gt, wl).view(-1) if want_w else None,
+                                   self.flat_p.view_of(gt, self.tail_lin.bias) if want_w else None)
+            else:
+                dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'], None, None)
+                # tail weight / bias gradients per half; the fake half's pooled features carry sigma_1 / sigma_2
+                gp = dlogit.view(-1, 1) * ctx['pooled']
+                n1 = pair['n']
+                r_t = pair['ratio'][tl.idx]
+                for k, (sl, gtmp) in enumerate(passes):
+                    gw = gp[sl].sum(0)
+                    self.flat_p.view_of(gtmp, wl).view(-1).copy_(gw if k == 0 else gw / r_t)
+                    self.flat_p.view_of(gtmp, self.tail_lin.bias).view(-1).copy_(dlogit[sl].sum().view(1))
             for bi in reversed(range(1, len(self.res))):
                 b, bc = self.res[bi], ctx['blocks'][bi]
                 x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
+                code1s = bc['code1s']
+                u1, u2 = codes[2 * bi - 1], codes[2 * bi]          # unscaled
                 c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
                 scm = self.sn_of[b.shortcut[1].module] if has_sc else None
                 a = 0.25 if pooled else 1.0
                 if want_w:
-                    ops.wgrad(Seg(c1, code=code2, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=pooled, alpha=a,
-                              bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias) if has_sc else None)
+                    wgrad_all(lambda sl: Seg(c1[sl], code=u2[sl], relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                              c2m.m.bias, scm.m.bias if has_sc else None, dy_ups=pooled, alpha=a)
                     if has_sc:
-                        ops.wgrad(Seg(x, ksize=1, code=code1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=pooled, alpha=a)
+                        wgrad_all(lambda sl: Seg(x[sl], ksize=1, code=u1[sl]), dy, scm.cout, scm.cin, scm.m.weight_orig,
+                                  dy_ups=pooled, alpha=a)
                 dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
                 if want_w:
-                    ops.wgrad(Seg(x, code=code1, relu=True), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
+                    wgrad_all(lambda sl: Seg(x[sl], code=u1[sl], relu=True), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
                 if has_sc:
-                    res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1)
+                    res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1s)
                 else:
                     res = dy
                 dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
@@ -507,19 +596,24 @@ class DiscriminatorEngine:
             b0, bc = self.res[0], ctx['blocks'][0]
             c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
             c1, code, img = bc['c1'], bc['code'], ctx['img']
+            u0 = codes[0]
             if want_w:
-                ops.wgrad(Seg(c1, code=code, relu=True), dy, c2m.cout, c2m.cin, T(c2m.m.weight_orig), dy_ups=True, alpha=0.25,
-                          bias_grad=T(c2m.m.bias), bias_grad2=T(scm.m.bias))
-                ops.wgrad(Seg(img, ksize=1), dy, scm.cout, scm.cin, T(scm.m.weight_orig), dy_ups=True, alpha=0.25)
+                wgrad_all(lambda sl: Seg(c1[sl], code=u0[sl], relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                          c2m.m.bias, scm.m.bias, dy_ups=True, alpha=0.25)
+                wgrad_all(lambda sl: Seg(img[sl], ksize=1), dy, scm.cout, scm.cin, scm.m.weight_orig, dy_ups=True, alpha=0.25)
             dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)
             if want_w:
-                ops.wgrad(Seg(img), dc1, c1m.cout, c1m.cin, T(c1m.m.weight_orig), bias_grad=T(c1m.m.bias))
+                wgrad_all(lambda sl: Seg(img[sl]), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
             dimg = None
             if need_input_grad:
+                if pair is not None:
+                    raise RuntimeError('input gradients of a paired pass are not needed by the D update and not built')
                 dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
                 dimg = ops.to_nchw(dimg_t, c1m.cin)
         if want_w:
             # d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used; biases are moved as is
-            ops.sn_grad_fix(gtmp, gflat, fp, uv, self._layers_dev, len(self.sn) + len(self.plain), sigma,
-                            accumulate=accumulate)
+            nl = len(self.sn) + len(self.plain)
+            ops.sn_grad_fix(passes[0][1], gflat, fp, uv, self._layers_dev, nl, sigma, accumulate=accumulate)
+            if pair is not None:
+                ops.sn_grad_fix(passes[1][1], gflat, fp, pair['uv2'], self._layers_dev, nl, pair['sigma2'], accumulate=True)
         return dimg

@@ -541,12 +541,16 @@ class CodeBatch:
         self._ensure()
         n = indicator.shape[0]
         if self._n_cached != n:
-            off = 0
-            for d in self._arr:
-                d.out_off = off
-                off += n * d.C
-            self._total = off
-            self._table = _struct_table(self._arr, indicator.device)
+            # one descriptor table per batch size (the paired discriminator pass alternates 2N and N)
+            if not isinstance(getattr(self, '_tables', None), dict) or self._tables.get('key') != self._key:
+                self._tables = {'key': self._key}
+            if n not in self._tables:
+                off = 0
+                for d in self._arr:
+                    d.out_off = off
+                    off += n * d.C
+                self._tables[n] = (off, _struct_table(self._arr, indicator.device))
+            self._total, self._table = self._tables[n]
             self._n_cached = n
         if indicator.shape[1] != self._arr[0].M:
             raise _lib.McgenError(f'indicator has {indicator.shape[1]} modes, codebook has {self._arr[0].M}')

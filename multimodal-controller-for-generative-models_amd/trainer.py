@@ -28,6 +28,9 @@ from .gan_engine import FlatState, _bump
 # making HIP calls while this thread captures; only this thread's illegal calls abort the capture.
 _CAPTURE_MODE = 'thread_local'
 
+import os as _os
+_PAIR_D = _os.environ.get('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
+
 
 class FusedAdam:
     """torch.optim.Adam semantics over one flat parameter buffer: one launch per step."""
@@ -80,6 +83,16 @@ class GANTrainer:
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
     def d_compute(self, img, ind, z):
+        if _PAIR_D:
+            # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
+            # power iterations of the two reference forwards depend on the weights alone and run first, in order
+            fake, _ = self.geng.forward(z, ind, True)
+            logits, ctx = self.deng.forward_pair(img, fake, ind)
+            n = img.shape[0]
+            lg = logits.view(-1)
+            loss, dreal, dfake = ops.hinge_d(lg[:n], lg[n:])
+            self.deng.backward(ctx, torch.cat([dreal, dfake]), self.grad_d, False, False)
+            return loss
         d_real, ctx_r = self.deng.forward(img, ind, True)
         fake, _ = self.geng.forward(z, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
