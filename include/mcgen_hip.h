@@ -154,8 +154,11 @@ int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int
 /* code[N, C] = indicator[N, M] @ codebook[M, C]      MultimodalController.forward, modules.py:73 */
 int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream);
 /* codes of all MultimodalController layers of a network in ONE launch: code_base + out_off <- indicator @ codebook */
-typedef struct { const float* codebook; int64_t out_off; int32_t M, C; } mcgen_code_t;
-int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream);
+typedef struct { const float* codebook; int64_t out_off; int32_t M, C; int32_t scale_idx, _pad; } mcgen_code_t;
+/* optional per-sample scaling (paired discriminator pass): rows n >= n_half of job j are multiplied by
+ * scale[descs[j].scale_idx] (scale_idx < 0 or scale == NULL: no scaling) */
+int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
+                        const float* scale, int n_half, void* stream);
 /* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);

@@ -47,7 +47,8 @@ class Prep(C.Structure):
 
 
 class Code(C.Structure):
-    _fields_ = [('codebook', C.c_void_p), ('out_off', C.c_int64), ('M', C.c_int32), ('C', C.c_int32)]
+    _fields_ = [('codebook', C.c_void_p), ('out_off', C.c_int64), ('M', C.c_int32), ('C', C.c_int32),
+                ('scale_idx', C.c_int32), ('_pad', C.c_int32)]
 
 
 class SnLayer(C.Structure):
@@ -96,7 +97,7 @@ SYMBOLS = {
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
-    'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

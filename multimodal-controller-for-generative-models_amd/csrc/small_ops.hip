@@ -105,8 +105,9 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
 // ---- MultimodalController ---------------------------------------------------------------------------
 // codes of every MultimodalController of a network in one launch: blockIdx.y = descriptor
 __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_code_t* __restrict__ descs,
-                                     float* __restrict__ code_base, int N) {
+                                     float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
     const mcgen_code_t d = descs[blockIdx.y];
+    const float tail_scale = (scale && d.scale_idx >= 0) ? scale[d.scale_idx] : 1.f;
     const size_t total = (size_t)N * d.C;
     float* code = code_base + d.out_off;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -121,7 +122,7 @@ __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_
         } else {
             for (int m = 0; m < d.M; ++m) { const float w = ind[(size_t)n * d.M + m]; if (w != 0.f) s = fmaf(w, d.codebook[(size_t)m * d.C + c], s); }
         }
-        code[i] = s;
+        code[i] = (n >= n_half) ? s * tail_scale : s;
     }
 }
 __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __restrict__ cb, float* __restrict__ code,
@@ -537,9 +538,10 @@ extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, con
         hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
     MCGEN_LAUNCH_CHECK("prep_weight_batch"); return 0;
 }
-extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream) {
+extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
+                                   const float* scale, int n_half, void* stream) {
     MCGEN_CHECK(indicator && descs_dev && code_base && n > 0 && N > 0, "mc_code_batch: bad arguments");
-    hipLaunchKernelGGL(mc_code_batch_kernel, dim3(32, n), dim3(256), 0, STREAM(stream), indicator, descs_dev, code_base, N);
+    hipLaunchKernelGGL(mc_code_batch_kernel, dim3(32, n), dim3(256), 0, STREAM(stream), indicator, descs_dev, code_base, N, scale, scale ? n_half : N);
     MCGEN_LAUNCH_CHECK("mc_code_batch"); return 0;
 }
 

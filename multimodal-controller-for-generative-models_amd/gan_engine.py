@@ -436,23 +436,25 @@ class DiscriminatorEngine:
         sigma2, uv2 = self._power_iter(True)
         ratio = sigma1 / sigma2
         ind2 = torch.cat([indicator, indicator])
-        codes = self._codes.run(ind2)                          # [2N, C] each; both halves equal
         uses = self._code_uses()
-        scaled = {}
-        by_width: Dict[int, list] = {}
-        for u in uses:
-            w = codes[u[0]].shape[1] if u[0] is not None else 8
-            by_width.setdefault(w, []).append(u)
-        dev = real_nchw.device
-        for w, us in by_width.items():
-            base = torch.stack([codes[mc_i] if mc_i is not None else torch.ones(2 * n, w, device=dev) for mc_i, _ in us])
-            idx = torch.tensor([sn for _, sn in us], device=dev) if (w, len(us)) not in self._use_idx else self._use_idx[(w, len(us))]
-            self._use_idx[(w, len(us))] = idx
-            r = ratio.index_select(0, idx)                                            # [U]
-            scale = torch.cat([torch.ones(len(us), n, device=dev), r[:, None].expand(-1, n)], 1).unsqueeze(-1)
-            out = base * scale
-            for k, u in enumerate(us):
-                scaled[u] = out[k]
+        if getattr(self, '_codes_pair', None) is None:
+            # one job per convolution input: the MC's codebook (an all-ones table for the image inputs, which have no
+            # MC) and the SN layer whose sigma ratio scales the fake half
+            class _Ones:                                        # stands in for an MC on the raw image (8 padded channels)
+                pass
+            ones = _Ones()
+            ones.codebook = torch.ones(indicator.shape[1], 8, device=indicator.device)
+            self._ones_mc = ones
+            self._codes_pair = ops.CodeBatch([self._codes.mcs[u[0]] if u[0] is not None else ones for u in uses],
+                                             [u[1] for u in uses])
+        outs = self._codes_pair.run(ind2, ratio, n)            # all scaled codes of the pass: one launch
+        scaled = dict(zip(uses, outs))
+        # unscaled codes (weight gradients): the real half of any use of that MC
+        first_use = {}
+        for u, t in zip(uses, outs):
+            if u[0] is not None and u[0] not in first_use:
+                first_use[u[0]] = t
+        codes = [first_use[i] for i in range(len(self._codes.mcs))]
         x = torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
@@ -534,7 +536,9 @@ class DiscriminatorEngine:
         sigma, uv = ctx['sigma'], ctx['uv']
         pair = ctx['pair']
         want_w = gflat is not None
-        codes = ctx['codes']                       # unscaled codes of every MC (weight gradients see the true conv input)
+        # unscaled codes of every MC (weight gradients see the true conv input); in a paired pass only the real half
+        # of the stored tensors is unscaled, and both halves carry the same labels
+        codes = ctx['codes'] if pair is None else [t[:pair['n']] for t in ctx['codes']]
         nmc = len(self._codes.mcs)
         # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first: one buffer per pass
         if pair is None:
@@ -574,19 +578,19 @@ class DiscriminatorEngine:
                 b, bc = self.res[bi], ctx['blocks'][bi]
                 x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
                 code1s = bc['code1s']
-                u1, u2 = codes[2 * bi - 1], codes[2 * bi]          # unscaled
+                u1, u2 = codes[2 * bi - 1], codes[2 * bi]          # unscaled (paired pass: only the real half is)
                 c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
                 scm = self.sn_of[b.shortcut[1].module] if has_sc else None
                 a = 0.25 if pooled else 1.0
                 if want_w:
-                    wgrad_all(lambda sl: Seg(c1[sl], code=u2[sl], relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                    wgrad_all(lambda sl: Seg(c1[sl], code=u2, relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
                               c2m.m.bias, scm.m.bias if has_sc else None, dy_ups=pooled, alpha=a)
                     if has_sc:
-                        wgrad_all(lambda sl: Seg(x[sl], ksize=1, code=u1[sl]), dy, scm.cout, scm.cin, scm.m.weight_orig,
+                        wgrad_all(lambda sl: Seg(x[sl], ksize=1, code=u1), dy, scm.cout, scm.cin, scm.m.weight_orig,
                                   dy_ups=pooled, alpha=a)
                 dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
                 if want_w:
-                    wgrad_all(lambda sl: Seg(x[sl], code=u1[sl], relu=True), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
+                    wgrad_all(lambda sl: Seg(x[sl], code=u1, relu=True), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
                 if has_sc:
                     res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1s)
                 else:
@@ -598,7 +602,7 @@ class DiscriminatorEngine:
             c1, code, img = bc['c1'], bc['code'], ctx['img']
             u0 = codes[0]
             if want_w:
-                wgrad_all(lambda sl: Seg(c1[sl], code=u0[sl], relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                wgrad_all(lambda sl: Seg(c1[sl], code=u0, relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
                           c2m.m.bias, scm.m.bias, dy_ups=True, alpha=0.25)
                 wgrad_all(lambda sl: Seg(img[sl], ksize=1), dy, scm.cout, scm.cin, scm.m.weight_orig, dy_ups=True, alpha=0.25)
             dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)

@@ -515,8 +515,11 @@ class CodeBatch:
     """Codes of a list of MultimodalController modules in ONE launch; rebuilt when a codebook buffer was
     re-registered (models.utils.create / transit) or moved."""
 
-    def __init__(self, mcs):
+    def __init__(self, mcs, scale_idx=None):
+        """`mcs`: modules with a `codebook` buffer; `scale_idx[i]` (optional): index into the `scale` vector given to
+        run() whose entry multiplies the rows n >= n_half of job i (-1: none)."""
         self.mcs = list(mcs)
+        self.scale_idx = list(scale_idx) if scale_idx is not None else [-1] * len(self.mcs)
         self._key = None
 
     def _ensure(self):
@@ -530,13 +533,14 @@ class CodeBatch:
                 if cb.dtype != torch.float32 or not cb.is_contiguous():
                     raise _lib.McgenError('codebook must be a contiguous float32 buffer')
                 d.codebook, d.out_off, d.M, d.C = _p(cb), off, cb.shape[0], cb.shape[1]
+                d.scale_idx = self.scale_idx[len(self.offsets)]
                 self.offsets.append((off, cb.shape[1]))
                 off += 0                                   # per-forward: offsets scale with N, filled in run()
             self._arr = arr
             self._key = key
             self._n_cached = None
 
-    def run(self, indicator: Tensor):
+    def run(self, indicator: Tensor, scale: Optional[Tensor] = None, n_half: int = 0):
         """-> list of [N, C] code tensors (views of one buffer), in module order."""
         self._ensure()
         n = indicator.shape[0]
@@ -556,7 +560,7 @@ class CodeBatch:
             raise _lib.McgenError(f'indicator has {indicator.shape[1]} modes, codebook has {self._arr[0].M}')
         buf = torch.empty(self._total, dtype=torch.float32, device=indicator.device)
         check(_lib.load().mcgen_mc_code_batch(_f32(indicator.contiguous()), _p(self._table), len(self.mcs), _f32(buf), n,
-                                              _stream()), 'mc_code_batch')
+                                              _f32(scale), n_half, _stream()), 'mc_code_batch')
         out, off = [], 0
         for d in self._arr:
             out.append(buf[off:off + n * d.C].view(n, d.C))

@@ -91,7 +91,8 @@ class GANTrainer:
             n = img.shape[0]
             lg = logits.view(-1)
             loss, dreal, dfake = ops.hinge_d(lg[:n], lg[n:])
-            self.deng.backward(ctx, torch.cat([dreal, dfake]), self.grad_d, False, False)
+            dboth = torch.cat([dreal, dfake])
+            self.deng.backward(ctx, dboth, self.grad_d, False, False)
             return loss
         d_real, ctx_r = self.deng.forward(img, ind, True)
         fake, _ = self.geng.forward(z, ind, True)
