@@ -109,6 +109,8 @@ typedef struct {
     int32_t dy_ups;        /* 1: dy is the gradient of a 2x2-pooled output                  */
     float*  slabs;
     int32_t splits;
+    int32_t halves;        /* 1: splits [0, splits/2) walk the first half of the pixel tiles, the rest the second half
+                            * (paired discriminator pass: one slab set per half of the batch); needs even splits, m_tiles */
     float*  bias_slabs;    /* [splits*4][Cout_w] partial column sums of dy (the bias gradient), or NULL    */
 } mcgen_wgrad_t;
 

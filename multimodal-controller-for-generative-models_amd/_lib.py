@@ -30,7 +30,8 @@ class Wgrad(C.Structure):
     _fields_ = [('seg', Seg), ('dy', C.c_void_p),
                 ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('Cout', C.c_int32), ('Cout_w', C.c_int32), ('Cdy', C.c_int32),
-                ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32), ('bias_slabs', C.c_void_p)]
+                ('dy_ups', C.c_int32), ('slabs', C.c_void_p), ('splits', C.c_int32), ('halves', C.c_int32),
+                ('bias_slabs', C.c_void_p)]
 
 
 class WReduce(C.Structure):

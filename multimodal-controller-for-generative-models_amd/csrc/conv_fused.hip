@@ -1242,6 +1242,8 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     static const int m128 = getenv("MCGEN_CONV_M128") ? atoi(getenv("MCGEN_CONV_M128")) : 5;
     static const int m128w = getenv("MCGEN_CONV_M128W") ? atoi(getenv("MCGEN_CONV_M128W")) : 5;
     if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 5};
+    static const long big128 = getenv("MCGEN_CONV_BIG128") ? atol(getenv("MCGEN_CONV_BIG128")) : 0;
+    if (big128 > 0 && M >= big128 && rows256 && p->Cout_w > 64) return {256, 128, 5};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, m128};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, m128w};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};

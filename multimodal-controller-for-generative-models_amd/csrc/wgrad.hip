@@ -134,7 +134,11 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
 
     PatchStager<T, WG_NT, NI, APITCH> stager;
     stager.setup_static(KS, g0, W, tid);
-    for (int tile = blockIdx.z; tile < m_tiles; tile += gridDim.z) {
+    // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
+    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
+    const int t_lo = p.halves ? ((int)blockIdx.z / zs) * mt : 0;
+    for (int tile = t_lo + (int)blockIdx.z % zs; tile < t_lo + mt; tile += zs) {
         const Geo g = make_geo(WG_BM, tile, H, W);
         stager.bind(sg, g, N, H, W);
         __syncthreads();                                        // previous tile's reads are done
@@ -249,7 +253,11 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const int wa = wave >> 1, wb = wave & 1;
     const Geo g0 = make_geo(WG_BM, 0, H, W);
     const int PR = g0.TH + 2 * halo;
-    const int cnt = (m_tiles - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // tiles of this workgroup
+    // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
+    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
+    const int t_first = (p.halves ? ((int)blockIdx.z / zs) * mt : 0) + (int)blockIdx.z % zs;
+    const int cnt = (mt - (int)blockIdx.z % zs + zs - 1) / zs;                          // tiles of this workgroup
     const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
     constexpr int DUNITS = WG_BCO * ESZ / 16;
     constexpr int DITEMS = WG_BM * DUNITS / WG_NT;
@@ -265,7 +273,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
             u32x4 d[DITEMS];
         };
         auto fetch = [&](int i, TileRegs& r) {
-            const int tile = blockIdx.z + i * gridDim.z;
+            const int tile = t_first + i * zs;
             const Geo g = make_geo(WG_BM, tile, H, W);
             stager.bind_into(sg, g, N, H, W, r.src, r.nn);
 #pragma unroll
@@ -556,6 +564,8 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
     MCGEN_CHECK(p->seg.ksize == 1 || p->seg.ksize == 3, "wgrad: ksize must be 1 or 3");
     MCGEN_CHECK(p->Cout > 0 && p->Cout_w == round_up(p->Cout, 16) && p->Cdy >= p->Cout, "wgrad: bad Cout/Cout_w/Cdy");
     MCGEN_CHECK(p->splits >= 1 && p->splits <= 65535, "wgrad: bad splits");
+    MCGEN_CHECK(!p->halves || (p->splits % 2 == 0 && (((long)p->N * p->H * p->W + WG_BM - 1) / WG_BM) % 2 == 0 && ((long)p->N * p->H * p->W) % (2 * WG_BM) == 0),
+                "wgrad: halves needs even splits and a whole number of pixel tiles per half");
     MCGEN_CHECK(!p->dy_ups || (p->H >= 2 && p->W >= 2), "wgrad: dy_ups needs H, W >= 2");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MCGEN_F32) return launch_t<float>(p, st);

@@ -85,6 +85,7 @@ class _BN:
     __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
 
+_PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
 _pending_counters: List[Tensor] = []
 
 
@@ -449,12 +450,7 @@ class DiscriminatorEngine:
                                              [u[1] for u in uses])
         outs = self._codes_pair.run(ind2, ratio, n)            # all scaled codes of the pass: one launch
         scaled = dict(zip(uses, outs))
-        # unscaled codes (weight gradients): the real half of any use of that MC
-        first_use = {}
-        for u, t in zip(uses, outs):
-            if u[0] is not None and u[0] not in first_use:
-                first_use[u[0]] = t
-        codes = [first_use[i] for i in range(len(self._codes.mcs))]
+        codes = self._codes.run(ind2)                          # unscaled [2N, C] codes: the weight gradients' conv inputs
         x = torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
@@ -536,9 +532,11 @@ class DiscriminatorEngine:
         sigma, uv = ctx['sigma'], ctx['uv']
         pair = ctx['pair']
         want_w = gflat is not None
-        # unscaled codes of every MC (weight gradients see the true conv input); in a paired pass only the real half
-        # of the stored tensors is unscaled, and both halves carry the same labels
-        codes = ctx['codes'] if pair is None else [t[:pair['n']] for t in ctx['codes']]
+        # unscaled codes of every MC (weight gradients see the true conv input)
+        codes_full = ctx['codes']
+
+        def U(i, sl):                                  # code rows matching the activation rows x[sl]
+            return codes_full[i][sl]
         nmc = len(self._codes.mcs)
         # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first: one buffer per pass
         if pair is None:
@@ -547,10 +545,19 @@ class DiscriminatorEngine:
             passes = [(slice(0, pair['n']), torch.empty_like(fp)), (slice(pair['n'], 2 * pair['n']), torch.empty_like(fp))]
 
         def wgrad_all(seg_fn, dy, cout, cin, param, bias=None, bias2=None, **kw):
-            for sl, gtmp in passes:
+            def dests(gtmp):
                 T = lambda p: self.flat_p.view_of(gtmp, p)                         # noqa: E731
-                ops.wgrad(seg_fn(sl), dy[sl], cout, cin, T(param), bias_grad=T(bias) if bias is not None else None,
-                          bias_grad2=T(bias2) if bias2 is not None else None, **kw)
+                return T(param), (T(bias) if bias is not None else None), (T(bias2) if bias2 is not None else None)
+            hq = dy.shape[1] * dy.shape[2] * (4 if kw.get('dy_ups') else 1)          # pixels per image at the conv resolution
+            if pair is not None and _PAIR_WGRAD and (pair['n'] * hq) % 128 == 0:
+                # one launch over the 2N batch, one slab set per half; the codes of the two halves are equal
+                seg = seg_fn(slice(None))
+                (g1, b1, b12), second = dests(passes[0][1]), dests(passes[1][1])
+                ops.wgrad(seg, dy, cout, cin, g1, bias_grad=b1, bias_grad2=b12, second=second, **kw)
+                return
+            for sl, gtmp in passes:
+                g1, b1, b12 = dests(gtmp)
+                ops.wgrad(seg_fn(sl), dy[sl], cout, cin, g1, bias_grad=b1, bias_grad2=b12, **kw)
 
         self._ensure_preps()
         self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
@@ -578,19 +585,19 @@ class DiscriminatorEngine:
                 b, bc = self.res[bi], ctx['blocks'][bi]
                 x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']
                 code1s = bc['code1s']
-                u1, u2 = codes[2 * bi - 1], codes[2 * bi]          # unscaled (paired pass: only the real half is)
+                i1, i2 = 2 * bi - 1, 2 * bi                        # MC indices of the block's unscaled codes
                 c1m, c2m = self.sn_of[b.conv[2].module], self.sn_of[b.conv[5].module]
                 scm = self.sn_of[b.shortcut[1].module] if has_sc else None
                 a = 0.25 if pooled else 1.0
                 if want_w:
-                    wgrad_all(lambda sl: Seg(c1[sl], code=u2, relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                    wgrad_all(lambda sl: Seg(c1[sl], code=U(i2, sl), relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
                               c2m.m.bias, scm.m.bias if has_sc else None, dy_ups=pooled, alpha=a)
                     if has_sc:
-                        wgrad_all(lambda sl: Seg(x[sl], ksize=1, code=u1), dy, scm.cout, scm.cin, scm.m.weight_orig,
+                        wgrad_all(lambda sl: Seg(x[sl], ksize=1, code=U(i1, sl)), dy, scm.cout, scm.cin, scm.m.weight_orig,
                                   dy_ups=pooled, alpha=a)
                 dc1, _ = ops.conv_fused([Seg(dy, ups=pooled)], I[f'{bi}.c2t'], c2m.cin, ocode=code2, gate_x=c1)
                 if want_w:
-                    wgrad_all(lambda sl: Seg(x[sl], code=u1, relu=True), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
+                    wgrad_all(lambda sl: Seg(x[sl], code=U(i1, sl), relu=True), dc1, c1m.cout, c1m.cin, c1m.m.weight_orig, c1m.m.bias)
                 if has_sc:
                     res, _ = ops.conv_fused([Seg(dy, ksize=1, ups=pooled)], I[f'{bi}.sct'], scm.cin, ocode=code1s)
                 else:
@@ -600,9 +607,8 @@ class DiscriminatorEngine:
             b0, bc = self.res[0], ctx['blocks'][0]
             c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
             c1, code, img = bc['c1'], bc['code'], ctx['img']
-            u0 = codes[0]
             if want_w:
-                wgrad_all(lambda sl: Seg(c1[sl], code=u0, relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
+                wgrad_all(lambda sl: Seg(c1[sl], code=U(0, sl), relu=True), dy, c2m.cout, c2m.cin, c2m.m.weight_orig,
                           c2m.m.bias, scm.m.bias, dy_ups=True, alpha=0.25)
                 wgrad_all(lambda sl: Seg(img[sl], ksize=1), dy, scm.cout, scm.cin, scm.m.weight_orig, dy_ups=True, alpha=0.25)
             dc1, _ = ops.conv_fused([Seg(dy, ups=True)], I['0.c2t'], c2m.cin, ocode=code, gate_x=c1)

@@ -243,9 +243,11 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
 
 def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bool = False,
           alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None,
-          bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None):
+          bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None, second=None):
     """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment; optionally also the bias
-    gradient bias_grad[Cout] (+)= alpha * sum_pixels dy (and a copy into bias_grad2)."""
+    gradient bias_grad[Cout] (+)= alpha * sum_pixels dy (and a copy into bias_grad2).
+    `second` = (grad_b, bias_grad_b, bias_grad2_b): the batch is two halves (paired discriminator pass) and the
+    second half's gradient goes to these tensors instead -- one launch, one slab set per half."""
     n = seg.x.shape[0]
     h = seg.x.shape[1] * (2 if seg.ups else 1)
     w = seg.x.shape[2] * (2 if seg.ups else 1)
@@ -268,7 +270,12 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         # 20 % with 16 instead of 64 splits)
         target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL
         splits = max(1, min(m_tiles, (target + blocks - 1) // blocks, 64))
+        if second is not None:
+            splits = max(2, splits + (splits & 1))
+    if second is not None and ((n * h * w) % 256 != 0 or splits % 2):
+        raise _lib.McgenError('wgrad: a two-half launch needs whole 128-pixel tiles per half and even splits')
     p.splits = splits
+    p.halves = int(second is not None)
     lib = _lib.load()
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
     # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
@@ -291,15 +298,20 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
                lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
-    if _deferred is not None:
-        if not grad.is_contiguous():
-            raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
-        _deferred.append((slabs, grad, bias_slabs, bias_grad, bias_grad2, splits, cout, cin, seg.ksize, pad16(cout), row_perm,
-                          int(accumulate), float(alpha)))
-        return
-    check(lib.mcgen_wgrad_reduce(_p(slabs), splits, _f32(grad), cout, cin, seg.ksize, pad16(cout), row_perm,
-                                 float(alpha), int(accumulate), _p(bias_slabs), _f32(bias_grad), _f32(bias_grad2),
-                                 _stream()), 'wgrad_reduce')
+    if second is None:
+        parts = [(slabs, bias_slabs, grad, bias_grad, bias_grad2, splits)]
+    else:
+        hs = splits // 2
+        parts = [(slabs[:hs], bias_slabs[:hs * 4] if bias_slabs is not None else None, grad, bias_grad, bias_grad2, hs),
+                 (slabs[hs:], bias_slabs[hs * 4:] if bias_slabs is not None else None, second[0], second[1], second[2], hs)]
+    for sl, bs, gr, bg, bg2, ns in parts:
+        if _deferred is not None:
+            if not gr.is_contiguous():
+                raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
+            _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha)))
+        else:
+            check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
+                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _stream()), 'wgrad_reduce')
 
 
 _deferred = None
