@@ -875,6 +875,165 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "dma3g" form: dma3 for PURE 1x1 launches, three chunks per barrier round ------------------------------------
+// A 1x1 convolution has one tap per 32-channel chunk, so dma3 spends a barrier round (window staging + wait) per MFMA
+// step; here the windows of three consecutive chunks are staged side by side and their three weight tiles (which are
+// consecutive in the image) form one DMA group.  A separate kernel: sharing dma3's code cost the 3x3 launches 1-3 %.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_dma3g_kernel(const mcgen_conv_t p, const int a_bytes) {
+    constexpr bool G3 = true;
+    constexpr int g1 = 3;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+    constexpr int TPS = 3;
+    constexpr int NW = WM * WN;
+    constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
+    constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
+    constexpr int SLOT = TPS * C::BBYTES;
+    constexpr int SUBW = BM * APITCH;                      // one chunk's window of a 1x1 segment (no halo)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    // group bookkeeping over the linear (segment, chunk, tap) sequence
+    const int nt0 = p.seg[0].ksize * p.seg[0].ksize, nc0 = (p.seg[0].C + MCGEN_CK - 1) / MCGEN_CK;
+    // a group = 3 taps of one chunk (3x3) or g1 consecutive chunks of a 1x1 segment (their weight tiles are consecutive)
+    const int G0 = (nt0 == 9) ? nc0 * 3 : (nc0 + g1 - 1) / g1, S0 = nc0 * nt0;
+    int nt1 = 1, nc1 = 0;
+    if (p.nseg > 1) { nt1 = p.seg[1].ksize * p.seg[1].ksize; nc1 = (p.seg[1].C + MCGEN_CK - 1) / MCGEN_CK; }
+    const int GT = G0 + ((p.nseg > 1) ? ((nt1 == 9) ? nc1 * 3 : (nc1 + g1 - 1) / g1) : 0);   // total groups
+
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    int d_src[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+        const int lgrp = grp ^ (3 * ((row >> 3) & 1));
+        d_src[k] = (piece < KB && cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : -1;
+    }
+    auto G_dma = [&](int gi) {                             // all taps of group gi -> slot gi & 1
+        if (gi >= GT) return;
+        int blk0, ntg;
+        if (gi < G0) {
+            if (nt0 == 9) { ntg = 3; blk0 = gi * 3; }
+            else { blk0 = gi * g1; ntg = (nc0 - blk0) < g1 ? (nc0 - blk0) : g1; }
+        } else {
+            const int gj = gi - G0;
+            if (nt1 == 9) { ntg = 3; blk0 = S0 + gj * 3; }
+            else { const int c0 = gj * g1; ntg = (nc1 - c0) < g1 ? (nc1 - c0) : g1; blk0 = S0 + c0; }
+        }
+        char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) {
+            const int blk = blk0 + (t < ntg ? t : ntg - 1);        // short group: re-load the last tap (constant DMA count)
+            const char* wb = wimg + (size_t)blk * wblock_bytes;
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) {
+                const int piece = wave * PPW + k;
+                if (piece < KB) {
+                    const char* src = wb + (d_src[k] >= 0 ? d_src[k] : (lane % UPR) * 16);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(slot + t * C::BBYTES + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
+
+    int gi = 0;
+    G_dma(0);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = p.seg[s];
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, NT, C::NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+        // 3x3: one chunk per round, 3 groups of 3 taps; 1x1: g1 chunks per round (windows side by side), one group
+        const int gpc = (ntap == 9) ? 3 : 1, qs = (ntap == 9) ? 1 : g1;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; q += qs) {
+            const int ntg = (ntap == 9) ? 3 : ((nchunk - q) < g1 ? (nchunk - q) : g1);
+            __builtin_amdgcn_s_barrier();                  // everyone is past the previous round's window reads
+            stager.stage(sg, q * MCGEN_CK, ldsA);
+            if constexpr (G3) {
+                if (qs > 1 && q + 1 < nchunk) stager.stage(sg, (q + 1) * MCGEN_CK, ldsA + SUBW);
+                if (qs > 1 && q + 2 < nchunk) stager.stage(sg, (q + 2) * MCGEN_CK, ldsA + 2 * SUBW);
+            }
+#pragma unroll 1
+            for (int gq = 0; gq < gpc; ++gq) {
+                // this group's tiles have landed (this wave's pieces); then all waves' pieces + window writes
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                G_dma(gi + 1);                            // slot (gi+1)&1: its readers (group gi-1) passed the barrier
+                const char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) {
+                    if (t < ntg) {
+                        const int tap = gq * 3 + t;
+                        const int tapoff = (ntap == 9) ? ((tap / 3) * PC + (tap % 3)) * APITCH : t * SUBW;
+                        const char* ldsB = slot + t * C::BBYTES;
+                        typename M::frag af[FM], wf[FN];
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm)
+                            af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+                            wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                            for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                    }
+                }
+                ++gi;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- "cp" form (chunk-pipelined), for the tiles of small maps ---------------------------------------------------
 // On 8x8 / 16x16 maps (and for skinny-N convolutions) a workgroup's MFMA work per 32-channel chunk is a fraction of a
 // microsecond, so the forms above are a serial chain of exposed round trips: stage the window, wait, DMA a tap group,
@@ -1326,12 +1485,31 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     const int nt = (p->Cout_w + BN - 1) / BN;
     const int PP = patch_pixels(p, BM);
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
-    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    int a_bytes = round_up(PP * C::APITCH, 1024);
+    // pure 1x1 launches with several chunks: the grouped form, when its three side-by-side windows fit the LDS budget
+    static const int g1_env = getenv("MCGEN_CONV_G1") ? atoi(getenv("MCGEN_CONV_G1")) : 3;
+    const int a3 = round_up(3 * BM * C::APITCH, 1024);
+    // (K-deep ones only: at 8 chunks and fewer the plain form measured as fast or faster)
+    const bool grouped = TPS == 3 && g1_env == 3 && p->nseg == 1 && p->seg[0].ksize == 1 && p->seg[0].C >= 12 * MCGEN_CK &&
+                         (a3 > a_bytes ? a3 : a_bytes) + 6 * C::BBYTES <= 96 * 1024;
+    if (grouped && a3 > a_bytes) a_bytes = a3;
     int lds = a_bytes + (TPS == 3 ? 6 : 3) * C::BBYTES;
     const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    if (grouped) {
+        auto kg = conv_dma3g_kernel<T, BM, BN, WM, WN>;
+        static int raisedg = 0;
+        if (lds > 64 * 1024 && lds > raisedg) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return mcgen_fail("conv_fused: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+            raisedg = lds;
+        }
+        hipLaunchKernelGGL(kg, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+        MCGEN_LAUNCH_CHECK("conv_fused(dma3g)");
+        return 0;
+    }
     auto kern = (TPS == 3) ? conv_dma3_kernel<T, BM, BN, WM, WN> : conv_dma_kernel<T, BM, BN, WM, WN>;
     static int raised = 0;
     if (lds > 64 * 1024 && lds > raised) {
