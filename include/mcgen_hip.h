@@ -141,6 +141,14 @@ int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin,
  * (ZeroConv2d's exp(3*scale), mcglow.py:127-130; ActNorm.reverse folded into the inverse 1x1 conv, mcglow.py:53-55) */
 int mcgen_prep_weight_rows(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
                            const float* row_scale, void* stream);
+/* generalised builder: strided source [Cout][Cin][KH][KW] (element strides s_*), embedded at tap (kh0, kw0) of the
+ * ksize x ksize image, source scaled by row_scale[co] * col_scale[ci] * wscale, forward or transposed+flipped, image
+ * extents rows_img x k_img (zero outside the source).  Covers PixelCNN's (k/2+1) x k / 1 x (k/2+1) stacks inside 3x3
+ * images (mcpixelcnn.py:29-35), Glow's exp(3*scale) / ActNorm-scaled and zero-padded coupling weights and every
+ * input-gradient image of those models without intermediate tensor ops. */
+int mcgen_prep_weight_ex(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout, int Cin,
+                         int KH, int KW, int kh0, int kw0, int ksize, int transpose, int rows_img, int k_img,
+                         const float* row_scale, const float* col_scale, float wscale, void* image, int dtype, void* stream);
 /* the same for all layers of a network pass in ONE launch; sigma = sigma_base[sigma_idx] (idx < 0: none) */
 typedef struct {
     const float* w; void* image;

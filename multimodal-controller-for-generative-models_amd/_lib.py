@@ -97,6 +97,7 @@ SYMBOLS = {
     'mcgen_code_bn_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),
+    'mcgen_prep_weight_ex': (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -71,6 +71,43 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+
+// Generalised weight image: any strided [Cout][Cin][KH][KW] source, embedded at tap offset (kh0, kw0) of a ksize x ksize
+// image (other taps zero), optional per-output-channel / per-input-channel scales of the SOURCE, forward or transposed
+// (+ flipped) orientation, and explicit image extents (rows_img x k_img; zero outside the source).  One launch replaces
+// the pad / flip / transpose / scale tensor ops that otherwise precede mcgen_prep_weight.
+struct PrepEx {
+    const float* w; long s_co, s_ci, s_kh, s_kw;
+    int Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img;
+    const float* row_scale; const float* col_scale; float wscale;
+};
+template <typename T>
+__global__ void prep_weight_ex_kernel(const PrepEx d, T* __restrict__ img) {
+    const int ntap = d.ksize * d.ksize;
+    const int rows_w = (d.rows_img + 15) / 16 * 16;
+    const int nchunk = (((d.k_img + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t total = (size_t)nchunk * ntap * rows_w * MCGEN_CK;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % MCGEN_CK); size_t t = i / MCGEN_CK;
+        const int row = (int)(t % rows_w); t /= rows_w;
+        const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
+        const int k = q * MCGEN_CK + col;
+        float v = 0.f;
+        const int co = d.transpose ? k : row, ci = d.transpose ? row : k;
+        if (row < d.rows_img && k < d.k_img && co < d.Cout && ci < d.Cin) {
+            int kh = tap / d.ksize, kw = tap % d.ksize;
+            if (d.transpose) { kh = d.ksize - 1 - kh; kw = d.ksize - 1 - kw; }
+            const int sh = kh - d.kh0, sw = kw - d.kw0;
+            if (sh >= 0 && sh < d.KH && sw >= 0 && sw < d.KW) {
+                v = d.w[co * d.s_co + ci * d.s_ci + sh * d.s_kh + sw * d.s_kw] * d.wscale;
+                if (d.row_scale) v *= d.row_scale[co];
+                if (d.col_scale) v *= d.col_scale[ci];
+            }
+        }
+        img[i] = Elem<T>::from_f(v);
+    }
+}
+
 // all weight images of a network pass in one launch: blockIdx.y = descriptor
 template <typename T>
 __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs, const float* __restrict__ sigma_base) {
@@ -518,6 +555,20 @@ extern "C" int mcgen_prep_weight_rows(const float* w, void* image, int dtype, in
         hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, 0, 1, nullptr, 1.f, row_scale),
         hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, 0, 1, nullptr, 1.f, row_scale));
     MCGEN_LAUNCH_CHECK("prep_weight_rows"); return 0;
+}
+
+extern "C" int mcgen_prep_weight_ex(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout, int Cin,
+                                    int KH, int KW, int kh0, int kw0, int ksize, int transpose, int rows_img, int k_img,
+                                    const float* row_scale, const float* col_scale, float wscale, void* image, int dtype, void* stream) {
+    MCGEN_CHECK(w && image && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (ksize == 1 || ksize == 3) && rows_img > 0 && k_img > 0,
+                "prep_weight_ex: bad arguments");
+    MCGEN_CHECK(kh0 >= 0 && kw0 >= 0 && kh0 + KH <= ksize && kw0 + KW <= ksize, "prep_weight_ex: source taps do not fit the image");
+    PrepEx d{w, s_co, s_ci, s_kh, s_kw, Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img, row_scale, col_scale, wscale};
+    const size_t total = (size_t)mcgen_weight_image_elems(transpose ? k_img : rows_img, transpose ? rows_img : k_img, ksize, transpose);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_weight_ex_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), d, (float*)image),
+        hipLaunchKernelGGL(prep_weight_ex_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), d, (bf16_t*)image));
+    MCGEN_LAUNCH_CHECK("prep_weight_ex"); return 0;
 }
 
 extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,

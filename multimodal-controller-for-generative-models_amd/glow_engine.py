@@ -52,10 +52,7 @@ class GlowEngine:
     def _zero_conv_image(self, zc, cin_pad: int):
         """ZeroConv2d (mcglow.py:119-130) as weight image + bias with exp(3*scale) folded into the rows."""
         rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
-        w = zc.conv.weight.detach()
-        if w.shape[1] < cin_pad:
-            w = F.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
-        return ops.prep_weight_rows(w, self.dtype, rs), zc.conv.bias.detach() * rs
+        return ops.prep_weight_ex(zc.conv.weight.detach(), self.dtype, row_scale=rs, k_img=cin_pad), zc.conv.bias.detach() * rs
 
     def _coupling_net(self, cp_net, x: Tensor, c: int, codes, train: bool, saved=None):
         """AffineCoupling.net on the first c/2 channels of x -> [log_s | t] (c channels)."""
@@ -65,9 +62,9 @@ class GlowEngine:
         count = n * h * w
         conv0, an1, mc1, conv1, an5, mc2, zc = (net[0].module, net[1].module, net[3], net[4].module, net[5].module,
                                                  net[7], net[8].module)
-        w0 = F.pad(conv0.weight.detach(), (0, 0, 0, 0, 0, cp - conv0.weight.shape[1]))      # zero over channels >= c/2
         need1 = train and not self.assume_initialized and int(an1.initialized) == 0
-        h1, st1 = ops.conv_fused([Seg(x)], ops.prep_weight(w0, dt), conv0.out_channels, bias=conv0.bias,
+        # the image is zero over the input channels >= c/2: the coupling net reads only the first half of x
+        h1, st1 = ops.conv_fused([Seg(x)], ops.prep_weight_ex(conv0.weight.detach(), dt, k_img=cp), conv0.out_channels, bias=conv0.bias,
                                  stats_mode=1 if need1 else 0)
         hid = conv0.out_channels
         a1, b1 = self._actnorm(an1, lambda: st1, count, train, hid)
@@ -88,8 +85,7 @@ class GlowEngine:
         a, b = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
         ic = flow.invconv
         wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
-        wpad = F.pad(wmat, (0, cp - c)).reshape(c, cp, 1, 1)
-        out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)], ops.prep_weight(wpad, dt), c, cy=cp)
+        out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)], ops.prep_weight_ex(wmat, dt, 1, k_img=cp), c, cy=cp)
         # parameter-only log-determinants: H*W * (sum log|scale| + sum w_s)   (mcglow.py:46-47,101)
         logdet += (h * w) * (torch.log(torch.abs(flow.actnorm.scale.detach())).sum() + ic.w_s.detach().sum())
         net = flow.coupling.net
@@ -118,8 +114,7 @@ class GlowEngine:
         _, winv = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, inverse=True)
         # ActNorm.reverse folded in: x_prev = (W^-1 x) / scale - loc
         an = flow.actnorm
-        wpad = F.pad(winv, (0, cp - c)).reshape(c, cp, 1, 1)
-        wimg = ops.prep_weight_rows(wpad, dt, 1.0 / an.scale.detach().reshape(-1))
+        wimg = ops.prep_weight_ex(winv, dt, 1, row_scale=1.0 / an.scale.detach().reshape(-1), k_img=cp)
         out, _ = ops.conv_fused([Seg(x, ksize=1)], wimg, c, bias=-an.loc.detach().reshape(-1), cy=cp)
         return out
 
@@ -197,9 +192,8 @@ class GlowEngine:
         self._grad(zc.conv.bias).copy_(gb * rs)
         if not need_dx:
             return None, None
-        wt = (zc.conv.weight.detach() * rs[:, None, None, None]).flip(2, 3).transpose(0, 1)       # [cin, cout, 3, 3]
-        wt = F.pad(wt, (0, 0, 0, 0, 0, dout.shape[-1] - cout)).contiguous()
-        return ops.conv_fused([Seg(dout)], ops.prep_weight(wt, dt), cin, res=res, **dgrad_kw)
+        wt = ops.prep_weight_ex(zc.conv.weight.detach(), dt, transpose=True, row_scale=rs, k_img=dout.shape[-1])
+        return ops.conv_fused([Seg(dout)], wt, cin, res=res, **dgrad_kw)
 
     def _flow_backward(self, flow, r, dy: Tensor, c: int, g0: float) -> Tensor:
         dt = self.dtype
@@ -224,8 +218,8 @@ class GlowEngine:
         ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid, gw, bias_grad=gb)
         self._grad(conv1.weight).copy_((gw * s5[:, None]).view_as(conv1.weight))
         self._grad(conv1.bias).copy_(gb * s5)
-        w1t = (conv1.weight.detach().reshape(hid, hid) * s5[:, None]).t().contiguous().reshape(hid, hid, 1, 1)
-        v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], ops.prep_weight(w1t, dt), hid, ocode=codes[0], gate_x=r['h1'],
+        w1t = ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5)
+        v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], w1t, hid, ocode=codes[0], gate_x=r['h1'],
                                  gscale=r['a1'], gshift=r['b1'], gmean=-an1.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
         ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
         s1 = an1.scale.detach().reshape(-1)
@@ -235,9 +229,8 @@ class GlowEngine:
         ops.wgrad(Seg(out), v1, hid, cp, gw0, bias_grad=gb0)
         self._grad(conv0.weight).copy_(gw0[:, :c // 2] * s1[:, None, None, None])
         self._grad(conv0.bias).copy_(gb0 * s1)
-        w0t = (conv0.weight.detach() * s1[:, None, None, None]).flip(2, 3).transpose(0, 1)          # [c/2, hid, 3, 3]
-        w0t = F.pad(w0t, (0, 0, 0, 0, 0, 0, 0, c - c // 2)).contiguous()                            # rows >= c/2: zero
-        dvt, _ = ops.conv_fused([Seg(v1)], ops.prep_weight(w0t, dt), c, res=dv, cy=cp)
+        w0t = ops.prep_weight_ex(conv0.weight.detach(), dt, transpose=True, row_scale=s1, rows_img=c)   # rows >= c/2: zero
+        dvt, _ = ops.conv_fused([Seg(v1)], w0t, c, res=dv, cy=cp)
         # invertible 1x1 conv <- ActNorm
         an, ic = flow.actnorm, flow.invconv
         gW = torch.empty((c, cp), dtype=torch.float32, device=dev)
@@ -246,8 +239,8 @@ class GlowEngine:
                         self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s))
         s = an.scale.detach().reshape(-1)
         wmat = r['wmat']
-        wt = F.pad((wmat * s[None, :]).t(), (0, cp - c)).contiguous().reshape(c, cp, 1, 1)          # [ci, co] = W[co, ci] * s[ci]
-        dx, st = ops.conv_fused([Seg(dvt, ksize=1)], ops.prep_weight(wt, dt), c, cy=cp, gate_x=x,
+        wt = ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp)                 # [ci, co] = W[co, ci] * s[ci]
+        dx, st = ops.conv_fused([Seg(dvt, ksize=1)], wt, c, cy=cp, gate_x=x,
                                 gscale=self._full(0.0, c, dev), gshift=self._full(1.0, c, dev),
                                 gmean=-an.loc.detach().reshape(-1), grstd=self._full(1.0, c, dev),
                                 stats_mode=2)

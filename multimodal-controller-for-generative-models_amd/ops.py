@@ -842,3 +842,26 @@ def argmin_channels(x: Tensor, c: int) -> Tensor:
     idx = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
     check(_lib.load().mcgen_argmin_channels(_p(x), idx.data_ptr(), _dt(x.dtype), pixels, c, x.shape[-1], _stream()), 'argmin_channels')
     return idx
+
+
+def prep_weight_ex(w: Tensor, dtype: torch.dtype, ksize: Optional[int] = None, *, kh0: int = 0, kw0: int = 0,
+                   transpose: bool = False, row_scale: Optional[Tensor] = None, col_scale: Optional[Tensor] = None,
+                   rows_img: Optional[int] = None, k_img: Optional[int] = None, wscale: float = 1.0) -> Tensor:
+    """Weight image straight from a (possibly strided / narrower) master tensor [Cout, Cin(, KH, KW)]: the source taps
+    sit at (kh0, kw0) of the ksize x ksize image, row_scale[co] / col_scale[ci] scale the SOURCE, `transpose` builds the
+    input-gradient image, rows_img / k_img widen the image with zeros (see mcgen_prep_weight_ex)."""
+    if w.dtype != torch.float32 or not w.is_cuda:
+        raise _lib.McgenError('prep_weight_ex: float32 device tensor expected')
+    cout, cin = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    st = w.stride()
+    s_kh, s_kw = (st[2], st[3]) if w.dim() == 4 else (0, 0)
+    ks = ksize if ksize is not None else kh
+    rows = rows_img if rows_img is not None else (cin if transpose else cout)
+    kk = k_img if k_img is not None else (cout if transpose else cin)
+    n = weight_image_elems(kk if transpose else rows, rows if transpose else kk, ks, transpose)
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    check(_lib.load().mcgen_prep_weight_ex(w.data_ptr(), st[0], st[1], s_kh, s_kw, cout, cin, kh, kw, kh0, kw0, ks, int(transpose),
+                                           rows, kk, _f32(row_scale), _f32(col_scale), float(wscale), _p(out), _dt(dtype), _stream()),
+          'prep_weight_ex')
+    return out
