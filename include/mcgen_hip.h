@@ -122,7 +122,8 @@ int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
  * transpose=0 only (weight gradients are always produced in forward orientation). */
 int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
                        int Cout_w, int row_perm, float alpha, int accumulate,
-                       const float* bias_slabs, float* bias_grad, float* bias_grad2, void* stream);
+                       const float* bias_slabs, float* bias_grad, float* bias_grad2,
+                       const float* row_scale /* optional [Cout] */, int cin_slab /* 0 = Cin */, void* stream);
 /* bias_slabs/bias_grad (optional): bias_grad[Cout] (+)= alpha * sum_s bias_slabs[s] (same row_perm);
  * bias_grad2 receives the same values (a second conv that shares dy, e.g. the 1x1 shortcut). */
 
@@ -270,6 +271,9 @@ typedef struct {
     float*       bias_grad2;  /* optional second destination                 */
     int32_t splits, Cout, Cin, ksize, Cout_w, row_perm, accumulate;
     float   alpha;
+    const float* row_scale;   /* optional [Cout]: grad row co is scaled by row_scale[co] (output-side factors such as
+                               * ActNorm's scale or ZeroConv2d's exp(3*scale) that follow the convolution)     */
+    int32_t cin_slab, _pad;   /* channel count the slabs were built for (the padded activation); 0 = Cin        */
 } mcgen_wreduce_t;
 int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void* stream);
 

@@ -404,7 +404,8 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int splits, size_t slab_elems,
                                            float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                            int row_perm, float alpha, int accumulate,
-                                           const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
+                                           const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
+                                           const float* __restrict__ row_scale) {
     const int ntap = KS * KS;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int Cc = row_perm > 1 ? Cout / row_perm : Cout;
@@ -427,11 +428,12 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
         }
         for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_elems + e);
         const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;      // image row -> master row
+        const float ra = row_scale ? alpha * row_scale[com] : alpha;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ci + j >= Cin) break;
             const size_t i = ((size_t)com * Cin + ci + j) * ntap + tap;
-            const float v = s[j] * alpha;
+            const float v = s[j] * ra;
             grad[i] = accumulate ? grad[i] + v : v;
         }
     }
@@ -443,8 +445,8 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
             for (int z = lane; z < splits * 4; z += 64) s += bias_slabs[(size_t)z * Cout_w + co];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
             if (lane == 0) {
-                s *= alpha;
                 const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;
+                s *= row_scale ? alpha * row_scale[com] : alpha;
                 bias_grad[com] = accumulate ? bias_grad[com] + s : s;
                 if (bias_grad2) bias_grad2[com] = accumulate ? bias_grad2[com] + s : s;
             }
@@ -454,18 +456,20 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, size_t slab_elems,
                                     float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                     int row_perm, float alpha, int accumulate,
-                                    const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2) {
-    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2);
+                                    const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
+                                    const float* __restrict__ row_scale) {
+    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2, row_scale);
 }
 // All reductions of one backward pass in ONE launch: blockIdx.y picks the job, the job table travels by value
 // in the kernel arguments (graph-capture safe: no host table to keep alive).
 struct ReduceJobs { mcgen_wreduce_t j[MCGEN_WREDUCE_MAX]; };
 __global__ void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
     const mcgen_wreduce_t& j = jobs.j[blockIdx.y];
-    const int nchunk = ((j.Cin + 7) / 8 * 8 + MCGEN_CK - 1) / MCGEN_CK;
+    const int cs = j.cin_slab > 0 ? j.cin_slab : j.Cin;
+    const int nchunk = ((cs + 7) / 8 * 8 + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK;
     reduce_job(j.slabs, j.splits, slab_elems, j.grad, j.Cout, j.Cin, j.ksize, j.Cout_w, j.row_perm, j.alpha, j.accumulate,
-               j.bias_slabs, j.bias_grad, j.bias_grad2);
+               j.bias_slabs, j.bias_grad, j.bias_grad2, j.row_scale);
 }
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
@@ -575,15 +579,17 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
 
 extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
                                   int Cout_w, int row_perm, float alpha, int accumulate,
-                                  const float* bias_slabs, float* bias_grad, float* bias_grad2, void* stream) {
+                                  const float* bias_slabs, float* bias_grad, float* bias_grad2,
+                                  const float* row_scale, int cin_slab, void* stream) {
     MCGEN_CHECK(slabs && grad && splits >= 1, "wgrad_reduce: bad arguments");
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
-    const int nchunk = (round_up(Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
+    MCGEN_CHECK(cin_slab == 0 || cin_slab >= Cin, "wgrad_reduce: cin_slab is the (padded) channel count the slabs were built for");
+    const int nchunk = (round_up(cin_slab > 0 ? cin_slab : Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
     int blocks = (int)((slab_elems / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
-                       bias_slabs, bias_grad, bias_grad2);
+                       bias_slabs, bias_grad, bias_grad2, row_scale);
     MCGEN_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }
@@ -599,7 +605,7 @@ extern "C" int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void
             MCGEN_CHECK(j.slabs && j.grad && j.splits > 0 && j.Cout > 0 && j.Cin > 0 && (j.ksize == 1 || j.ksize == 3) && j.Cout_w >= j.Cout,
                         "wgrad_reduce_batch: bad job %d", base + i);
             t.j[i] = j;
-            const int nchunk = (round_up(j.Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
+            const int nchunk = (round_up(j.cin_slab > 0 ? j.cin_slab : j.Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
             const size_t v4 = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK / 4;
             if (v4 > most) most = v4;
         }

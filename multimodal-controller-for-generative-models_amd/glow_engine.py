@@ -180,16 +180,14 @@ class GlowEngine:
         dt = self.dtype
         rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
         ops.prod_colsum(out, dout, cout, self._grad(zc.scale).view(-1), alpha=3.0)
-        gb = torch.empty(cout, dtype=torch.float32, device=dout.device)
         if seg_in is not None:
-            cin_p = seg_in.x.shape[-1]
-            gw = torch.empty((cout, cin_p, 3, 3), dtype=torch.float32, device=dout.device)
-            ops.wgrad(seg_in, dout, cout, cin_p, gw, bias_grad=gb)
-            self._grad(zc.conv.weight).copy_(gw[:, :cin] * rs[:, None, None, None])
+            # weight / bias gradients land in place: the split-K reduce scales row co by exp(3 * scale[co])
+            ops.wgrad(seg_in, dout, cout, cin, self._grad(zc.conv.weight), bias_grad=self._grad(zc.conv.bias), row_scale=rs)
         else:
+            gb = torch.empty(cout, dtype=torch.float32, device=dout.device)
             self._grad(zc.conv.weight).zero_()
             ops.colsum(dout, cout, gb)
-        self._grad(zc.conv.bias).copy_(gb * rs)
+            self._grad(zc.conv.bias).copy_(gb * rs)
         if not need_dx:
             return None, None
         wt = ops.prep_weight_ex(zc.conv.weight.detach(), dt, transpose=True, row_scale=rs, k_img=dout.shape[-1])
@@ -213,30 +211,24 @@ class GlowEngine:
         ops.actnorm_bwd(st5, an5.scale.detach(), 0.0, False, self._grad(an5.loc), self._grad(an5.scale))
         s5 = an5.scale.detach().reshape(-1)
         # 1x1 conv <- MC <- ReLU <- ActNorm(1)
-        gw = torch.empty((hid, hid), dtype=torch.float32, device=dev)
-        gb = torch.empty(hid, dtype=torch.float32, device=dev)
-        ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid, gw, bias_grad=gb)
-        self._grad(conv1.weight).copy_((gw * s5[:, None]).view_as(conv1.weight))
-        self._grad(conv1.bias).copy_(gb * s5)
+        ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid,
+                  self._grad(conv1.weight), bias_grad=self._grad(conv1.bias), row_scale=s5)
         w1t = ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5)
         v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], w1t, hid, ocode=codes[0], gate_x=r['h1'],
                                  gscale=r['a1'], gshift=r['b1'], gmean=-an1.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
         ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
         s1 = an1.scale.detach().reshape(-1)
         # 3x3 conv on the first c/2 channels of v; its input gradient joins the direct coupling gradient dv
-        gw0 = torch.empty((hid, cp, 3, 3), dtype=torch.float32, device=dev)
-        gb0 = torch.empty(hid, dtype=torch.float32, device=dev)
-        ops.wgrad(Seg(out), v1, hid, cp, gw0, bias_grad=gb0)
-        self._grad(conv0.weight).copy_(gw0[:, :c // 2] * s1[:, None, None, None])
-        self._grad(conv0.bias).copy_(gb0 * s1)
+        ops.wgrad(Seg(out), v1, hid, c // 2, self._grad(conv0.weight), bias_grad=self._grad(conv0.bias), row_scale=s1)
         w0t = ops.prep_weight_ex(conv0.weight.detach(), dt, transpose=True, row_scale=s1, rows_img=c)   # rows >= c/2: zero
         dvt, _ = ops.conv_fused([Seg(v1)], w0t, c, res=dv, cy=cp)
         # invertible 1x1 conv <- ActNorm
         an, ic = flow.actnorm, flow.invconv
         gW = torch.empty((c, cp), dtype=torch.float32, device=dev)
         ops.wgrad(Seg(x, ksize=1, scale=r['a'], shift=r['b']), dvt, c, cp, gW)
-        ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef,
-                        self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s))
+        gl, gu, gs = self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s)
+        # the LU-parameter gradients need the reduced dW: after the pass's batched split-K reduction
+        self._post.append(lambda: ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef, gl, gu, gs))
         s = an.scale.detach().reshape(-1)
         wmat = r['wmat']
         wt = ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp)                 # [ci, co] = W[co, ci] * s[ci]
@@ -251,6 +243,16 @@ class GlowEngine:
         """Fill `.grad` of every parameter with d(mean bits/dim)/d(parameter) from the tape of one forward."""
         m = self.m
         g0 = -1.0 / (n * math.log(2.) * n_pixel)
+        self._post = []
+        with ops.deferred_reduces():               # every split-K reduction of the pass: a handful of batched launches
+            dkeep = self._backward_body(tape, g0)
+        for f in self._post:
+            f()
+        self._post = []
+        return dkeep
+
+    def _backward_body(self, tape, g0: float):
+        m = self.m
         dkeep = None
         for blk, rec in reversed(list(zip(m.blocks, tape))):
             x, c = rec['x'], rec['c']

@@ -243,9 +243,12 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
 
 def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bool = False,
           alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None,
-          bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None, second=None):
+          bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None, second=None,
+          row_scale: Optional[Tensor] = None):
     """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment; optionally also the bias
     gradient bias_grad[Cout] (+)= alpha * sum_pixels dy (and a copy into bias_grad2).
+    `cin` may be smaller than the (padded) channel count of seg.x: only the first cin input channels are written.
+    `row_scale[Cout]` (optional) multiplies row co of the weight gradient and entry co of the bias gradients.
     `second` = (grad_b, bias_grad_b, bias_grad2_b): the batch is two halves (paired discriminator pass) and the
     second half's gradient goes to these tensors instead -- one launch, one slab set per half."""
     n = seg.x.shape[0]
@@ -308,10 +311,12 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         if _deferred is not None:
             if not gr.is_contiguous():
                 raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
-            _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha)))
+            _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha),
+                              row_scale, seg.x.shape[-1]))
         else:
             check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
-                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _stream()), 'wgrad_reduce')
+                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _f32(row_scale),
+                                         seg.x.shape[-1], _stream()), 'wgrad_reduce')
 
 
 _deferred = None
@@ -360,11 +365,12 @@ class deferred_reduces:
                 _side_keep.clear()
         if et is None and jobs:
             arr = (_lib.WReduce * len(jobs))()
-            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha) in zip(arr, jobs):
+            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha, rscale, cin_slab) in zip(arr, jobs):
                 a.slabs, a.grad, a.bias_slabs = _p(slabs), _f32(grad), _p(bs)
                 a.bias_grad, a.bias_grad2 = _f32(bg) if bs is not None else None, _f32(bg2) if bs is not None else None
                 a.splits, a.Cout, a.Cin, a.ksize, a.Cout_w = splits, cout, cin, ks, cout_w
                 a.row_perm, a.accumulate, a.alpha = row_perm, acc, alpha
+                a.row_scale, a.cin_slab = _f32(rscale), cin_slab
             check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch')
         return False
 
