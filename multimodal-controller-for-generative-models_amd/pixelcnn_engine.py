@@ -81,15 +81,20 @@ class PixelCNNEngine:
         sm = 1 if train else 0
         if L.mask_type == 'A':
             L.make_causal()                                   # zeroes the parameters in place, as the reference does
-        wv, wh = self._stack_weights(L)
         k2 = L.kernel // 2
         if L.kernel == 3:
+            # the (2 x 3) and (1 x 2) stacks sit at taps (0, 0) and (1, 0) of 3x3 images (zero elsewhere)
+            wv = wh = None
             in_v, in_h = Seg(x_v), Seg(x_h)
+            img_v = ops.prep_weight_ex(L.vert_stack.weight.detach(), dt, 3)
+            img_h = ops.prep_weight_ex(L.horiz_stack.weight.detach(), dt, 3, kh0=1)
         else:
+            wv, wh = self._stack_weights(L)
             in_v = Seg(ops.im2col(x_v, k2 + 1, L.kernel, k2, k2), ksize=1)
             in_h = Seg(ops.im2col(x_h, 1, k2 + 1, 0, k2), ksize=1)
-        h_vert, st_v = ops.conv_fused([in_v], ops.prep_weight(wv, dt), 2 * c, bias=L.vert_stack.bias.detach(), stats_mode=sm)
-        wimg = torch.cat([ops.prep_weight(L.vert_to_horiz.weight.detach(), dt), ops.prep_weight(wh, dt)])
+            img_v, img_h = ops.prep_weight(wv, dt), ops.prep_weight(wh, dt)
+        h_vert, st_v = ops.conv_fused([in_v], img_v, 2 * c, bias=L.vert_stack.bias.detach(), stats_mode=sm)
+        wimg = torch.cat([ops.prep_weight(L.vert_to_horiz.weight.detach(), dt), img_h])
         s, st_s = ops.conv_fused([Seg(h_vert, ksize=1), in_h], wimg, 2 * c,
                                  bias=L.vert_to_horiz.bias.detach() + L.horiz_stack.bias.detach(), stats_mode=sm)
         code_v, code_h = L.gate_v.mc.code_of_labels(label), L.gate_h.mc.code_of_labels(label)
@@ -137,13 +142,11 @@ class PixelCNNEngine:
         dt = self.dtype
         cout = conv.out_channels
         cin_p = seg_in.x.shape[-1]
-        gw = torch.empty((cout, cin_p), dtype=torch.float32, device=dy.device)
-        ops.wgrad(seg_in, dy, cout, cin_p, gw, bias_grad=self._grad(conv.bias))
-        self._grad(conv.weight).copy_(gw[:, :conv.in_channels].reshape(conv.weight.shape))
+        ops.wgrad(seg_in, dy, cout, conv.in_channels, self._grad(conv.weight), bias_grad=self._grad(conv.bias))
         if not need_dx:
             return None, None
-        wt = F.pad(_t1x1(conv.weight.detach()), (0, 0, 0, 0, 0, dy.shape[-1] - cout))
-        return ops.conv_fused([Seg(dy, ksize=1)], ops.prep_weight(wt.contiguous(), dt), conv.in_channels, **dgrad_kw)
+        wt = ops.prep_weight_ex(conv.weight.detach(), dt, transpose=True, k_img=dy.shape[-1])
+        return ops.conv_fused([Seg(dy, ksize=1)], wt, conv.in_channels, **dgrad_kw)
 
     def _layer_backward(self, L, r, g_v: Optional[Tensor], g_h: Tensor, need_dx: bool):
         """g_v / g_h: gradients w.r.t. this layer's (out_v, x_h').  Returns gradients w.r.t. (x_v, x_h)."""
@@ -157,40 +160,40 @@ class PixelCNNEngine:
         ds = ops.gated_bwd(r['s'], sc, sh, mean, rstd, r['code_h'], d_out_h, self._grad(L.gate_h.bn.weight), self._grad(L.gate_h.bn.bias))
         # s = vert_to_horiz(h_vert) + horiz_stack(x_h): both biases see sum(ds)
         c2 = 2 * c
-        gw = torch.empty((c2, c2), dtype=torch.float32, device=ds.device)
-        ops.wgrad(Seg(r['h_vert'], ksize=1), ds, c2, c2, gw, bias_grad=self._grad(L.vert_to_horiz.bias),
+        ops.wgrad(Seg(r['h_vert'], ksize=1), ds, c2, c2, self._grad(L.vert_to_horiz.weight), bias_grad=self._grad(L.vert_to_horiz.bias),
                   bias_grad2=self._grad(L.horiz_stack.bias))
-        self._grad(L.vert_to_horiz.weight).copy_(gw.reshape(L.vert_to_horiz.weight.shape))
         k2 = L.kernel // 2
         in_h = r['in_h']
         cin_h = in_h.x.shape[-1]
         gwh = torch.empty((c2, cin_h, in_h.ksize, in_h.ksize), dtype=torch.float32, device=ds.device)
         ops.wgrad(in_h, ds, c2, cin_h, gwh)
+        gh = self._grad(L.horiz_stack.weight)
         if L.kernel == 3:
-            self._grad(L.horiz_stack.weight).copy_(gwh[:, :, 1:2, 0:2])
+            self._post.append(lambda: gh.copy_(gwh[:, :, 1:2, 0:2]))
         else:
-            self._grad(L.horiz_stack.weight).copy_(gwh.reshape(c2, 1, k2 + 1, c).permute(0, 3, 1, 2))
+            self._post.append(lambda: gh.copy_(gwh.reshape(c2, 1, k2 + 1, c).permute(0, 3, 1, 2)))
         # gate_v and the vertical stack
         d_hv = None
         if g_v is not None:
             sc, sh, mean, rstd = r['bn_v']
             d_hv = ops.gated_bwd(r['h_vert'], sc, sh, mean, rstd, r['code_v'], g_v, self._grad(L.gate_v.bn.weight),
                                  self._grad(L.gate_v.bn.bias))
-        d_hv, _ = ops.conv_fused([Seg(ds, ksize=1)], ops.prep_weight(_t1x1(L.vert_to_horiz.weight.detach()), dt), c2, res=d_hv)
+        d_hv, _ = ops.conv_fused([Seg(ds, ksize=1)], ops.prep_weight_ex(L.vert_to_horiz.weight.detach(), dt, transpose=True), c2, res=d_hv)
         in_v = r['in_v']
         cin_v = in_v.x.shape[-1]
         gwv = torch.empty((c2, cin_v, in_v.ksize, in_v.ksize), dtype=torch.float32, device=ds.device)
         ops.wgrad(in_v, d_hv, c2, cin_v, gwv, bias_grad=self._grad(L.vert_stack.bias))
+        gv = self._grad(L.vert_stack.weight)
         if L.kernel == 3:
-            self._grad(L.vert_stack.weight).copy_(gwv[:, :, 0:2, :])
+            self._post.append(lambda: gv.copy_(gwv[:, :, 0:2, :]))
         else:
-            self._grad(L.vert_stack.weight).copy_(gwv.reshape(c2, k2 + 1, L.kernel, c).permute(0, 3, 1, 2))
+            self._post.append(lambda: gv.copy_(gwv.reshape(c2, k2 + 1, L.kernel, c).permute(0, 3, 1, 2)))
         if not need_dx:
             return None, None
         res_h = g_h if L.residual else None
         if L.kernel == 3:
-            d_xh, _ = ops.conv_fused([Seg(ds)], ops.prep_weight(_t3x3(r['wh']), dt), c, res=res_h)
-            d_xv, _ = ops.conv_fused([Seg(d_hv)], ops.prep_weight(_t3x3(r['wv']), dt), c)
+            d_xh, _ = ops.conv_fused([Seg(ds)], ops.prep_weight_ex(L.horiz_stack.weight.detach(), dt, 3, kh0=1, transpose=True), c, res=res_h)
+            d_xv, _ = ops.conv_fused([Seg(d_hv)], ops.prep_weight_ex(L.vert_stack.weight.detach(), dt, 3, transpose=True), c)
         else:
             dcol_h, _ = ops.conv_fused([Seg(ds, ksize=1)], ops.prep_weight(_t1x1(r['wh']), dt), r['wh'].shape[1])
             d_xh = ops.col2im(dcol_h, c, 1, k2 + 1, 0, k2)
@@ -202,6 +205,14 @@ class PixelCNNEngine:
 
     def backward(self, tape):
         """Fill the gradient of the mean cross-entropy for every parameter from the tape of one forward."""
+        self._post = []
+        with ops.deferred_reduces():               # every split-K reduction of the pass: a few batched launches
+            self._backward_body(tape)
+        for f in self._post:                       # slices of the 3x3-embedded stack gradients -> the (2x3)/(1x2) parameters
+            f()
+        self._post = []
+
+    def _backward_body(self, tape):
         m, dt = self.m, self.dtype
         oc = m.output_conv
         conv0, bn0, conv4 = oc[0].module, oc[1].module, oc[4].module
