@@ -243,7 +243,11 @@ int mcgen_channel_stats(const void* x, int dtype, int64_t pixels, int Cp, float*
 /* ActNorm.initialize (mcglow.py:32-39): loc = -mean, scale = 1 / (unbiased std + 1e-6) from such partials */
 int mcgen_actnorm_init(const float* partials, int tiles, int pitch, int C, double count, float* loc, float* scale, void* stream);
 /* ActNorm.forward as a conv prologue (mcglow.py:41-51): a = scale, b = scale * loc (zero beyond C) */
-int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b, void* stream);
+int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b,
+                         float* negloc /* optional: -loc, the gate mean of the backward */, void* stream);
+/* logdet[n] += HW * (sum_c log|scale_c| + sum_c w_s_c): the parameter-only log-determinants of one flow
+ * (ActNorm mcglow.py:46-47, InvConv2dLU mcglow.py:101) */
+int mcgen_glow_param_logdet(const float* scale, int C, const float* w_s, int Cw, float hw, float* logdet, int N, void* stream);
 /* InvConv2dLU.calc_weight (mcglow.py:105-111): W = P (L o mask + I) (U o mask + diag(sign * exp(w_s))), and
  * W^-1 (reverse, mcglow.py:113-116) when weight_inv != NULL; one workgroup, matrices in LDS, C <= 64 */
 int mcgen_invconv_weight(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,

@@ -75,7 +75,8 @@ SYMBOLS = {
     'mcgen_glow_squeeze': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_channel_stats': (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
     'mcgen_actnorm_init': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp]),
-    'mcgen_actnorm_affine': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'mcgen_actnorm_affine': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    'mcgen_glow_param_logdet': (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp]),
     'mcgen_invconv_weight': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'mcgen_glow_coupling': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_gaussian_logp': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -69,11 +69,22 @@ __global__ void actnorm_init_kernel(const float* __restrict__ part, int tiles, i
     scale[c] = (float)(1.0 / (sqrt(var) + 1e-6));
 }
 // prologue vectors of the op that consumes an ActNorm: y = s * (x + loc) = x * s + s * loc
-__global__ void actnorm_affine_kernel(const float* loc, const float* scale, int C, int Cp, float* a, float* b) {
+__global__ void actnorm_affine_kernel(const float* loc, const float* scale, int C, int Cp, float* a, float* b, float* negloc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cp) return;
     a[c] = c < C ? scale[c] : 0.f;
     b[c] = c < C ? scale[c] * loc[c] : 0.f;
+    if (negloc) negloc[c] = c < C ? -loc[c] : 0.f;       // "mean" of the backward gate: x - mean = x + loc
+}
+// parameter-only log-determinant of a flow (mcglow.py:46-47,101): logdet[n] += HW * (sum log|scale| + sum w_s), one launch
+__global__ void glow_param_logdet_kernel(const float* __restrict__ scale, int C, const float* __restrict__ ws, int Cw, float hw,
+                                         float* __restrict__ logdet, int N) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) s += logf(fabsf(scale[i]));
+    for (int i = threadIdx.x; i < Cw; i += blockDim.x) s += ws[i];
+    s = block_sum_g(s, red);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) logdet[n] += hw * s;
 }
 
 // ---- InvConv2dLU.calc_weight (mcglow.py:105-111) and its inverse, one workgroup, C <= 64 -----------------------
@@ -409,10 +420,15 @@ extern "C" int mcgen_actnorm_init(const float* partials, int tiles, int pitch, i
     hipLaunchKernelGGL(actnorm_init_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), partials, tiles, pitch, C, count, loc, scale);
     MCGEN_LAUNCH_CHECK("actnorm_init"); return 0;
 }
-extern "C" int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b, void* stream) {
+extern "C" int mcgen_actnorm_affine(const float* loc, const float* scale, int C, int Cp, float* a, float* b, float* negloc, void* stream) {
     MCGEN_CHECK(loc && scale && a && b && Cp >= C, "actnorm_affine: bad arguments");
-    hipLaunchKernelGGL(actnorm_affine_kernel, dim3((Cp + 63) / 64), dim3(64), 0, STREAM(stream), loc, scale, C, Cp, a, b);
+    hipLaunchKernelGGL(actnorm_affine_kernel, dim3((Cp + 63) / 64), dim3(64), 0, STREAM(stream), loc, scale, C, Cp, a, b, negloc);
     MCGEN_LAUNCH_CHECK("actnorm_affine"); return 0;
+}
+extern "C" int mcgen_glow_param_logdet(const float* scale, int C, const float* w_s, int Cw, float hw, float* logdet, int N, void* stream) {
+    MCGEN_CHECK(scale && w_s && logdet && C > 0 && Cw > 0 && N > 0, "glow_param_logdet: bad arguments");
+    hipLaunchKernelGGL(glow_param_logdet_kernel, dim3(1), dim3(256), 0, STREAM(stream), scale, C, w_s, Cw, hw, logdet, N);
+    MCGEN_LAUNCH_CHECK("glow_param_logdet"); return 0;
 }
 
 extern "C" int mcgen_invconv_weight(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,

@@ -47,7 +47,7 @@ class GlowEngine:
         if train and not self.assume_initialized and int(an.initialized) == 0:
             ops.actnorm_init(x_stats_fn(), count, an.loc.data, an.scale.data)
             an.initialized.fill_(1)
-        return ops.actnorm_affine(an.loc.data, an.scale.data, cp)
+        return ops.actnorm_affine(an.loc.data, an.scale.data, cp, with_negloc=True)
 
     def _zero_conv_image(self, zc, cin_pad: int):
         """ZeroConv2d (mcglow.py:119-130) as weight image + bias with exp(3*scale) folded into the rows."""
@@ -67,30 +67,30 @@ class GlowEngine:
         h1, st1 = ops.conv_fused([Seg(x)], ops.prep_weight_ex(conv0.weight.detach(), dt, k_img=cp), conv0.out_channels, bias=conv0.bias,
                                  stats_mode=1 if need1 else 0)
         hid = conv0.out_channels
-        a1, b1 = self._actnorm(an1, lambda: st1, count, train, hid)
+        a1, b1, nl1 = self._actnorm(an1, lambda: st1, count, train, hid)
         need5 = train and not self.assume_initialized and int(an5.initialized) == 0
         h2, st2 = ops.conv_fused([Seg(h1, ksize=1, scale=a1, shift=b1, relu=True, code=codes[0])],
                                  ops.prep_weight(conv1.weight.detach(), dt), hid, bias=conv1.bias,
                                  stats_mode=1 if need5 else 0)
-        a5, b5 = self._actnorm(an5, lambda: st2, count, train, hid)
+        a5, b5, nl5 = self._actnorm(an5, lambda: st2, count, train, hid)
         wz, bz = self._zero_conv_image(zc, hid)
         hz, _ = ops.conv_fused([Seg(h2, scale=a5, shift=b5, relu=True, code=codes[1])], wz, c, bias=bz, cy=cp)
         if saved is not None:
-            saved.update(h1=h1, h2=h2, a1=a1, b1=b1, a5=a5, b5=b5)
+            saved.update(h1=h1, h2=h2, a1=a1, b1=b1, a5=a5, b5=b5, nl1=nl1, nl5=nl5)
         return hz
 
     def _flow_forward(self, flow, x: Tensor, c: int, indicator: Tensor, logdet: Tensor, train: bool, tape=None, label=None) -> Tensor:
         dt = self.dtype
         n, h, w, cp = x.shape
-        a, b = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
+        a, b, nl = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
         ic = flow.invconv
         wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
         out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)], ops.prep_weight_ex(wmat, dt, 1, k_img=cp), c, cy=cp)
         # parameter-only log-determinants: H*W * (sum log|scale| + sum w_s)   (mcglow.py:46-47,101)
-        logdet += (h * w) * (torch.log(torch.abs(flow.actnorm.scale.detach())).sum() + ic.w_s.detach().sum())
+        ops.glow_param_logdet(flow.actnorm.scale.detach(), ic.w_s.detach(), h * w, logdet)
         net = flow.coupling.net
         codes = self._codes(net, indicator, label)
-        rec = None if tape is None else dict(x=x, a=a, b=b, out=out, codes=codes, wmat=wmat)
+        rec = None if tape is None else dict(x=x, a=a, b=b, nl=nl, out=out, codes=codes, wmat=wmat)
         hz = self._coupling_net(net, out, c, codes, train, rec)
         if tape is not None:
             rec['hz'] = hz
@@ -207,7 +207,7 @@ class GlowEngine:
         # ZeroConv2d <- MC <- ReLU <- ActNorm(5)
         v5, st5 = self._zero_conv_bwd(zc, Seg(r['h2'], scale=r['a5'], shift=r['b5'], relu=True, code=codes[1]), hz, dhz, c, hid,
                                       True, ocode=codes[1], gate_x=r['h2'], gscale=r['a5'], gshift=r['b5'],
-                                      gmean=-an5.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
+                                      gmean=r['nl5'], grstd=ones, stats_mode=2)
         ops.actnorm_bwd(st5, an5.scale.detach(), 0.0, False, self._grad(an5.loc), self._grad(an5.scale))
         s5 = an5.scale.detach().reshape(-1)
         # 1x1 conv <- MC <- ReLU <- ActNorm(1)
@@ -215,7 +215,7 @@ class GlowEngine:
                   self._grad(conv1.weight), bias_grad=self._grad(conv1.bias), row_scale=s5)
         w1t = ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5)
         v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], w1t, hid, ocode=codes[0], gate_x=r['h1'],
-                                 gscale=r['a1'], gshift=r['b1'], gmean=-an1.loc.detach().reshape(-1), grstd=ones, stats_mode=2)
+                                 gscale=r['a1'], gshift=r['b1'], gmean=r['nl1'], grstd=ones, stats_mode=2)
         ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
         s1 = an1.scale.detach().reshape(-1)
         # 3x3 conv on the first c/2 channels of v; its input gradient joins the direct coupling gradient dv
@@ -234,7 +234,7 @@ class GlowEngine:
         wt = ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp)                 # [ci, co] = W[co, ci] * s[ci]
         dx, st = ops.conv_fused([Seg(dvt, ksize=1)], wt, c, cy=cp, gate_x=x,
                                 gscale=self._full(0.0, c, dev), gshift=self._full(1.0, c, dev),
-                                gmean=-an.loc.detach().reshape(-1), grstd=self._full(1.0, c, dev),
+                                gmean=r['nl'], grstd=self._full(1.0, c, dev),
                                 stats_mode=2)
         ops.actnorm_bwd(st, an.scale.detach(), ld_coef, True, self._grad(an.loc), self._grad(an.scale))
         return dx

@@ -620,12 +620,19 @@ def actnorm_init(partials: Tensor, count: int, loc: Tensor, scale: Tensor):
                                          _stream()), 'actnorm_init')
 
 
-def actnorm_affine(loc: Tensor, scale: Tensor, cp: int):
+def actnorm_affine(loc: Tensor, scale: Tensor, cp: int, with_negloc: bool = False):
+    """Prologue vectors of the op that consumes an ActNorm: y = x * a + b with a = scale, b = scale * loc (zero-padded to
+    cp); with_negloc also returns -loc (the gate mean of the backward pass)."""
     c = loc.numel()
-    ab = torch.empty((2, cp), dtype=torch.float32, device=loc.device)
-    check(_lib.load().mcgen_actnorm_affine(_f32(loc), _f32(scale), c, cp, ab[0].data_ptr(), ab[1].data_ptr(), _stream()),
-          'actnorm_affine')
-    return ab[0], ab[1]
+    ab = torch.empty((3 if with_negloc else 2, cp), dtype=torch.float32, device=loc.device)
+    check(_lib.load().mcgen_actnorm_affine(_f32(loc), _f32(scale), c, cp, ab[0].data_ptr(), ab[1].data_ptr(),
+                                           ab[2].data_ptr() if with_negloc else None, _stream()), 'actnorm_affine')
+    return (ab[0], ab[1], ab[2]) if with_negloc else (ab[0], ab[1])
+
+
+def glow_param_logdet(scale: Tensor, w_s: Tensor, hw: int, logdet: Tensor):
+    check(_lib.load().mcgen_glow_param_logdet(_f32(scale), scale.numel(), _f32(w_s), w_s.numel(), float(hw), _f32(logdet),
+                                              logdet.numel(), _stream()), 'glow_param_logdet')
 
 
 def invconv_weight(w_p, w_l, w_u, w_s, s_sign, inverse: bool = False):
