@@ -1405,7 +1405,8 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (big128 > 0 && M >= big128 && rows256 && p->Cout_w > 64) return {256, 128, 5};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, m128};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, m128w};
-    if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
+    static const long t64x128 = getenv("MCGEN_CONV_T64X128") ? atol(getenv("MCGEN_CONV_T64X128")) : 32768;
+    if (M >= t64x128 && p->Cout_w > 64) return {64, 128, 5};
     // The 8-wave forms of this tile (modes 10 / 11) are ~15 % faster on 8x8 maps and bit-identical in their outputs,
     // but their BatchNorm partial sums round differently and the bf16 full-size digest run then drifts 0.1 in the
     // second-iteration G loss (tools/digest_probe.py) -- not understood yet, so the 4-wave form stays the default.

@@ -38,50 +38,61 @@ class _PixelFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(sink[id(p)] * gloss if id(p) in sink else None for p in ctx.params)
 
 
+def _controller(width, modes, rate):
+    return MultimodalController(width, modes, rate)
+
+
 class MCGatedActivation(nn.Module):
-    """mcpixelcnn.py:9-20."""
+    """mcpixelcnn.py:9-20 -- parameter container of one gate: ``bn`` over the first half of the 2C input, ``mc`` on the
+    gated product (the arithmetic is mcgen_gated_fwd / _bwd)."""
 
     def __init__(self, hidden_size, num_mode, controller_rate):
         super().__init__()
-        self.bn = nn.BatchNorm2d(hidden_size)
-        self.activation = nn.ReLU(inplace=True)
-        self.mc = MultimodalController(hidden_size, num_mode, controller_rate)
+        self.bn, self.activation = nn.BatchNorm2d(hidden_size), nn.ReLU(inplace=True)
+        self.mc = _controller(hidden_size, num_mode, controller_rate)
 
 
 class MCGatedMaskedConv2d(nn.Module):
-    """mcpixelcnn.py:23-61."""
+    """mcpixelcnn.py:23-61 -- one gated layer: a vertical stack (k//2+1 rows x k columns, rows above and including the
+    current one), a horizontal stack (1 x k//2+1, columns up to the current one), the 1x1 vertical-to-horizontal link,
+    two gates and the 1x1 -> BN -> MC residual branch of the horizontal stream."""
 
     def __init__(self, mask_type, hidden_size, kernel, residual, num_mode, controller_rate):
         super().__init__()
         if kernel % 2 != 1:
             raise ValueError('Not valid kernel size: must be odd')
         self.mask_type, self.residual, self.kernel, self.hidden_size = mask_type, residual, kernel, hidden_size
-        self.vert_stack = nn.Conv2d(hidden_size, 2 * hidden_size, (kernel // 2 + 1, kernel), 1, (kernel // 2, kernel // 2))
-        self.vert_to_horiz = nn.Conv2d(2 * hidden_size, 2 * hidden_size, 1)
-        self.horiz_stack = nn.Conv2d(hidden_size, 2 * hidden_size, (1, kernel // 2 + 1), 1, (0, kernel // 2))
-        self.gate_v = MCGatedActivation(hidden_size, num_mode, controller_rate)
-        self.gate_h = MCGatedActivation(hidden_size, num_mode, controller_rate)
-        self.horiz_resid = nn.Sequential(Wrapper(nn.Conv2d(hidden_size, hidden_size, 1)), Wrapper(nn.BatchNorm2d(hidden_size)),
-                                         MultimodalController(hidden_size, num_mode, controller_rate))
+        half, c, c2 = kernel // 2, hidden_size, 2 * hidden_size
+        self.vert_stack = nn.Conv2d(c, c2, kernel_size=(half + 1, kernel), stride=1, padding=(half, half))
+        self.vert_to_horiz = nn.Conv2d(c2, c2, kernel_size=1)
+        self.horiz_stack = nn.Conv2d(c, c2, kernel_size=(1, half + 1), stride=1, padding=(0, half))
+        self.gate_v, self.gate_h = (MCGatedActivation(c, num_mode, controller_rate) for _ in range(2))
+        self.horiz_resid = nn.Sequential(Wrapper(nn.Conv2d(c, c, kernel_size=1)), Wrapper(nn.BatchNorm2d(c)),
+                                         _controller(c, num_mode, controller_rate))
 
     def make_causal(self):
-        self.vert_stack.weight.data[:, :, -1].zero_()          # mask the final row
-        self.horiz_stack.weight.data[:, :, :, -1].zero_()      # mask the final column
+        """Mask 'A' (mcpixelcnn.py:43-45): the current row of the vertical stack and the current column of the
+        horizontal stack are zeroed IN THE PARAMETERS, on every forward of the first layer."""
+        with torch.no_grad():
+            self.vert_stack.weight[:, :, -1].zero_()
+            self.horiz_stack.weight[:, :, :, -1].zero_()
 
 
 class MCGatedPixelCNN(nn.Module):
-    """mcpixelcnn.py:64-112."""
+    """mcpixelcnn.py:64-112 -- embedding of the code map, one 7x7 mask-A layer without residual, 3x3 mask-B layers with
+    residual, a two-layer 1x1 head over 512 channels."""
 
     def __init__(self, input_size=256, hidden_size=64, num_layer=15, num_mode=10, controller_rate=0.5):
         super().__init__()
         self.input_size, self.hidden_size = input_size, hidden_size
         self.embedding = nn.Embedding(input_size, hidden_size)
-        self.layers = nn.ModuleList(
-            MCGatedMaskedConv2d('A' if i == 0 else 'B', hidden_size, 7 if i == 0 else 3, i != 0, num_mode, controller_rate)
-            for i in range(num_layer))
-        self.output_conv = nn.Sequential(
-            Wrapper(nn.Conv2d(hidden_size, 512, 1)), Wrapper(nn.BatchNorm2d(512)), Wrapper(nn.ReLU(inplace=True)),
-            MultimodalController(512, num_mode, controller_rate), Wrapper(nn.Conv2d(512, input_size, 1)))
+        first = MCGatedMaskedConv2d('A', hidden_size, 7, False, num_mode, controller_rate)
+        rest = [MCGatedMaskedConv2d('B', hidden_size, 3, True, num_mode, controller_rate) for _ in range(num_layer - 1)]
+        self.layers = nn.ModuleList([first] + rest)
+        head = 512
+        self.output_conv = nn.Sequential(Wrapper(nn.Conv2d(hidden_size, head, kernel_size=1)), Wrapper(nn.BatchNorm2d(head)),
+                                         Wrapper(nn.ReLU(inplace=True)), _controller(head, num_mode, controller_rate),
+                                         Wrapper(nn.Conv2d(head, input_size, kernel_size=1)))
 
     def _engine(self):
         eng = self.__dict__.get('_eng')

@@ -37,56 +37,70 @@ class _VAEFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(sink[id(p)] * gloss if id(p) in sink else None for p in ctx.params)
 
 
+def _mc(width, modes, rate):
+    return MultimodalController(width, modes, rate)
+
+
+def _wrapped(*layers):
+    """Plain torch layers inside the reference's list-protocol ``Wrapper`` (parameter containers only here)."""
+    return [Wrapper(layer) for layer in layers]
+
+
+def _stage(conv, width, modes, rate):
+    """conv -> BatchNorm2d -> ReLU -> MC: the four entries one encoder / decoder stage adds to ``blocks``."""
+    return _wrapped(conv, nn.BatchNorm2d(width), nn.ReLU(inplace=True)) + [_mc(width, modes, rate)]
+
+
+def _encoded_shape(data_shape, widths):
+    shrink = 2 ** len(widths)
+    return (widths[-1], data_shape[1] // shrink, data_shape[2] // shrink)
+
+
 class ResBlock(nn.Module):
-    """mcvae.py:17-35."""
+    """mcvae.py:17-35 -- ``conv`` holds conv, BN, ReLU, MC, conv, BN, MC (indices 0..6); the skip + ReLU live in
+    the fused tail kernel."""
 
     def __init__(self, hidden_size, num_mode, controller_rate):
         super().__init__()
-        self.conv = nn.Sequential(
-            Wrapper(nn.Conv2d(hidden_size, hidden_size, 3, 1, 1)), Wrapper(nn.BatchNorm2d(hidden_size)),
-            Wrapper(nn.ReLU(inplace=True)), MultimodalController(hidden_size, num_mode, controller_rate),
-            Wrapper(nn.Conv2d(hidden_size, hidden_size, 3, 1, 1)), Wrapper(nn.BatchNorm2d(hidden_size)),
-            MultimodalController(hidden_size, num_mode, controller_rate))
+        w = hidden_size
+        first = _stage(nn.Conv2d(w, w, 3, 1, 1), w, num_mode, controller_rate)
+        second = _wrapped(nn.Conv2d(w, w, 3, 1, 1), nn.BatchNorm2d(w)) + [_mc(w, num_mode, controller_rate)]
+        self.conv = nn.Sequential(*(first + second))
         self.activation = Wrapper(nn.ReLU(inplace=True))
 
 
 class Encoder(nn.Module):
-    """mcvae.py:38-68."""
+    """mcvae.py:38-68 -- ``blocks``: len(hidden) strided stages, then the residual blocks; ``mu`` / ``logvar`` heads."""
 
     def __init__(self, data_shape, hidden_size, latent_size, num_res_block, num_mode, controller_rate):
         super().__init__()
-        blocks = []
-        cin = data_shape[0]
-        for h in hidden_size:
-            blocks.extend([Wrapper(nn.Conv2d(cin, h, 4, 2, 1)), Wrapper(nn.BatchNorm2d(h)), Wrapper(nn.ReLU(inplace=True)),
-                           MultimodalController(h, num_mode, controller_rate)])
-            cin = h
-        for _ in range(num_res_block):
-            blocks.append(ResBlock(hidden_size[-1], num_mode, controller_rate))
-        self.blocks = nn.Sequential(*blocks)
-        self.encoded_shape = (hidden_size[-1], data_shape[1] // (2 ** len(hidden_size)), data_shape[2] // (2 ** len(hidden_size)))
-        self.mu = nn.Linear(int(np.prod(self.encoded_shape)), latent_size)
-        self.logvar = nn.Linear(int(np.prod(self.encoded_shape)), latent_size)
+        layers, width_in = [], data_shape[0]
+        for width in hidden_size:
+            layers += _stage(nn.Conv2d(width_in, width, 4, 2, 1), width, num_mode, controller_rate)
+            width_in = width
+        layers += [ResBlock(width_in, num_mode, controller_rate) for _ in range(num_res_block)]
+        self.blocks = nn.Sequential(*layers)
+        self.encoded_shape = _encoded_shape(data_shape, hidden_size)
+        features = int(np.prod(self.encoded_shape))
+        self.mu, self.logvar = nn.Linear(features, latent_size), nn.Linear(features, latent_size)
 
 
 class Decoder(nn.Module):
-    """mcvae.py:71-101."""
+    """mcvae.py:71-101 -- ``linear``: MC, Linear, BatchNorm1d, ReLU; ``blocks``: MC, residual blocks, transposed-conv
+    stages up to the image, Sigmoid."""
 
     def __init__(self, data_shape, hidden_size, latent_size, num_res_block, num_mode, controller_rate):
         super().__init__()
-        self.encoded_shape = (hidden_size[-1], data_shape[1] // (2 ** len(hidden_size)), data_shape[2] // (2 ** len(hidden_size)))
-        feat = int(np.prod(self.encoded_shape))
-        self.linear = nn.Sequential(MultimodalController(latent_size, num_mode, controller_rate), Wrapper(nn.Linear(latent_size, feat)),
-                                    Wrapper(nn.BatchNorm1d(feat)), Wrapper(nn.ReLU(inplace=True)))
-        blocks = [MultimodalController(hidden_size[-1], num_mode, controller_rate)]
-        for _ in range(num_res_block):
-            blocks.append(ResBlock(hidden_size[-1], num_mode, controller_rate))
-        for i in range(len(hidden_size) - 1, 0, -1):
-            blocks.extend([Wrapper(nn.ConvTranspose2d(hidden_size[i], hidden_size[i - 1], 4, 2, 1)),
-                           Wrapper(nn.BatchNorm2d(hidden_size[i - 1])), Wrapper(nn.ReLU(inplace=True)),
-                           MultimodalController(hidden_size[i - 1], num_mode, controller_rate)])
-        blocks.extend([Wrapper(nn.ConvTranspose2d(hidden_size[0], data_shape[0], 4, 2, 1)), Wrapper(nn.Sigmoid())])
-        self.blocks = nn.Sequential(*blocks)
+        self.encoded_shape = _encoded_shape(data_shape, hidden_size)
+        features = int(np.prod(self.encoded_shape))
+        self.linear = nn.Sequential(_mc(latent_size, num_mode, controller_rate),
+                                    *_wrapped(nn.Linear(latent_size, features), nn.BatchNorm1d(features), nn.ReLU(inplace=True)))
+        top = hidden_size[-1]
+        layers = [_mc(top, num_mode, controller_rate)] + [ResBlock(top, num_mode, controller_rate) for _ in range(num_res_block)]
+        for wide, narrow in zip(reversed(hidden_size[1:]), reversed(hidden_size[:-1])):
+            layers += _stage(nn.ConvTranspose2d(wide, narrow, 4, 2, 1), narrow, num_mode, controller_rate)
+        layers += _wrapped(nn.ConvTranspose2d(hidden_size[0], data_shape[0], 4, 2, 1), nn.Sigmoid())
+        self.blocks = nn.Sequential(*layers)
 
 
 class MCVAE(nn.Module):
