@@ -1407,10 +1407,11 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, m128w};
     static const long t64x128 = getenv("MCGEN_CONV_T64X128") ? atol(getenv("MCGEN_CONV_T64X128")) : 32768;
     if (M >= t64x128 && p->Cout_w > 64) return {64, 128, 5};
-    // The 8-wave forms of this tile (modes 10 / 11) are ~15 % faster on 8x8 maps and bit-identical in their outputs,
-    // but their BatchNorm partial sums round differently and the bf16 full-size digest run then drifts 0.1 in the
-    // second-iteration G loss (tools/digest_probe.py) -- not understood yet, so the 4-wave form stays the default.
-    int small_mode = 5;
+    // 64x64 tile on 8 waves (4 x 2): ~15 % faster than 4 waves on 8x8 maps, bit-identical outputs.  (Its BatchNorm partial
+    // sums round differently in the last bit, which once looked like a defect: the bf16 full-size digest run is bimodal
+    // in its second-iteration G loss -- 1.81 or 1.70 -- under ANY 1e-7 nudge of the batch sums, see tools/digest_probe.py
+    // with MCGEN_BN_PERTURB.)
+    int small_mode = 11;
     if (const char* e = getenv("MCGEN_CONV_SMALL")) small_mode = atoi(e);       // tuning override for the 64x64 fallback
     return {64, 64, small_mode};
 }

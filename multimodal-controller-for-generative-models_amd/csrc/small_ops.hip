@@ -205,12 +205,13 @@ __global__ __launch_bounds__(64 * RED_WAVES)
 void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
                         const float* __restrict__ gamma, const float* __restrict__ beta,
                         float* rmean, float* rvar, float momentum, float eps,
-                        float* scale, float* shift, float* mean_o, float* rstd_o) {
+                        float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
     __shared__ double sh[RED_WAVES][2][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s1, s2;
     reduce_partials(part, tiles * fold, pitch, fold, C, c, c < C, s1, s2, sh);
     if (threadIdx.x >= 64 || c >= C) return;
+    s1 *= perturb1; s2 *= perturb2;                      // 1.0 unless the sensitivity probe (MCGEN_BN_PERTURB) is on
     const double mean = s1 / count;
     double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -611,13 +612,16 @@ extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dty
     MCGEN_LAUNCH_CHECK("mc_apply"); return 0;
 }
 
+// sensitivity probe (tools/digest_probe.py): MCGEN_BN_PERTURB=1e-7 nudges the batch sums by that relative amount
+static double bn_perturb() { static const double v = getenv("MCGEN_BN_PERTURB") ? atof(getenv("MCGEN_BN_PERTURB")) : 0.0; return v; }
 extern "C" int mcgen_bn_finalize(const float* partials, int tiles, int pitch, int fold, int C, double count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
                 "bn_finalize: bad arguments");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
+                       1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
     MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
 }
 extern "C" int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
