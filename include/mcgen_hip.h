@@ -150,6 +150,16 @@ int mcgen_prep_weight_rows(const float* w, void* image, int dtype, int Cout, int
 int mcgen_prep_weight_ex(const float* w, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int Cout, int Cin,
                          int KH, int KW, int kh0, int kw0, int ksize, int transpose, int rows_img, int k_img,
                          const float* row_scale, const float* col_scale, float wscale, void* image, int dtype, void* stream);
+/* many generalised images in a few launches (jobs travel by value in the kernel arguments, 16 per launch) */
+#define MCGEN_PREPEX_MAX 16
+typedef struct {
+    const float* w; int64_t s_co, s_ci, s_kh, s_kw;
+    int32_t Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img;
+    const float* row_scale; const float* col_scale;
+    void*   image;
+    float   wscale; int32_t _pad;
+} mcgen_prepex_t;
+int mcgen_prep_weight_ex_batch(const mcgen_prepex_t* jobs, int n, int dtype, void* stream);
 /* the same for all layers of a network pass in ONE launch; sigma = sigma_base[sigma_idx] (idx < 0: none) */
 typedef struct {
     const float* w; void* image;

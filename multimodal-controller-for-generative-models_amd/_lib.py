@@ -42,6 +42,13 @@ class WReduce(C.Structure):
                 ('row_scale', C.c_void_p), ('cin_slab', C.c_int32), ('_pad', C.c_int32)]
 
 
+class PrepEx(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('s_co', C.c_int64), ('s_ci', C.c_int64), ('s_kh', C.c_int64), ('s_kw', C.c_int64),
+                ('Cout', C.c_int32), ('Cin', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('kh0', C.c_int32), ('kw0', C.c_int32),
+                ('ksize', C.c_int32), ('transpose', C.c_int32), ('rows_img', C.c_int32), ('k_img', C.c_int32),
+                ('row_scale', C.c_void_p), ('col_scale', C.c_void_p), ('image', C.c_void_p), ('wscale', C.c_float), ('_pad', C.c_int32)]
+
+
 class Prep(C.Structure):
     _fields_ = [('w', C.c_void_p), ('image', C.c_void_p),
                 ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('transpose', C.c_int32),
@@ -100,6 +107,7 @@ SYMBOLS = {
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),
     'mcgen_prep_weight_ex': (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp]),
+    'mcgen_prep_weight_ex_batch': (_i, [_vp, _i, _i, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -76,13 +76,9 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // image (other taps zero), optional per-output-channel / per-input-channel scales of the SOURCE, forward or transposed
 // (+ flipped) orientation, and explicit image extents (rows_img x k_img; zero outside the source).  One launch replaces
 // the pad / flip / transpose / scale tensor ops that otherwise precede mcgen_prep_weight.
-struct PrepEx {
-    const float* w; long s_co, s_ci, s_kh, s_kw;
-    int Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img;
-    const float* row_scale; const float* col_scale; float wscale;
-};
+typedef mcgen_prepex_t PrepEx;
 template <typename T>
-__global__ void prep_weight_ex_kernel(const PrepEx d, T* __restrict__ img) {
+__device__ __forceinline__ void prep_weight_ex_body(const PrepEx& d, T* __restrict__ img) {
     const int ntap = d.ksize * d.ksize;
     const int rows_w = (d.rows_img + 15) / 16 * 16;
     const int nchunk = (((d.k_img + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
@@ -106,6 +102,15 @@ __global__ void prep_weight_ex_kernel(const PrepEx d, T* __restrict__ img) {
         }
         img[i] = Elem<T>::from_f(v);
     }
+}
+template <typename T>
+__global__ void prep_weight_ex_kernel(const PrepEx d, T* __restrict__ img) { prep_weight_ex_body<T>(d, img); }
+// up to MCGEN_PREPEX_MAX images per launch: blockIdx.y picks the job, the table travels by value (graph-capture safe)
+struct PrepExJobs { PrepEx j[MCGEN_PREPEX_MAX]; };
+template <typename T>
+__global__ void prep_weight_ex_batch_kernel(const PrepExJobs jobs) {
+    const PrepEx& d = jobs.j[blockIdx.y];
+    prep_weight_ex_body<T>(d, reinterpret_cast<T*>(d.image));
 }
 
 // all weight images of a network pass in one launch: blockIdx.y = descriptor
@@ -564,12 +569,36 @@ extern "C" int mcgen_prep_weight_ex(const float* w, int64_t s_co, int64_t s_ci, 
     MCGEN_CHECK(w && image && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (ksize == 1 || ksize == 3) && rows_img > 0 && k_img > 0,
                 "prep_weight_ex: bad arguments");
     MCGEN_CHECK(kh0 >= 0 && kw0 >= 0 && kh0 + KH <= ksize && kw0 + KW <= ksize, "prep_weight_ex: source taps do not fit the image");
-    PrepEx d{w, s_co, s_ci, s_kh, s_kw, Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img, row_scale, col_scale, wscale};
+    PrepEx d{w, s_co, s_ci, s_kh, s_kw, Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img, row_scale, col_scale, image, wscale, 0};
     const size_t total = (size_t)mcgen_weight_image_elems(transpose ? k_img : rows_img, transpose ? rows_img : k_img, ksize, transpose);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(prep_weight_ex_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), d, (float*)image),
         hipLaunchKernelGGL(prep_weight_ex_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), d, (bf16_t*)image));
     MCGEN_LAUNCH_CHECK("prep_weight_ex"); return 0;
+}
+
+extern "C" int mcgen_prep_weight_ex_batch(const mcgen_prepex_t* jobs, int n, int dtype, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "prep_weight_ex_batch: bad arguments");
+    for (int base = 0; base < n; base += MCGEN_PREPEX_MAX) {
+        const int m = (n - base < MCGEN_PREPEX_MAX) ? n - base : MCGEN_PREPEX_MAX;
+        PrepExJobs t;
+        size_t most = 1;
+        for (int i = 0; i < m; ++i) {
+            const mcgen_prepex_t& j = jobs[base + i];
+            MCGEN_CHECK(j.w && j.image && j.Cout > 0 && j.Cin > 0 && j.KH > 0 && j.KW > 0 && (j.ksize == 1 || j.ksize == 3) && j.rows_img > 0 && j.k_img > 0 &&
+                        j.kh0 >= 0 && j.kw0 >= 0 && j.kh0 + j.KH <= j.ksize && j.kw0 + j.KW <= j.ksize, "prep_weight_ex_batch: bad job %d", base + i);
+            t.j[i] = j;
+            const size_t e = (size_t)mcgen_weight_image_elems(j.rows_img, j.k_img, j.ksize, 0);
+            if (e > most) most = e;
+        }
+        for (int i = m; i < MCGEN_PREPEX_MAX; ++i) t.j[i] = t.j[0];
+        const int blocks = grid_for(most, 256, 512);
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(prep_weight_ex_batch_kernel<float>, dim3(blocks, m), dim3(256), 0, STREAM(stream), t),
+            hipLaunchKernelGGL(prep_weight_ex_batch_kernel<bf16_t>, dim3(blocks, m), dim3(256), 0, STREAM(stream), t));
+        MCGEN_LAUNCH_CHECK("prep_weight_ex_batch");
+    }
+    return 0;
 }
 
 extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,

@@ -878,3 +878,34 @@ def prep_weight_ex(w: Tensor, dtype: torch.dtype, ksize: Optional[int] = None, *
                                            rows, kk, _f32(row_scale), _f32(col_scale), float(wscale), _p(out), _dt(dtype), _stream()),
           'prep_weight_ex')
     return out
+
+
+def prep_weight_ex_many(jobs, dtype: torch.dtype):
+    """Several prep_weight_ex images in ceil(n / 16) launches.  `jobs`: list of (w, kwargs) with the keyword arguments of
+    prep_weight_ex (ksize, kh0, kw0, transpose, row_scale, col_scale, rows_img, k_img, wscale).  Returns the images."""
+    if not jobs:
+        return []
+    arr = (_lib.PrepEx * len(jobs))()
+    outs, keep = [], []
+    for a, (w, kw) in zip(arr, jobs):
+        if w.dtype != torch.float32 or not w.is_cuda:
+            raise _lib.McgenError('prep_weight_ex_many: float32 device tensors expected')
+        cout, cin = w.shape[0], w.shape[1]
+        kh, kwid = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+        st = w.stride()
+        transpose = bool(kw.get('transpose', False))
+        ks = kw.get('ksize') or kh
+        rows = kw.get('rows_img') or (cin if transpose else cout)
+        kk = kw.get('k_img') or (cout if transpose else cin)
+        out = torch.empty(weight_image_elems(rows, kk, ks, False), dtype=dtype, device=w.device)
+        a.w, a.s_co, a.s_ci = w.data_ptr(), st[0], st[1]
+        a.s_kh, a.s_kw = (st[2], st[3]) if w.dim() == 4 else (0, 0)
+        a.Cout, a.Cin, a.KH, a.KW = cout, cin, kh, kwid
+        a.kh0, a.kw0, a.ksize, a.transpose = kw.get('kh0', 0), kw.get('kw0', 0), ks, int(transpose)
+        a.rows_img, a.k_img = rows, kk
+        rs, cs = kw.get('row_scale'), kw.get('col_scale')
+        a.row_scale, a.col_scale, a.image, a.wscale = _f32(rs), _f32(cs), _p(out), float(kw.get('wscale', 1.0))
+        outs.append(out)
+        keep += [w, rs, cs]
+    check(_lib.load().mcgen_prep_weight_ex_batch(arr, len(jobs), _dt(dtype), _stream()), 'prep_weight_ex_batch')
+    return outs

@@ -73,8 +73,29 @@ class PixelCNNEngine:
         return (wv.permute(0, 2, 3, 1).reshape(wv.shape[0], -1, 1, 1).contiguous(),
                 wh.permute(0, 2, 3, 1).reshape(wh.shape[0], -1, 1, 1).contiguous())
 
+    # ---- weight images of a whole pass in a few launches ------------------------------------------------------------
+    def _images(self, backward: bool):
+        """{(layer index | 'head', name): image}.  Forward: the stacks embedded into 3x3 images, the 1x1 links, the head;
+        backward: their transposed (+ flipped) counterparts.  The 7x7 layer's im2col matrices are built separately."""
+        m, dt = self.m, self.dtype
+        jobs, keys = [], []
+
+        def add(key, w, **kw):
+            keys.append(key); jobs.append((w.detach(), dict(kw, transpose=backward)))
+
+        for i, L in enumerate(m.layers):
+            if L.kernel == 3:
+                add((i, 'v'), L.vert_stack.weight, ksize=3)
+                add((i, 'h'), L.horiz_stack.weight, ksize=3, kh0=1)
+            add((i, 'v2h'), L.vert_to_horiz.weight)
+            add((i, 'r'), L.horiz_resid[0].module.weight)
+        oc = m.output_conv
+        add(('head', 0), oc[0].module.weight)
+        add(('head', 4), oc[4].module.weight, **({'k_img': pad8(oc[4].module.out_channels)} if backward else {}))
+        return dict(zip(keys, ops.prep_weight_ex_many(jobs, dt)))
+
     # ---- forward ------------------------------------------------------------------------------------------------
-    def _layer_forward(self, L, x_v: Tensor, x_h: Tensor, label: Tensor, train: bool, tape):
+    def _layer_forward(self, L, x_v: Tensor, x_h: Tensor, label: Tensor, train: bool, tape, I, li):
         dt = self.dtype
         n, h, w, c = x_v.shape
         count = n * h * w
@@ -86,15 +107,14 @@ class PixelCNNEngine:
             # the (2 x 3) and (1 x 2) stacks sit at taps (0, 0) and (1, 0) of 3x3 images (zero elsewhere)
             wv = wh = None
             in_v, in_h = Seg(x_v), Seg(x_h)
-            img_v = ops.prep_weight_ex(L.vert_stack.weight.detach(), dt, 3)
-            img_h = ops.prep_weight_ex(L.horiz_stack.weight.detach(), dt, 3, kh0=1)
+            img_v, img_h = I[(li, 'v')], I[(li, 'h')]
         else:
             wv, wh = self._stack_weights(L)
             in_v = Seg(ops.im2col(x_v, k2 + 1, L.kernel, k2, k2), ksize=1)
             in_h = Seg(ops.im2col(x_h, 1, k2 + 1, 0, k2), ksize=1)
             img_v, img_h = ops.prep_weight(wv, dt), ops.prep_weight(wh, dt)
         h_vert, st_v = ops.conv_fused([in_v], img_v, 2 * c, bias=L.vert_stack.bias.detach(), stats_mode=sm)
-        wimg = torch.cat([ops.prep_weight(L.vert_to_horiz.weight.detach(), dt), img_h])
+        wimg = torch.cat([I[(li, 'v2h')], img_h])
         s, st_s = ops.conv_fused([Seg(h_vert, ksize=1), in_h], wimg, 2 * c,
                                  bias=L.vert_to_horiz.bias.detach() + L.horiz_stack.bias.detach(), stats_mode=sm)
         code_v, code_h = L.gate_v.mc.code_of_labels(label), L.gate_h.mc.code_of_labels(label)
@@ -103,7 +123,7 @@ class PixelCNNEngine:
         out_v = ops.gated_fwd(h_vert, bn_v[0], bn_v[1], code_v)
         out_h = ops.gated_fwd(s, bn_h[0], bn_h[1], code_h)
         conv_r, bn_rm, mc_r = L.horiz_resid[0].module, L.horiz_resid[1].module, L.horiz_resid[2]
-        r, st_r = ops.conv_fused([Seg(out_h, ksize=1)], ops.prep_weight(conv_r.weight.detach(), dt), c,
+        r, st_r = ops.conv_fused([Seg(out_h, ksize=1)], I[(li, 'r')], c,
                                  bias=conv_r.bias.detach(), stats_mode=sm)
         bn_r = self._bn(bn_rm, st_r, count, train)
         code_r = mc_r.code_of_labels(label)
@@ -120,24 +140,25 @@ class PixelCNNEngine:
         x = F.embedding(codes, m.embedding.weight.detach()).to(dt).contiguous()           # [N, H, W, C] is already NHWC
         x_v = x_h = x
         layers = [] if tape is not None else None
-        for L in m.layers:
-            x_v, x_h = self._layer_forward(L, x_v, x_h, label, train, layers)
+        I = self._images(False)
+        for li, L in enumerate(m.layers):
+            x_v, x_h = self._layer_forward(L, x_v, x_h, label, train, layers, I, li)
         oc = m.output_conv
         conv0, bn0, mc0, conv4 = oc[0].module, oc[1].module, oc[3], oc[4].module
         count = n * h * w
-        h0, st0 = ops.conv_fused([Seg(x_h, ksize=1)], ops.prep_weight(conv0.weight.detach(), dt), conv0.out_channels,
+        h0, st0 = ops.conv_fused([Seg(x_h, ksize=1)], I[('head', 0)], conv0.out_channels,
                                  bias=conv0.bias.detach(), stats_mode=1 if train else 0)
         bn = self._bn(bn0, st0, count, train)
         code0 = mc0.code_of_labels(label)
         logits, _ = ops.conv_fused([Seg(h0, ksize=1, scale=bn[0], shift=bn[1], relu=True, code=code0)],
-                                   ops.prep_weight(conv4.weight.detach(), dt), conv4.out_channels, bias=conv4.bias.detach())
+                                   I[('head', 4)], conv4.out_channels, bias=conv4.bias.detach())
         rows, dlogits = ops.cross_entropy(logits, codes.reshape(-1), conv4.out_channels, want_grad)
         if tape is not None:
             tape.update(layers=layers, codes=codes, x_h=x_h, h0=h0, bn0=bn, code0=code0, dlogits=dlogits)
         return rows.mean(), logits, dlogits
 
     # ---- backward -----------------------------------------------------------------------------------------------
-    def _conv1x1_bwd(self, conv, seg_in: Seg, dy: Tensor, need_dx: bool = True, **dgrad_kw):
+    def _conv1x1_bwd(self, conv, seg_in: Seg, dy: Tensor, need_dx: bool = True, wt=None, **dgrad_kw):
         """Weight/bias gradients of a 1x1 convolution and (optionally) its input gradient."""
         dt = self.dtype
         cout = conv.out_channels
@@ -145,17 +166,18 @@ class PixelCNNEngine:
         ops.wgrad(seg_in, dy, cout, conv.in_channels, self._grad(conv.weight), bias_grad=self._grad(conv.bias))
         if not need_dx:
             return None, None
-        wt = ops.prep_weight_ex(conv.weight.detach(), dt, transpose=True, k_img=dy.shape[-1])
+        if wt is None:
+            wt = ops.prep_weight_ex(conv.weight.detach(), dt, transpose=True, k_img=dy.shape[-1])
         return ops.conv_fused([Seg(dy, ksize=1)], wt, conv.in_channels, **dgrad_kw)
 
-    def _layer_backward(self, L, r, g_v: Optional[Tensor], g_h: Tensor, need_dx: bool):
+    def _layer_backward(self, L, r, g_v: Optional[Tensor], g_h: Tensor, need_dx: bool, I, li):
         """g_v / g_h: gradients w.r.t. this layer's (out_v, x_h').  Returns gradients w.r.t. (x_v, x_h)."""
         dt = self.dtype
         c = L.hidden_size
         conv_r, bn_rm = L.horiz_resid[0].module, L.horiz_resid[1].module
         sc_r, _, mean_r, rstd_r = r['bn_r']
         d_r = ops.code_bn_bwd(g_h, r['code_r'], r['r'], sc_r, mean_r, rstd_r, self._grad(bn_rm.weight), self._grad(bn_rm.bias))
-        d_out_h, _ = self._conv1x1_bwd(conv_r, Seg(r['out_h'], ksize=1), d_r)
+        d_out_h, _ = self._conv1x1_bwd(conv_r, Seg(r['out_h'], ksize=1), d_r, wt=I[(li, 'r')])
         sc, sh, mean, rstd = r['bn_h']
         ds = ops.gated_bwd(r['s'], sc, sh, mean, rstd, r['code_h'], d_out_h, self._grad(L.gate_h.bn.weight), self._grad(L.gate_h.bn.bias))
         # s = vert_to_horiz(h_vert) + horiz_stack(x_h): both biases see sum(ds)
@@ -178,7 +200,7 @@ class PixelCNNEngine:
             sc, sh, mean, rstd = r['bn_v']
             d_hv = ops.gated_bwd(r['h_vert'], sc, sh, mean, rstd, r['code_v'], g_v, self._grad(L.gate_v.bn.weight),
                                  self._grad(L.gate_v.bn.bias))
-        d_hv, _ = ops.conv_fused([Seg(ds, ksize=1)], ops.prep_weight_ex(L.vert_to_horiz.weight.detach(), dt, transpose=True), c2, res=d_hv)
+        d_hv, _ = ops.conv_fused([Seg(ds, ksize=1)], I[(li, 'v2h')], c2, res=d_hv)
         in_v = r['in_v']
         cin_v = in_v.x.shape[-1]
         gwv = torch.empty((c2, cin_v, in_v.ksize, in_v.ksize), dtype=torch.float32, device=ds.device)
@@ -192,8 +214,8 @@ class PixelCNNEngine:
             return None, None
         res_h = g_h if L.residual else None
         if L.kernel == 3:
-            d_xh, _ = ops.conv_fused([Seg(ds)], ops.prep_weight_ex(L.horiz_stack.weight.detach(), dt, 3, kh0=1, transpose=True), c, res=res_h)
-            d_xv, _ = ops.conv_fused([Seg(d_hv)], ops.prep_weight_ex(L.vert_stack.weight.detach(), dt, 3, transpose=True), c)
+            d_xh, _ = ops.conv_fused([Seg(ds)], I[(li, 'h')], c, res=res_h)
+            d_xv, _ = ops.conv_fused([Seg(d_hv)], I[(li, 'v')], c)
         else:
             dcol_h, _ = ops.conv_fused([Seg(ds, ksize=1)], ops.prep_weight(_t1x1(r['wh']), dt), r['wh'].shape[1])
             d_xh = ops.col2im(dcol_h, c, 1, k2 + 1, 0, k2)
@@ -219,16 +241,17 @@ class PixelCNNEngine:
         sc, sh, mean, rstd = tape['bn0']
         h0, code0 = tape['h0'], tape['code0']
         # logits = conv4(code * relu(BN(h0))): input gradient through the gate with BN-backward sums in the epilogue
-        dz, st = self._conv1x1_bwd(conv4, Seg(h0, ksize=1, scale=sc, shift=sh, relu=True, code=code0), tape['dlogits'],
+        I = self._images(True)
+        dz, st = self._conv1x1_bwd(conv4, Seg(h0, ksize=1, scale=sc, shift=sh, relu=True, code=code0), tape['dlogits'], wt=I[('head', 4)],
                                    ocode=code0, gate_x=h0, gscale=sc, gshift=sh, gmean=mean, grstd=rstd, stats_mode=2)
         n, h, w, _ = h0.shape
         d_h0 = ops.bn_backward(st, dz, h0, n * h * w, sc, mean, rstd, self._grad(bn0.weight), self._grad(bn0.bias))
-        g_h, _ = self._conv1x1_bwd(conv0, Seg(tape['x_h'], ksize=1), d_h0)
+        g_h, _ = self._conv1x1_bwd(conv0, Seg(tape['x_h'], ksize=1), d_h0, wt=I[('head', 0)])
         g_v = None                                              # the last layer's out_v feeds nothing
         layers = tape['layers']
         d_emb = None
         for i in reversed(range(len(m.layers))):
-            g_v, g_h = self._layer_backward(m.layers[i], layers[i], g_v, g_h, need_dx=True)
+            g_v, g_h = self._layer_backward(m.layers[i], layers[i], g_v, g_h, True, I, i)
         d_x = g_v + g_h                                          # layer 0: x_v and x_h are the same embedding output
         ge = self._grad(m.embedding.weight)
         ge.zero_()

@@ -67,6 +67,14 @@ def wgrad_layers():
         out['wg' + name] = (lambda x=x, dy=dy, sc=sc, sh=sh, code=code, g=g, bg=bg, c=c:
                             ops.wgrad(Seg(x, scale=sc, shift=sh, code=code, relu=True), dy, c, c, g, bias_grad=bg),
                             2.0 * N * h * h * c * c * 9)
+    for name, h, c in (('K1_16', 16, 512), ('K1_8', 8, 512)):
+        x, dy = act(N, h, c), act(N, h, c)
+        sc, sh, code = rnd(c), rnd(c), (torch.rand(N, c, device=dev) < 0.5).float()
+        g = torch.zeros(c, c, 1, 1, device=dev)
+        bg = torch.zeros(c, device=dev)
+        out['wg' + name] = (lambda x=x, dy=dy, sc=sc, sh=sh, code=code, g=g, bg=bg, c=c:
+                            ops.wgrad(Seg(x, ksize=1, scale=sc, shift=sh, code=code, relu=True), dy, c, c, g, bias_grad=bg),
+                            2.0 * N * h * h * c * c)
     return out
 
 
