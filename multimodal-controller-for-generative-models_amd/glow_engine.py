@@ -37,6 +37,59 @@ class GlowEngine:
             t = self._const[key] = torch.full((n,), value, dtype=torch.float32, device=device)
         return t
 
+    # ---- weight images of a whole pass in a few batched launches (ops.prep_weight_ex_many) -------------------------
+    def _block_dims(self):
+        """[(c, cp)] per block: logical / padded channel count seen by that block's flows."""
+        c, out = self.m.data_shape[0], []
+        for blk in self.m.blocks:
+            c *= 4
+            out.append((c, pad8(c)))
+            if blk.split:
+                c //= 2
+        return out
+
+    def _prepare(self, backward: bool, wmats=None):
+        """Fill self._I with every weight image of the pass: {(id(module), tag): image}; self._rs with exp(3 * scale) of
+        every ZeroConv2d.  Forward also computes the LU weights (self._wmat) the backward reuses."""
+        m, dt = self.m, self.dtype
+        zcs = [f.coupling.net[8].module for b in m.blocks for f in b.flows] + [b.prior for b in m.blocks]
+        if not backward:
+            rs = torch._foreach_exp(torch._foreach_mul([z.scale.detach().reshape(-1) for z in zcs], 3.0))
+            self._rs = {id(z): r for z, r in zip(zcs, rs)}
+            self._wmat = {}
+        jobs, keys = [], []
+
+        def add(key, w, **kw):
+            keys.append(key); jobs.append((w.detach(), dict(kw, transpose=backward)))
+
+        for blk, (c, cp) in zip(m.blocks, self._block_dims()):
+            for flow in blk.flows:
+                net = flow.coupling.net
+                conv0, an1, conv1, an5, zc = net[0].module, net[1].module, net[4].module, net[5].module, net[8].module
+                hid, ic, rs = conv0.out_channels, flow.invconv, self._rs[id(zc)]
+                if not backward:
+                    wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
+                    self._wmat[id(ic)] = wmat
+                    add((id(conv0), 'f'), conv0.weight, k_img=cp)
+                    add((id(conv1), 'f'), conv1.weight)
+                    add((id(zc), 'f'), zc.conv.weight, row_scale=rs, k_img=hid)
+                    add((id(ic), 'f'), wmat, ksize=1, k_img=cp)
+                else:
+                    add((id(zc), 'b'), zc.conv.weight, row_scale=rs, k_img=cp)
+                    add((id(conv1), 'b'), conv1.weight, row_scale=an5.scale.detach().reshape(-1))
+                    add((id(conv0), 'b'), conv0.weight, row_scale=an1.scale.detach().reshape(-1), rows_img=c)
+                    add((id(ic), 'b'), self._wmat[id(ic)], ksize=1, col_scale=flow.actnorm.scale.detach().reshape(-1), k_img=cp)
+            pz, prs = blk.prior, self._rs[id(blk.prior)]
+            if not backward:
+                add((id(pz), 'f'), pz.conv.weight, row_scale=prs, k_img=(pad8(c // 2) if blk.split else cp))
+            elif blk.split:
+                add((id(pz), 'b'), pz.conv.weight, row_scale=prs, k_img=cp)
+        self._I = dict(zip(keys, ops.prep_weight_ex_many(jobs, dt)))
+
+    def _img(self, key, build):
+        t = self._I.get(key) if getattr(self, '_I', None) else None
+        return t if t is not None else build()
+
     def all_initialized(self) -> bool:
         flags = [mod.initialized for mod in self.m.modules() if hasattr(mod, 'initialized')]
         return bool(torch.stack([f.reshape(()) for f in flags]).min().item() != 0)
@@ -51,8 +104,11 @@ class GlowEngine:
 
     def _zero_conv_image(self, zc, cin_pad: int):
         """ZeroConv2d (mcglow.py:119-130) as weight image + bias with exp(3*scale) folded into the rows."""
-        rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
-        return ops.prep_weight_ex(zc.conv.weight.detach(), self.dtype, row_scale=rs, k_img=cin_pad), zc.conv.bias.detach() * rs
+        rs = getattr(self, '_rs', {}).get(id(zc)) if getattr(self, '_I', None) else None
+        if rs is None:
+            rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
+        img = self._img((id(zc), 'f'), lambda: ops.prep_weight_ex(zc.conv.weight.detach(), self.dtype, row_scale=rs, k_img=cin_pad))
+        return img, zc.conv.bias.detach() * rs
 
     def _coupling_net(self, cp_net, x: Tensor, c: int, codes, train: bool, saved=None):
         """AffineCoupling.net on the first c/2 channels of x -> [log_s | t] (c channels)."""
@@ -64,13 +120,14 @@ class GlowEngine:
                                                  net[7], net[8].module)
         need1 = train and not self.assume_initialized and int(an1.initialized) == 0
         # the image is zero over the input channels >= c/2: the coupling net reads only the first half of x
-        h1, st1 = ops.conv_fused([Seg(x)], ops.prep_weight_ex(conv0.weight.detach(), dt, k_img=cp), conv0.out_channels, bias=conv0.bias,
+        w0img = self._img((id(conv0), 'f'), lambda: ops.prep_weight_ex(conv0.weight.detach(), dt, k_img=cp))
+        h1, st1 = ops.conv_fused([Seg(x)], w0img, conv0.out_channels, bias=conv0.bias,
                                  stats_mode=1 if need1 else 0)
         hid = conv0.out_channels
         a1, b1, nl1 = self._actnorm(an1, lambda: st1, count, train, hid)
         need5 = train and not self.assume_initialized and int(an5.initialized) == 0
         h2, st2 = ops.conv_fused([Seg(h1, ksize=1, scale=a1, shift=b1, relu=True, code=codes[0])],
-                                 ops.prep_weight(conv1.weight.detach(), dt), hid, bias=conv1.bias,
+                                 self._img((id(conv1), 'f'), lambda: ops.prep_weight(conv1.weight.detach(), dt)), hid, bias=conv1.bias,
                                  stats_mode=1 if need5 else 0)
         a5, b5, nl5 = self._actnorm(an5, lambda: st2, count, train, hid)
         wz, bz = self._zero_conv_image(zc, hid)
@@ -84,8 +141,11 @@ class GlowEngine:
         n, h, w, cp = x.shape
         a, b, nl = self._actnorm(flow.actnorm, lambda: ops.channel_stats(x), n * h * w, train, cp)
         ic = flow.invconv
-        wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
-        out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)], ops.prep_weight_ex(wmat, dt, 1, k_img=cp), c, cy=cp)
+        wmat = self._wmat.get(id(ic)) if getattr(self, '_I', None) else None
+        if wmat is None:
+            wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
+        out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)],
+                                self._img((id(ic), 'f'), lambda: ops.prep_weight_ex(wmat, dt, 1, k_img=cp)), c, cy=cp)
         # parameter-only log-determinants: H*W * (sum log|scale| + sum w_s)   (mcglow.py:46-47,101)
         ops.glow_param_logdet(flow.actnorm.scale.detach(), ic.w_s.detach(), h * w, logdet)
         net = flow.coupling.net
@@ -122,6 +182,7 @@ class GlowEngine:
     def forward(self, img: Tensor, indicator: Tensor, noise: Tensor, train: bool, tape=None, label=None):
         m, dt = self.m, self.dtype
         n = img.shape[0]
+        self._prepare(False)
         x0 = img * 0.5 + noise / 256                                   # mcglow.py:298-299
         c = m.data_shape[0]
         x = ops.to_nhwc(x0.contiguous(), dt)
@@ -178,7 +239,9 @@ class GlowEngine:
     def _zero_conv_bwd(self, zc, seg_in, out: Tensor, dout: Tensor, cout: int, cin: int, need_dx: bool, res=None, **dgrad_kw):
         """ZeroConv2d backward: out = (conv(A) + b) * exp(3 scale).  Returns (dA, stats) when need_dx."""
         dt = self.dtype
-        rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
+        rs = getattr(self, '_rs', {}).get(id(zc)) if getattr(self, '_I', None) else None
+        if rs is None:
+            rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
         ops.prod_colsum(out, dout, cout, self._grad(zc.scale).view(-1), alpha=3.0)
         if seg_in is not None:
             # weight / bias gradients land in place: the split-K reduce scales row co by exp(3 * scale[co])
@@ -190,7 +253,7 @@ class GlowEngine:
             self._grad(zc.conv.bias).copy_(gb * rs)
         if not need_dx:
             return None, None
-        wt = ops.prep_weight_ex(zc.conv.weight.detach(), dt, transpose=True, row_scale=rs, k_img=dout.shape[-1])
+        wt = self._img((id(zc), 'b'), lambda: ops.prep_weight_ex(zc.conv.weight.detach(), dt, transpose=True, row_scale=rs, k_img=dout.shape[-1]))
         return ops.conv_fused([Seg(dout)], wt, cin, res=res, **dgrad_kw)
 
     def _flow_backward(self, flow, r, dy: Tensor, c: int, g0: float) -> Tensor:
@@ -213,14 +276,14 @@ class GlowEngine:
         # 1x1 conv <- MC <- ReLU <- ActNorm(1)
         ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid,
                   self._grad(conv1.weight), bias_grad=self._grad(conv1.bias), row_scale=s5)
-        w1t = ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5)
+        w1t = self._img((id(conv1), 'b'), lambda: ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5))
         v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], w1t, hid, ocode=codes[0], gate_x=r['h1'],
                                  gscale=r['a1'], gshift=r['b1'], gmean=r['nl1'], grstd=ones, stats_mode=2)
         ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
         s1 = an1.scale.detach().reshape(-1)
         # 3x3 conv on the first c/2 channels of v; its input gradient joins the direct coupling gradient dv
         ops.wgrad(Seg(out), v1, hid, c // 2, self._grad(conv0.weight), bias_grad=self._grad(conv0.bias), row_scale=s1)
-        w0t = ops.prep_weight_ex(conv0.weight.detach(), dt, transpose=True, row_scale=s1, rows_img=c)   # rows >= c/2: zero
+        w0t = self._img((id(conv0), 'b'), lambda: ops.prep_weight_ex(conv0.weight.detach(), dt, transpose=True, row_scale=s1, rows_img=c))   # rows >= c/2: zero
         dvt, _ = ops.conv_fused([Seg(v1)], w0t, c, res=dv, cy=cp)
         # invertible 1x1 conv <- ActNorm
         an, ic = flow.actnorm, flow.invconv
@@ -231,7 +294,7 @@ class GlowEngine:
         self._post.append(lambda: ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef, gl, gu, gs))
         s = an.scale.detach().reshape(-1)
         wmat = r['wmat']
-        wt = ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp)                 # [ci, co] = W[co, ci] * s[ci]
+        wt = self._img((id(ic), 'b'), lambda: ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp))   # [ci, co] = W[co, ci] * s[ci]
         dx, st = ops.conv_fused([Seg(dvt, ksize=1)], wt, c, cy=cp, gate_x=x,
                                 gscale=self._full(0.0, c, dev), gshift=self._full(1.0, c, dev),
                                 gmean=r['nl'], grstd=self._full(1.0, c, dev),
@@ -244,6 +307,7 @@ class GlowEngine:
         m = self.m
         g0 = -1.0 / (n * math.log(2.) * n_pixel)
         self._post = []
+        self._prepare(True)
         with ops.deferred_reduces():               # every split-K reduction of the pass: a handful of batched launches
             dkeep = self._backward_body(tape, g0)
         for f in self._post:
@@ -273,6 +337,7 @@ class GlowEngine:
     # ---- reverse: reconstruction / sampling ------------------------------------------------------------------------
     def reverse(self, zs: List[Tensor], indicator: Tensor, reconstruct: bool, label=None) -> Tensor:
         m, dt = self.m, self.dtype
+        self._I = None                              # images are built per use on this path
         L = len(m.blocks)
         x = None
         c_in = [m.data_shape[0] * 2 ** i for i in range(L)]               # channels entering block i
