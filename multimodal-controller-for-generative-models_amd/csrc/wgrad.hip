@@ -62,6 +62,22 @@ template <> struct KFrag<float> {
     }
 };
 
+
+// XCD-aware block order.  Hardware deals workgroup ids round-robin over the 8 XCDs (each with its own L2); the blocks
+// of one pixel split (all output-channel blocks x input-channel chunks) read the SAME x / dy tiles, so they should share
+// an L2: the linear id is re-read as (xcd, slot) -> virtual id xcd * (total / 8) + slot, and (bx, by, bz) are decoded from
+// the virtual id with bx, by fastest.  Falls back to the identity when the grid is not a multiple of 8.
+struct WgIdx { int bx, by, bz; };
+static __device__ __forceinline__ WgIdx wg_remap(int enabled) {
+    WgIdx r{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+    if (!enabled || (total & 7)) return r;
+    const int L = r.bx + gx * (r.by + gy * r.bz);
+    const int v = (L & 7) * (total >> 3) + (L >> 3);
+    r.bx = v % gx; r.by = (v / gx) % gy; r.bz = v / (gx * gy);
+    return r;
+}
+
 // Workgroup = 64 output channels x 32 input channels x all taps.  Waves are a 2 x 2 grid:
 // wave (a, b) owns output-channel fragments {2a, 2a+1} and input-channel block b for every tap, so per
 // 32-pixel step it reads 2 dy fragments + NTAP window fragments for 2*NTAP MFMAs (small footprint:
@@ -69,7 +85,7 @@ template <> struct KFrag<float> {
 // LGW = log2(W) is a template parameter so that every tap offset is an instruction immediate.
 template <typename T, int KS, int LGW>
 __global__ __launch_bounds__(WG_NT, 3)
-void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
+void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
@@ -88,8 +104,9 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, N = p.N;
-    const int co0 = blockIdx.x * WG_BCO;
-    const int q = blockIdx.y;                       // input-channel chunk
+    const WgIdx wi = wg_remap(xcd_map);
+    const int co0 = wi.bx * WG_BCO;
+    const int q = wi.by;                            // input-channel chunk
     const int c0 = q * MCGEN_CK;
     const mcgen_seg_t sg = p.seg;
     const char* dy = reinterpret_cast<const char*>(p.dy);
@@ -137,8 +154,8 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
     const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
     const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
-    const int t_lo = p.halves ? ((int)blockIdx.z / zs) * mt : 0;
-    for (int tile = t_lo + (int)blockIdx.z % zs; tile < t_lo + mt; tile += zs) {
+    const int t_lo = p.halves ? (wi.bz / zs) * mt : 0;
+    for (int tile = t_lo + wi.bz % zs; tile < t_lo + mt; tile += zs) {
         const Geo g = make_geo(WG_BM, tile, H, W);
         stager.bind(sg, g, N, H, W);
         __syncthreads();                                        // previous tile's reads are done
@@ -188,12 +205,12 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
     if (do_bias) {
         // four row-quarter partial sums per column; mcgen_wgrad_reduce adds all splits*4 rows in order
         const int col = tid & 63, part = tid >> 6;
-        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)blockIdx.z * 4 + part) * p.Cout_w + co0 + col] = bsum;
+        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)wi.bz * 4 + part) * p.Cout_w + co0 + col] = bsum;
     }
     // slab[z][q][tap][co][32]: lane holds D[co = 4*lg + r][ci = l15] of block (tap j, co fragment cf)
     const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
-    float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
+    float* out = p.slabs + (size_t)wi.bz * slab_elems;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         const int col = wb * 16 + l15;
@@ -218,7 +235,7 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
 // GEMM whose 64 x 32 output tile would otherwise re-read dy Cin/32 times: measured 132 TFLOP/s at 512 x 512).
 template <typename T, int KS, int LGW, int NCH>
 __global__ __launch_bounds__(2 * WG_NT, 2)
-void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles) {
+void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
@@ -244,8 +261,9 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, N = p.N;
-    const int co0 = blockIdx.x * WG_BCO;
-    const int q = blockIdx.y;
+    const WgIdx wi = wg_remap(xcd_map);
+    const int co0 = wi.bx * WG_BCO;
+    const int q = wi.by;
     const int c0 = q * NCH * MCGEN_CK;
     const mcgen_seg_t sg = p.seg;
     const char* dy = reinterpret_cast<const char*>(p.dy);
@@ -256,8 +274,8 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
     const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
     const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
-    const int t_first = (p.halves ? ((int)blockIdx.z / zs) * mt : 0) + (int)blockIdx.z % zs;
-    const int cnt = (mt - (int)blockIdx.z % zs + zs - 1) / zs;                          // tiles of this workgroup
+    const int t_first = (p.halves ? (wi.bz / zs) * mt : 0) + wi.bz % zs;
+    const int cnt = (mt - wi.bz % zs + zs - 1) / zs;                          // tiles of this workgroup
     const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
     constexpr int DUNITS = WG_BCO * ESZ / 16;
     constexpr int DITEMS = WG_BM * DUNITS / WG_NT;
@@ -377,7 +395,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     // slab[z][q][tap][co][32]
     const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
     const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
-    float* out = p.slabs + (size_t)blockIdx.z * slab_elems;
+    float* out = p.slabs + (size_t)wi.bz * slab_elems;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int col = wb * 16 + l15;
@@ -395,7 +413,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     }
     if (do_bias) {
         const int col = rtid & 63, part = rtid >> 6;
-        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)blockIdx.z * 4 + part) * p.Cout_w + co0 + col] = bsum;
+        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)wi.bz * 4 + part) * p.Cout_w + co0 + col] = bsum;
     }
 }
 
@@ -483,6 +501,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
     dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    static const int xcd_map = getenv("MCGEN_WGRAD_XCD") ? atoi(getenv("MCGEN_WGRAD_XCD")) : 1;
     const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
     // the role split only pays when a workgroup walks several tiles (staging of tile i+1 overlaps tile i)
     const bool pc = mode ? (mode[0] == '1') : (m_tiles >= 4 * p->splits);
@@ -500,7 +519,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
                 if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
             }
             dim3 grid4((p->Cout_w + WG_BCO - 1) / WG_BCO, (wgrad_chunks(p) + NCH - 1) / NCH, p->splits);
-            hipLaunchKernelGGL(kern4, grid4, dim3(2 * WG_NT), lds4, st, *p, a_bytes, m_tiles);
+            hipLaunchKernelGGL(kern4, grid4, dim3(2 * WG_NT), lds4, st, *p, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(pc, chunk groups)");
             return 0;
         }
@@ -514,7 +533,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kern2, grid, dim3(2 * WG_NT), lds2, st, *p, a_bytes, m_tiles);
+        hipLaunchKernelGGL(kern2, grid, dim3(2 * WG_NT), lds2, st, *p, a_bytes, m_tiles, xcd_map);
         MCGEN_LAUNCH_CHECK("wgrad(pc)");
         return 0;
     }
@@ -525,7 +544,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, *p, a_bytes, m_tiles);
+    hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, *p, a_bytes, m_tiles, xcd_map);
     MCGEN_LAUNCH_CHECK("wgrad");
     return 0;
 }
