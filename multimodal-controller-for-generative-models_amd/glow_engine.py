@@ -14,7 +14,6 @@ import math
 from typing import List
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .ops import Seg, pad8

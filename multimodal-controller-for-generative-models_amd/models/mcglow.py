@@ -12,7 +12,6 @@ import numpy as np
 import scipy.linalg as la
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..config import cfg
 from ..glow_engine import GlowEngine

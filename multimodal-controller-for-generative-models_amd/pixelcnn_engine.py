@@ -14,7 +14,7 @@ Backward mirrors it with the same fused kernel on transposed images, the wgrad k
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
@@ -28,11 +28,6 @@ Tensor = torch.Tensor
 def _t1x1(w: Tensor) -> Tensor:
     """[Cout, Cin(,1,1)] -> transposed 1x1 master weight [Cin, Cout, 1, 1]."""
     return w.reshape(w.shape[0], -1).t().contiguous().reshape(-1, w.shape[0], 1, 1)
-
-
-def _t3x3(w: Tensor) -> Tensor:
-    """[Cout, Cin, 3, 3] -> weight of the input-gradient convolution [Cin, Cout, 3, 3] (taps flipped)."""
-    return w.flip(2, 3).transpose(0, 1).contiguous()
 
 
 class PixelCNNEngine:

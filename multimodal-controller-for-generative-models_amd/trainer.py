@@ -16,7 +16,7 @@ nn.DataParallel (train_gan.py:96-98).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn.functional as F
