@@ -430,6 +430,7 @@ def main():
                        + f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                        'graph_replay': graphed},
+            'd_steps_per_s': 5 * a.steps * world / dt / world, 'g_steps_per_s': a.steps / dt,     # per replica
             'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses,
