@@ -733,6 +733,9 @@ void conv_dma_kernel(const mcgen_conv_t p, const int a_bytes) {
 // instructions (short groups re-load their last tap), so the counted vmcnt is a compile-time constant.
 // (measured: asking for a 256-register budget on the 256x256 tile -- __launch_bounds__(512, 2) -- removes its 24 bytes of
 // scratch but runs 4-9 % slower; the default budget stays)
+#ifndef MCGEN_STAGE2
+#define MCGEN_STAGE2 1
+#endif
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN)
 void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
@@ -740,6 +743,8 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     using M = Mma<T>;
     constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
     constexpr int TPS = 3;
+    // 128-pixel tiles only: the 256x256 tile has no registers to spare (128 accumulators), 64-pixel tiles have 2 items per thread
+    constexpr bool STAGE2 = MCGEN_STAGE2 && BM == 128;
     constexpr int NW = WM * WN;
     constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
     constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
@@ -836,7 +841,15 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
 #pragma unroll 1
         for (int q = 0; q < nchunk; ++q) {
             __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
-            stager.stage(sg, q * MCGEN_CK, ldsA);
+            if constexpr (STAGE2) {
+                // all global loads of the chunk's window first, then prologue + LDS stores: one exposed round trip per
+                // chunk instead of one per item (the item-sequential form keeps fewer registers live)
+                typename PatchStager<T, NT, C::NI, APITCH>::raw_t raw;
+                stager.load(sg, q * MCGEN_CK, raw);
+                stager.write(sg, q * MCGEN_CK, raw, ldsA, (g.TI == 1 && g.n0 < N) ? g.n0 : -1);
+            } else {
+                stager.stage(sg, q * MCGEN_CK, ldsA);
+            }
 #pragma unroll 1
             for (int gq = 0; gq < gpc; ++gq) {
                 // this group's tiles have landed (this wave's pieces); then all waves' pieces + window writes
