@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable ${MCGEN_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
 for f in conv_fused wgrad small_ops glow_ops pixelcnn_ops; do
