@@ -201,11 +201,13 @@ struct PatchStager {
         }
     }
     __device__ __forceinline__ void write_ext(const mcgen_seg_t& sg, int c0, const int (&src)[NI], const int (&nn)[NI],
-                                              const raw_t& raw, char* ldsA) const {
+                                              const raw_t& raw, char* ldsA, int one_n = -1) const {
         const int c = c0 + it_sub[0];
         const bool cok = c < sg.C;
-        float sc[8], sh[8];
+        float sc[8], sh[8], cd1[8];
         if (sg.scale && cok) { load8f(sg.scale + c, sc); load8f(sg.shift + c, sh); }
+        const bool code_once = sg.code && one_n >= 0 && cok;      // tile inside one image: one code row for all items
+        if (code_once) load8f(sg.code + (size_t)one_n * sg.C + c, cd1);
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (it_lds[k] < 0) continue;
@@ -220,7 +222,10 @@ struct PatchStager {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
                 }
-                if (sg.code) {
+                if (code_once) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd1[i];
+                } else if (sg.code) {
                     float cd[8];
                     load8f(sg.code + (size_t)nn[k] * sg.C + c, cd);
 #pragma unroll

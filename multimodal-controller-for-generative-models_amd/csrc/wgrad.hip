@@ -294,11 +294,13 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
             int src[NI], nn[NI];
             typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw[NCH];
             u32x4 d[DITEMS];
+            int one_n;                               // the tile's image when it lies inside one (shared code row), else -1
         };
         auto fetch = [&](int i, TileRegs& r) {
             const int tile = t_first + i * zs;
             const Geo g = make_geo(WG_BM, tile, H, W);
             stager.bind_into(sg, g, N, H, W, r.src, r.nn);
+            r.one_n = (g.TI == 1 && g.n0 < N) ? g.n0 : -1;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) stager.load_ext(sg, c0 + ch * MCGEN_CK, r.src, r.raw[ch]);
             if constexpr (!DDMA)
@@ -320,7 +322,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
         auto commit = [&](int i, const TileRegs& r) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
-                stager.write_ext(sg, c0 + ch * MCGEN_CK, r.src, r.nn, r.raw[ch], ldsA0 + (i & 1) * a_tile + ch * a_bytes);
+                stager.write_ext(sg, c0 + ch * MCGEN_CK, r.src, r.nn, r.raw[ch], ldsA0 + (i & 1) * a_tile + ch * a_bytes, r.one_n);
             if constexpr (!DDMA) {
             char* ldsD = ldsD0 + (i & 1) * D_BYTES;
 #pragma unroll
