@@ -159,7 +159,15 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, c
         const Geo g = make_geo(WG_BM, tile, H, W);
         stager.bind(sg, g, N, H, W);
         __syncthreads();                                        // previous tile's reads are done
-        stager.stage(sg, c0, ldsA);
+        if constexpr (KS == 1) {
+            // all global loads of the window first, then prologue + LDS stores: one exposed round trip instead of one per
+            // item (measured: -13 % on 1x1, but +30 % on 3x3 at 8x8, where the extra live registers cost a workgroup per CU)
+            typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw;
+            stager.load(sg, c0, raw);
+            stager.write(sg, c0, raw, ldsA, (g.TI == 1 && g.n0 < N) ? g.n0 : -1);
+        } else {
+            stager.stage(sg, c0, ldsA);
+        }
         // dy tile: [pixel m][64 co], raw 16-byte copies
 #pragma unroll
         for (int k = 0; k < DITEMS; ++k) {
