@@ -739,6 +739,9 @@ void conv_dma_kernel(const mcgen_conv_t p, const int a_bytes) {
 #ifndef MCGEN_STAGE2_BIG
 #define MCGEN_STAGE2_BIG 0
 #endif
+#ifndef MCGEN_STAGE2_SMALL
+#define MCGEN_STAGE2_SMALL 0
+#endif
 #ifndef MCGEN_BIG_WAVES
 #define MCGEN_BIG_WAVES 0
 #endif
@@ -750,7 +753,7 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
     constexpr int TPS = 3;
     // 128-pixel tiles only: the 256x256 tile has no registers to spare (128 accumulators), 64-pixel tiles have 2 items per thread
-    constexpr bool STAGE2 = MCGEN_STAGE2 && (BM == 128 || (MCGEN_STAGE2_BIG && BM * BN >= 256 * 256));
+    constexpr bool STAGE2 = MCGEN_STAGE2 && (BM == 128 || (MCGEN_STAGE2_SMALL && BM < 128) || (MCGEN_STAGE2_BIG && BM * BN >= 256 * 256));
     constexpr int NW = WM * WN;
     constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
     constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
