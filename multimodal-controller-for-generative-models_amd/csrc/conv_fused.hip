@@ -74,6 +74,10 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    // output code of a tile that lies inside one image: one row for every pixel of the tile, loaded once
+    const bool oc_once = p.ocode && vec_ok && g.TI == 1 && g.n0 < N && chunk_live;
+    float oc1[8];
+    if (oc_once) load8f(p.ocode + (size_t)g.n0 * p.Cout + co, oc1);
     const int lgWo = p.pool ? g.lgW - 1 : g.lgW;
     const int lgTHWo = p.pool ? g.lgTHW - 2 : g.lgTHW;
     const int out_pp = p.pool ? (PPX >> 2) : PPX;          // output pixels per pass
@@ -116,7 +120,10 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], p.alpha, bias[i]);
             if (p.ocode) {
-                if (vec_ok) {
+                if (oc_once) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= oc1[i];
+                } else if (vec_ok) {
                     float oc[8];
                     load8f(p.ocode + (size_t)n * p.Cout + co, oc);
 #pragma unroll
