@@ -236,6 +236,57 @@ struct PatchStager {
         }
     }
 
+    // ---- forms with caller-held prologue vectors -----------------------------------------------------------
+    // Memory loads return in order, so a prologue vector requested inside write_ext() queues behind every
+    // load issued before it -- including the NEXT tile's prefetch, whose latency it then exposes.  A caller
+    // that keeps tiles in flight loads the BN affine once (it depends on the chunk only) and the code row
+    // together with the tile's own loads, and hands both to write_pre().
+    __device__ __forceinline__ void load_affine(const mcgen_seg_t& sg, int c0, float (&sc)[8], float (&sh)[8]) const {
+        const int c = c0 + it_sub[0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+        if (sg.scale && c < sg.C) { load8f(sg.scale + c, sc); load8f(sg.shift + c, sh); }
+    }
+    __device__ __forceinline__ void load_code(const mcgen_seg_t& sg, int c0, int one_n, float (&cd)[8]) const {
+        const int c = c0 + it_sub[0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cd[i] = 1.f;
+        if (sg.code && one_n >= 0 && c < sg.C) load8f(sg.code + (size_t)one_n * sg.C + c, cd);
+    }
+    __device__ __forceinline__ void write_pre(const mcgen_seg_t& sg, int c0, const int (&src)[NI], const int (&nn)[NI],
+                                              const raw_t& raw, char* ldsA, int one_n,
+                                              const float (&sc)[8], const float (&sh)[8], const float (&cd1)[8]) const {
+        const int c = c0 + it_sub[0];
+        const bool cok = c < sg.C;
+        const bool code_once = sg.code && one_n >= 0;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (it_lds[k] < 0) continue;
+            float v[8];
+            unpack(raw[k], v);
+            if (src[k] >= 0 && cok) {
+                if (sg.scale) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (code_once) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd1[i];
+                } else if (sg.code) {
+                    float cd[8];
+                    load8f(sg.code + (size_t)nn[k] * sg.C + c, cd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= cd[i];
+                }
+            }
+            E::store8(reinterpret_cast<T*>(ldsA + it_lds[k]), v);
+        }
+    }
+
     // non-pipelined form: item by item (load, prologue, LDS store) -- few live registers, so several
     // workgroups fit on a CU and hide each other's latency
     __device__ __forceinline__ void stage(const mcgen_seg_t& sg, int c0, char* ldsA) const {

@@ -302,13 +302,20 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
             int src[NI], nn[NI];
             typename PatchStager<T, WG_NT, NI, APITCH>::raw_t raw[NCH];
             u32x4 d[DITEMS];
-            int one_n;                               // the tile's image when it lies inside one (shared code row), else -1
+            float cd[NCH][8];                        // the tile's code row(s) when it lies inside one image
+            int one_n;                               // that image, else -1 (code rows per item)
         };
+        // the BN affine depends on the chunk only: once per workgroup (see PatchStager::write_pre)
+        float sc[NCH][8], sh[NCH][8];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) stager.load_affine(sg, c0 + ch * MCGEN_CK, sc[ch], sh[ch]);
         auto fetch = [&](int i, TileRegs& r) {
             const int tile = t_first + i * zs;
             const Geo g = make_geo(WG_BM, tile, H, W);
             stager.bind_into(sg, g, N, H, W, r.src, r.nn);
             r.one_n = (g.TI == 1 && g.n0 < N) ? g.n0 : -1;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) stager.load_code(sg, c0 + ch * MCGEN_CK, r.one_n, r.cd[ch]);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) stager.load_ext(sg, c0 + ch * MCGEN_CK, r.src, r.raw[ch]);
             if constexpr (!DDMA)
@@ -330,7 +337,8 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
         auto commit = [&](int i, const TileRegs& r) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
-                stager.write_ext(sg, c0 + ch * MCGEN_CK, r.src, r.nn, r.raw[ch], ldsA0 + (i & 1) * a_tile + ch * a_bytes, r.one_n);
+                stager.write_pre(sg, c0 + ch * MCGEN_CK, r.src, r.nn, r.raw[ch], ldsA0 + (i & 1) * a_tile + ch * a_bytes, r.one_n,
+                                 sc[ch], sh[ch], r.cd[ch]);
             if constexpr (!DDMA) {
             char* ldsD = ldsD0 + (i & 1) * D_BYTES;
 #pragma unroll
