@@ -11,6 +11,7 @@
 // weight-image layout; mcgen_wgrad_reduce adds the slabs in a fixed order (deterministic).
 #include "conv_tile.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -490,6 +491,261 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     }
 }
 
+// ---- "ring" form (bf16, tiles inside one image, no upsampled reads) ------------------------------------------------
+// What bounds wgrad_pc_kernel on the 256 -> 256, 32x32 layer (2.08 us per 128-pixel tile against 0.48 us of MFMA; sides
+// removed one at a time: consumers alone 1.7 us, producers alone 1.65 us):
+//  * producers: a tile's loads were issued one tile ahead, so a tile cost a memory round trip (a deeper REGISTER pipeline
+//    does not survive the compiler: it puts vmcnt(0) at the loop head).  Here tiles travel by LDS-DMA into rings -- the
+//    raw window units of a tile into one of three slots, its dy tile (unpadded rows of 128 B, 16-byte units XOR-swizzled
+//    on the SOURCE side so that the transposing reads stay conflict-free) into one of four, its code row into a third --
+//    THREE tiles ahead, with a counted vmcnt (every wave issues the same number of DMA instructions per tile: the index
+//    of a tile past the end is clamped).  The prologue is then an LDS -> LDS pass over the thread's own units, and
+//    everything tile-independent is a per-thread constant (LDS offset, element offset from the tile's first pixel, row
+//    offset): per tile an item costs a row-range test and an address add.
+//  * consumers: LDS, not MFMA.  PMC on this kernel: LDS busy 80 % of the kernel, ~12 cycles per ds_read_b64_tr_b16 (a
+//    third of the plain read rate), MFMA busy 24 %.  Each consumer wave owns ALL 64 output channels x 16 input channels
+//    over HALF of the tile's pixels (13 fragment reads per 36 MFMAs instead of 11 per 18; the halves are added once,
+//    through LDS, after the last tile).  Ordering the reads ahead of the MFMAs (sched_group_barrier) was slower.
+// Measured 598 -> 628 TFLOP/s on that layer (525 -> 548, 506 -> 524 on the next two): the transposing reads are the floor.
+constexpr int WG_DSLOT = WG_BM * WG_BCO * 2;      // one dy tile, unpadded bf16 rows
+constexpr int WG_ND = 4, WG_NR = 3;               // ring depths: dy tiles, raw windows
+template <int KS, int LGW>
+__global__ __launch_bounds__(2 * WG_NT, 1)
+void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
+    typedef bf16_t T;
+    using E = Elem<T>;
+    using M = Mma<T>;
+    using TR = WgTraits<T>;
+    using KF = KFrag<T>;
+    constexpr int ESZ = 2, APITCH = TR::APITCH;
+    constexpr int NTAP = KS * KS, NV = NTAP, NCF = WG_BCO / 16;
+    constexpr int W = 1 << LGW, halo = KS >> 1, PC = W + 2 * halo;
+    constexpr int TH = WG_BM / W, PR = TH + 2 * halo, PP = PR * PC;     // tile rows, window rows, window pixels
+    static_assert(WG_BM % W == 0 && TH >= 1, "tiles inside one image");
+    constexpr int NIX = (PP * 4 + WG_NT - 1) / WG_NT;                  // raw units per producer thread
+    constexpr int RSLOT = NIX * WG_NT * 16;
+    constexpr int LD = NIX + 4;                                        // DMA instructions per producer wave and tile
+    constexpr int KSTEPS = WG_BM / 32, KSW = KSTEPS / 2;
+    constexpr int DROW = WG_BCO * ESZ;                                 // 128-byte dy rows
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA0 = smem;                                          // [2][a_bytes]   staged windows
+    char* const ldsR0 = smem + 2 * a_bytes;                            // [WG_NR][RSLOT] raw window units
+    char* const ldsD0 = ldsR0 + WG_NR * RSLOT;                         // [WG_ND][WG_DSLOT]
+    char* const ldsC0 = ldsD0 + WG_ND * WG_DSLOT;                      // [WG_NR][4 waves][32 floats] code rows (per producer wave)
+
+    const int tid = threadIdx.x;
+    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    const int rtid = tid & 255;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H;
+    const WgIdx wi = wg_remap(xcd_map);
+    const int co0 = wi.bx * WG_BCO;
+    const int q = wi.by;
+    const int c0 = q * MCGEN_CK;
+    const mcgen_seg_t sg = p.seg;
+    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
+    const int t_first = (p.halves ? (wi.bz / zs) * mt : 0) + wi.bz % zs;
+    const int cnt = (mt - wi.bz % zs + zs - 1) / zs;                   // tiles of this workgroup (>= 1)
+    const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
+    const int lgHW = 31 - __builtin_clz(H << LGW);
+    const int kh = wave >> 1, wb = wave & 1;                           // consumers: pixel half, input-channel half
+
+    f32x4 acc[NV][NCF];
+    float bsum = 0.f;
+
+    if (producer) {
+        const int sub = (rtid & 3) * 8;                                // channel offset inside the chunk
+        const bool cok = c0 + sub < sg.C;
+        int x_lds[NIX], x_off[NIX], x_dh[NIX];
+#pragma unroll
+        for (int k = 0; k < NIX; ++k) {
+            const int pp = (rtid + k * WG_NT) >> 2;
+            const int pr = pp / PC, pc = pp - pr * PC;
+            const int w = pc - halo;
+            const bool item = pp < PP;
+            x_lds[k] = item ? pp * APITCH + sub * ESZ : -1;
+            x_dh[k] = (item && cok && w >= 0 && w < W) ? pr - halo : (1 << 20);   // never passes the row test
+            x_off[k] = ((pr - halo) * W + w) * sg.C + sub;
+        }
+        float sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+        if (sg.scale && cok) { load8f(sg.scale + c0 + sub, sc); load8f(sg.shift + c0 + sub, sh); }
+        const char* xs = reinterpret_cast<const char*>(sg.x);
+        const char* dyb = reinterpret_cast<const char*>(p.dy);
+        const size_t dpix = (size_t)p.Cdy * ESZ;
+        // dy units of this lane: row (piece * 8 + lane / 8), 16-byte unit (lane % 8) ^ swizzle(row) on the source side
+        size_t d_src[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = (wave * 4 + k) * 8 + (lane >> 3);
+            int u = (lane & 7) ^ (((m >> 1) & 3) << 1);
+            if ((co0 + u * 8 + 8) > p.Cdy) u = 0;                      // beyond the dy pitch: any in-bounds unit (rows dropped at the end)
+            d_src[k] = (size_t)m * dpix + (size_t)co0 * ESZ + u * 16;
+        }
+        auto tile_of = [&](int i) { return t_first + (i < cnt ? i : cnt - 1) * zs; };
+        auto dma = [&](int i) {                                        // tile i -> R[i % 3], D[i % 4]; LD instructions per wave
+            const int pix0 = tile_of(i) * WG_BM;
+            const int h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
+            const char* xb = xs + ((size_t)pix0 * sg.C + c0) * ESZ;
+            char* rs = ldsR0 + (i % WG_NR) * RSLOT + wave * 1024;
+#pragma unroll
+            for (int k = 0; k < NIX; ++k) {
+                const bool ok = (unsigned)(h0 + x_dh[k]) < (unsigned)H;
+                const char* src = ok ? xb + (ptrdiff_t)x_off[k] * ESZ : xs;        // outside: any in-bounds address
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(rs + k * (WG_NT * 16)), 16, 0, 0);
+            }
+            const char* db = dyb + (size_t)pix0 * dpix;
+            char* ds = ldsD0 + (i % WG_ND) * WG_DSLOT + wave * 4096;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + d_src[k]),
+                                                 (__attribute__((address_space(3))) void*)(ds + k * 1024), 16, 0, 0);
+            // the tile's code row (32 floats of this chunk) also by DMA, one copy per wave: an ordinary load here would
+            // queue behind the DMAs just issued and its wait would drain them
+            if (sg.code && lane < 8) {
+                const int n0 = pix0 >> lgHW;
+                const int cc = c0 + lane * 4;
+                const float* src = sg.code + (size_t)n0 * sg.C + (cc + 4 <= sg.C ? cc : 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsC0 + ((i % WG_NR) * 4 + wave) * 128), 16, 0, 0);
+            }
+        };
+        auto prologue = [&](int i) {                                   // R[i % 3] -> A[i & 1]
+            const int pix0 = tile_of(i) * WG_BM;
+            const int h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
+            float cd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cd[e] = 1.f;
+            if (sg.code) load8f(reinterpret_cast<const float*>(ldsC0 + ((i % WG_NR) * 4 + wave) * 128) + sub, cd);
+            const char* rs = ldsR0 + (i % WG_NR) * RSLOT + rtid * 16;
+            char* ldsA = ldsA0 + (i & 1) * a_bytes;
+#pragma unroll
+            for (int k = 0; k < NIX; ++k) {
+                if (x_lds[k] < 0) continue;
+                float v[8];
+                E::load8(reinterpret_cast<const T*>(rs + k * (WG_NT * 16)), v);
+                if (sg.scale) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (sg.code) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= cd[e];
+                }
+                const bool ok = (unsigned)(h0 + x_dh[k]) < (unsigned)H;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
+                E::store8(reinterpret_cast<T*>(ldsA + x_lds[k]), v);
+            }
+        };
+        auto landed = [&]() {                                          // all but the two youngest tiles' DMAs are done
+            if (sg.code) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LD + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LD) : "memory");
+        };
+        dma(0); dma(1); dma(2);
+        landed();
+        prologue(0);
+        for (int i = 0; i < cnt; ++i) {
+            __syncthreads();                                           // tile i published; slots of tile i-1 are free
+            dma(i + 3);
+            landed();                                                  // tile i+1 has landed (this wave's units)
+            if (i + 1 < cnt) prologue(i + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the clamped extra tiles: nothing lands after this
+    } else {
+        // ---- consumers -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) acc[j][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // per k step: window offsets (two halves of a fragment) and swizzled dy offsets (per output-channel fragment)
+        int offA[KSW][2], offD[KSW][NCF][2];
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = (kh * KSW + ks) * 32 + 16 * j + 4 * lg + (l15 >> 2);
+                const int r = m >> LGW, c = m & (W - 1);
+                const int colb = (l15 & 3) * 8;
+                offA[ks][j] = (r * PC + c) * APITCH + colb + wb * 16 * ESZ;
+                const int fh = (m >> 1) & 3;
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf)
+                    offD[ks][cf][j] = m * DROW + (((colb >> 4) + 2 * (cf ^ fh)) << 4) + (colb & 15);
+            }
+        for (int i = 0; i < cnt; ++i) {
+            __syncthreads();
+            const char* ldsA = ldsA0 + (i & 1) * a_bytes;
+            const char* ldsD = ldsD0 + (i % WG_ND) * WG_DSLOT;
+            if (do_bias) {
+                const int col = rtid & 63, part = rtid >> 6;
+#pragma unroll 8
+                for (int r = 0; r < WG_BM / 4; ++r) {
+                    const int row = part * (WG_BM / 4) + r;
+                    const int cb = col * ESZ;
+                    bsum += E::to_f(*reinterpret_cast<const T*>(ldsD + row * DROW + ((((cb >> 4) ^ (((row >> 1) & 3) << 1))) << 4) + (cb & 15)));
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                typename M::frag dfrag[NCF];
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf) dfrag[cf] = KF::read(ldsD, offD[ks][cf], 0);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int tapoff = ((j / KS) * PC + (j % KS)) * APITCH;
+                    const typename M::frag afrag = KF::read(ldsA, offA[ks], tapoff);
+#pragma unroll
+                    for (int cf = 0; cf < NCF; ++cf) M::run(dfrag[cf], afrag, acc[j][cf]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                 // every tile is consumed and every DMA has landed: LDS is free
+    // the two pixel halves meet in LDS: waves 2/3 park their accumulators, waves 0/1 add them and write the slab
+    f32x4* park = reinterpret_cast<f32x4*>(smem);     // [wb][plane][cf][lane]: NV * 8 KB
+    if (!producer && kh == 1) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) park[((wb * NV + j) * NCF + cf) * 64 + lane] = acc[j][cf];
+    }
+    __syncthreads();
+    if (producer) return;
+    if (kh == 0) {
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
+        float* out = p.slabs + (size_t)wi.bz * slab_elems;      // slab[z][q][tap][co][32]
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int col = wb * 16 + l15;
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) {
+                const f32x4 o = park[((wb * NV + j) * NCF + cf) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + cf * 16 + lg * 4 + r;
+                    if (co < p.Cout_w)
+                        out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r] + o[r];
+                }
+            }
+        }
+    }
+    if (do_bias) {
+        const int col = rtid & 63, part = rtid >> 6;
+        if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)wi.bz * 4 + part) * p.Cout_w + co0 + col] = bsum;
+    }
+}
+
 // Sums the split slabs in slab order (coalesced 16-byte reads, 4 splits in flight) and scatters into
 // the master layout.
 __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int splits, size_t slab_elems,
@@ -612,6 +868,24 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
             }
             hipLaunchKernelGGL(kd, grid, dim3(2 * WG_NT), ldsd, st, *p, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(pc, dy dma)");
+            return 0;
+        }
+    }
+    if constexpr (sizeof(T) == 2 && (1 << LGW) <= WG_BM) {
+        // ring form: bf16, every tile inside one image, no upsampled reads, and the rings fit in LDS
+        static const int ring = getenv("MCGEN_WGRAD_RING") ? atoi(getenv("MCGEN_WGRAD_RING")) : 1;
+        const int nix = (PP * 4 + WG_NT - 1) / WG_NT;
+        const int ldsr = std::max(2 * a_bytes + WG_NR * nix * WG_NT * 16 + WG_ND * WG_DSLOT + WG_NR * 4 * 128, KS * KS * 8192);
+        if (pc && ring && (long)p->H * p->W >= WG_BM && !p->seg.ups && !p->dy_ups && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
+            auto kr = wgrad_ring_kernel<KS, LGW>;
+            static bool raisedr = false;
+            if (!raisedr) {
+                raisedr = true;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, ldsr);
+                if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(kr, grid, dim3(2 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
+            MCGEN_LAUNCH_CHECK("wgrad(ring)");
             return 0;
         }
     }

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'conv_' not in k and 'wgrad_kernel' not in k:
+            if 'conv_' not in k and 'wgrad_' not in k:
                 continue
             acc[k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, c in acc.items():
