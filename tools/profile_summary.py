@@ -24,6 +24,9 @@ def bench_name(k: str):
         return f'conv_fused<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)},{m.group(3)}>'
     if 'wgrad_reduce' in k:
         return None
+    m = re.search(r'wgrad_ring_kernel(?:ILi|<)(\d+)', k)        # bf16-only LDS-DMA ring form
+    if m:
+        return f'wgrad<bf16,{m.group(1)}>'
     m = re.search(r'wgrad_(?:pc_)?kernelI(DF16b|f)Li(\d+)E', k)
     if m:
         return f'wgrad<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)}>'
