@@ -188,34 +188,40 @@ __global__ void mc_apply_kernel(const T* __restrict__ x, const float* __restrict
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------------
-// Block = 64 channels (lane = channel, coalesced) x 16 waves that split the partial-sum rows;
-// fp64 accumulation, waves combined in a fixed order (deterministic).
+// Block = 16 channels x 64 row slots (1024 threads: thread = slot * 16 + channel); the slots split the partial-sum
+// rows, fp64 accumulation, slots combined in a fixed order (deterministic).  16 channels per block instead of 64:
+// these kernels sit on the critical path between two convolutions and a 256-channel layer used to run on 4 CUs
+// with 32 dependent iterations per wave (9.5 us); 16 blocks x 8 iterations take a third of that.
 constexpr int RED_WAVES = 16;
+constexpr int RED_CPB = 16, RED_SLOTS = 64 * RED_WAVES / RED_CPB;
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int rows_total, int pitch, int fold, int C,
-                                                int c, bool live, double& s1, double& s2, double (*sh)[2][64]) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                                                int c, bool live, double& s1, double& s2, double (*sh)[2][RED_CPB]) {
+    const int slot = threadIdx.x / RED_CPB, ch = threadIdx.x % RED_CPB;
     double a = 0.0, b = 0.0;
-    if (live)
-        for (int r = wave; r < rows_total; r += RED_WAVES) {
+    if (live) {
+#pragma unroll 4
+        for (int r = slot; r < rows_total; r += RED_SLOTS) {
             const int t = r / fold, f = r - t * fold;
             a += (double)part[((size_t)t * 2 + 0) * pitch + f * C + c];
             b += (double)part[((size_t)t * 2 + 1) * pitch + f * C + c];
         }
-    sh[wave][0][lane] = a; sh[wave][1][lane] = b;
+    }
+    sh[slot][0][ch] = a; sh[slot][1][ch] = b;
     __syncthreads();
     s1 = 0.0; s2 = 0.0;
-    for (int w = 0; w < RED_WAVES; ++w) { s1 += sh[w][0][lane]; s2 += sh[w][1][lane]; }
+    if (threadIdx.x < RED_CPB)
+        for (int w = 0; w < RED_SLOTS; ++w) { s1 += sh[w][0][ch]; s2 += sh[w][1][ch]; }
 }
 __global__ __launch_bounds__(64 * RED_WAVES)
 void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
                         const float* __restrict__ gamma, const float* __restrict__ beta,
                         float* rmean, float* rvar, float momentum, float eps,
                         float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
-    __shared__ double sh[RED_WAVES][2][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double sh[RED_SLOTS][2][RED_CPB];
+    const int c = blockIdx.x * RED_CPB + (threadIdx.x % RED_CPB);
     double s1, s2;
     reduce_partials(part, tiles * fold, pitch, fold, C, c, c < C, s1, s2, sh);
-    if (threadIdx.x >= 64 || c >= C) return;
+    if (threadIdx.x >= RED_CPB || c >= C) return;
     s1 *= perturb1; s2 *= perturb2;                      // 1.0 unless the sensitivity probe (MCGEN_BN_PERTURB) is on
     const double mean = s1 / count;
     double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
@@ -239,11 +245,11 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 __global__ __launch_bounds__(64 * RED_WAVES)
 void bn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int C,
                             float* dgamma, float* dbeta, float* sums, int accumulate) {
-    __shared__ double sh[RED_WAVES][2][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double sh[RED_SLOTS][2][RED_CPB];
+    const int c = blockIdx.x * RED_CPB + (threadIdx.x % RED_CPB);
     double s1, s2;
     reduce_partials(part, tiles, pitch, 1, C, c, c < C, s1, s2, sh);
-    if (threadIdx.x >= 64 || c >= C) return;
+    if (threadIdx.x >= RED_CPB || c >= C) return;
     sums[c] = (float)s1; sums[C + c] = (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
@@ -648,7 +654,7 @@ extern "C" int mcgen_bn_finalize(const float* partials, int tiles, int pitch, in
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
                 "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
                        gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
                        1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
     MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
@@ -662,7 +668,7 @@ extern "C" int mcgen_bn_eval_affine(const float* gamma, const float* beta, const
 extern "C" int mcgen_bn_bwd_finalize(const float* partials, int tiles, int pitch, int C, float* dgamma, float* dbeta,
                                      float* sums, int accumulate, void* stream) {
     MCGEN_CHECK(partials && sums && tiles > 0 && pitch >= C, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, C, dgamma, dbeta, sums, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, C, dgamma, dbeta, sums, accumulate);
     MCGEN_LAUNCH_CHECK("bn_bwd_finalize"); return 0;
 }
 extern "C" int mcgen_bn_bwd_apply(const void* dz, const void* x, const void* add, void* dx, int dtype, int64_t pixels, int C,
