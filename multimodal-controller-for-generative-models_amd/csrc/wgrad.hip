@@ -491,7 +491,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     }
 }
 
-// ---- "ring" form (bf16, tiles inside one image, no upsampled reads) ------------------------------------------------
+// ---- "ring" form (bf16, tiles inside one image) --------------------------------------------------------------------
 // What bounds wgrad_pc_kernel on the 256 -> 256, 32x32 layer (2.08 us per 128-pixel tile against 0.48 us of MFMA; sides
 // removed one at a time: consumers alone 1.7 us, producers alone 1.65 us):
 //  * producers: a tile's loads were issued one tile ahead, so a tile cost a memory round trip (a deeper REGISTER pipeline
@@ -568,7 +568,9 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
             const bool item = pp < PP;
             x_lds[k] = item ? pp * APITCH + sub * ESZ : -1;
             x_dh[k] = (item && cok && w >= 0 && w < W) ? pr - halo : (1 << 20);   // never passes the row test
-            x_off[k] = ((pr - halo) * W + w) * sg.C + sub;
+            // nearest-x2 upsampled input: the source pixel of (h, w) is (h >> 1, w >> 1); tiles start on even rows, so the
+            // halving splits into a tile part and this constant part
+            x_off[k] = (sg.ups ? (((pr - halo) >> 1) * (W >> 1) + (w >> 1)) : ((pr - halo) * W + w)) * sg.C + sub;
         }
         float sc[8], sh[8];
 #pragma unroll
@@ -584,13 +586,20 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
             const int m = (wave * 4 + k) * 8 + (lane >> 3);
             int u = (lane & 7) ^ (((m >> 1) & 3) << 1);
             if ((co0 + u * 8 + 8) > p.Cdy) u = 0;                      // beyond the dy pitch: any in-bounds unit (rows dropped at the end)
-            d_src[k] = (size_t)m * dpix + (size_t)co0 * ESZ + u * 16;
+            const int mp = p.dy_ups ? ((m >> LGW) >> 1) * (W >> 1) + ((m & (W - 1)) >> 1) : m;    // dy through an upsample: as x
+            d_src[k] = (size_t)mp * dpix + (size_t)co0 * ESZ + u * 16;
         }
+        // first source pixel of a tile (x / dy), directly or through the x2 upsample
+        auto first_pixel = [&](int pix0, bool up) -> size_t {
+            if (!up) return (size_t)pix0;
+            const int n0 = pix0 >> lgHW, h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
+            return ((size_t)n0 * (H >> 1) + (h0 >> 1)) * (W >> 1);
+        };
         auto tile_of = [&](int i) { return t_first + (i < cnt ? i : cnt - 1) * zs; };
         auto dma = [&](int i) {                                        // tile i -> R[i % 3], D[i % 4]; LD instructions per wave
             const int pix0 = tile_of(i) * WG_BM;
             const int h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
-            const char* xb = xs + ((size_t)pix0 * sg.C + c0) * ESZ;
+            const char* xb = xs + (first_pixel(pix0, sg.ups) * sg.C + c0) * ESZ;
             char* rs = ldsR0 + (i % WG_NR) * RSLOT + wave * 1024;
 #pragma unroll
             for (int k = 0; k < NIX; ++k) {
@@ -599,7 +608,7 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(rs + k * (WG_NT * 16)), 16, 0, 0);
             }
-            const char* db = dyb + (size_t)pix0 * dpix;
+            const char* db = dyb + first_pixel(pix0, p.dy_ups) * dpix;
             char* ds = ldsD0 + (i % WG_ND) * WG_DSLOT + wave * 4096;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -872,11 +881,13 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
         }
     }
     if constexpr (sizeof(T) == 2 && (1 << LGW) <= WG_BM) {
-        // ring form: bf16, every tile inside one image, no upsampled reads, and the rings fit in LDS
+        // ring form: bf16, every tile inside one image, and the rings fit in LDS
         static const int ring = getenv("MCGEN_WGRAD_RING") ? atoi(getenv("MCGEN_WGRAD_RING")) : 1;
         const int nix = (PP * 4 + WG_NT - 1) / WG_NT;
         const int ldsr = std::max(2 * a_bytes + WG_NR * nix * WG_NT * 16 + WG_ND * WG_DSLOT + WG_NR * 4 * 128, KS * KS * 8192);
-        if (pc && ring && (long)p->H * p->W >= WG_BM && !p->seg.ups && !p->dy_ups && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
+        // (upsampled reads need tiles that start on even rows: at least two rows per tile)
+        const bool ups_ok = (!p->seg.ups && !p->dy_ups) || (WG_BM / (1 << LGW)) % 2 == 0;
+        if (pc && ring && (long)p->H * p->W >= WG_BM && ups_ok && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
             auto kr = wgrad_ring_kernel<KS, LGW>;
             static bool raisedr = false;
             if (!raisedr) {

@@ -214,6 +214,13 @@ WG_CASES = [
     (8, 16, 160, 80, 1, False, False),      # 1x1 with 5 chunks: one chunk group of 4 + a ragged one (producer/consumer path)
     (8, 16, 256, 48, 1, True, False),
     (8, 16, 128, 128, 1, False, True),      # D shortcut: 1x1 chunk group with the pooled (dy_ups) gradient
+    # many tiles per split (8th entry = splits): the producer/consumer kernels; in bf16 the LDS-DMA ring form
+    (16, 32, 40, 72, 3, False, False, 2),
+    (16, 32, 64, 64, 3, True, False, 2),    # x through the x2 upsample
+    (16, 32, 32, 64, 3, False, True, 2),    # dy through the x2 upsample (pooled gradient)
+    (16, 16, 40, 24, 3, True, True, 2),
+    (16, 32, 8, 128, 1, False, True, 4),    # D's first shortcut
+    (8, 16, 96, 40, 1, True, False, 2),
 ]
 
 
@@ -221,7 +228,8 @@ WG_CASES = [
 @pytest.mark.parametrize('case', WG_CASES)
 def test_wgrad(case, dtype):
     ops = _ops()
-    n, h, ci, co, ks, ups, dy_ups = case
+    n, h, ci, co, ks, ups, dy_ups = case[:7]
+    splits = case[7] if len(case) > 7 else None
     g = torch.Generator().manual_seed(23 + h + ci)
     hs = h // 2 if ups else h
     x = _rnd(g, n, ci, hs, hs)
@@ -240,7 +248,8 @@ def test_wgrad(case, dtype):
     grad = torch.full((co, ci, ks, ks), 1.0, device='cuda')
     seg = ops.Seg(_nhwc(ops, x, dtype), ksize=ks, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=ups, relu=True)
     bg, bg2 = torch.full((co,), 2.0, device='cuda'), torch.full((co,), 3.0, device='cuda')
-    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, alpha=0.25, accumulate=True, bias_grad=bg, bias_grad2=bg2)
+    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, alpha=0.25, accumulate=True, bias_grad=bg, bias_grad2=bg2,
+              splits=splits)
     _assert_close(grad - 1.0, ref, dtype, 'wgrad')
     _assert_close(bg - 2.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad')
     _assert_close(bg2 - 3.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad (second output)')
