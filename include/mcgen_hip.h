@@ -228,6 +228,11 @@ int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w,
 int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, const float* code, const float* w,
                     const float* sigma, const float* pooled, void* dx, float* dw, float* db,
                     int N, int HW, int C, int accumulate, void* stream);
+/* Paired pass (D(real) and D(fake) as one 2N batch, gan_engine.DiscriminatorEngine.forward_pair): the tail's weight and bias
+ * gradients per half.  dlogit[2N], pooled[2N][C]; dw1/db1 from rows [0, N), dw2/db2 from rows [N, 2N) with dw2 divided
+ * by ratio[0] (= sigma_1 / sigma_2 of the tail layer, which the second half's pooled features carry). */
+int mcgen_dtail_pair_wgrad(const float* dlogit, const float* pooled, const float* ratio, int N, int C,
+                           float* dw1, float* db1, float* dw2, float* db2, void* stream);
 
 /* Hinge losses (train_gan.py:154,172).  d: loss = mean relu(1-real) + mean relu(1+fake);
  * g: loss = -mean(fake).  Writes the loss and d(loss)/d(logit). */

@@ -738,6 +738,45 @@ extern "C" int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, co
     MCGEN_LAUNCH_CHECK("dtail_bwd"); return 0;
 }
 
+// Paired discriminator pass: tail weight / bias gradients of the two halves of a 2N batch in one launch (blockIdx.y =
+// half); the second half's pooled features carry sigma_1 / sigma_2, which `ratio` divides out of its weight gradient.
+__global__ __launch_bounds__(256)
+void dtail_pair_w_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled, const float* __restrict__ ratio,
+                         float* dw1, float* db1, float* dw2, float* db2, int N, int C) {
+    __shared__ float sh[4][64];
+    const int half = blockIdx.y;
+    const float* dl = dlogit + (size_t)half * N;
+    const float* pl = pooled + (size_t)half * N * C;
+    float* dw = half ? dw2 : dw1;
+    float* db = half ? db2 : db1;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int n0 = part * ((N + 3) / 4), n1 = min(N, n0 + (N + 3) / 4);
+    float s = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int n = n0; n < n1; ++n) s = fmaf(dl[n], pl[(size_t)n * C + c], s);
+    }
+    sh[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        dw[c] = half ? t / ratio[0] : t;
+    }
+    if (blockIdx.x == 0 && part == 1) {
+        float t = 0.f;
+        for (int n = lane; n < N; n += 64) t += dl[n];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        if (lane == 0) db[0] = t;
+    }
+}
+extern "C" int mcgen_dtail_pair_wgrad(const float* dlogit, const float* pooled, const float* ratio, int N, int C,
+                                      float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+    MCGEN_CHECK(dlogit && pooled && ratio && dw1 && db1 && dw2 && db2 && N > 0 && C > 0, "dtail_pair_wgrad: bad arguments");
+    hipLaunchKernelGGL(dtail_pair_w_kernel, dim3((C + 63) / 64, 2), dim3(256), 0, STREAM(stream), dlogit, pooled, ratio, dw1, db1, dw2, db2, N, C);
+    MCGEN_LAUNCH_CHECK("dtail_pair_wgrad"); return 0;
+}
+
 extern "C" int mcgen_hinge_d(const float* real, const float* fake, int N, float* loss, float* dreal, float* dfake, void* stream) {
     MCGEN_CHECK(real && fake && loss && dreal && dfake && N > 0, "hinge_d: bad arguments");
     hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, STREAM(stream), real, fake, N, loss, dreal, dfake);

@@ -574,13 +574,10 @@ class DiscriminatorEngine:
             else:
                 dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'], None, None)
                 # tail weight / bias gradients per half; the fake half's pooled features carry sigma_1 / sigma_2
-                gp = dlogit.view(-1, 1) * ctx['pooled']
-                n1 = pair['n']
-                r_t = pair['ratio'][tl.idx]
-                for k, (sl, gtmp) in enumerate(passes):
-                    gw = gp[sl].sum(0)
-                    self.flat_p.view_of(gtmp, wl).view(-1).copy_(gw if k == 0 else gw / r_t)
-                    self.flat_p.view_of(gtmp, self.tail_lin.bias).view(-1).copy_(dlogit[sl].sum().view(1))
+                (_, g_a), (_, g_b) = passes
+                ops.dtail_pair_wgrad(dlogit, ctx['pooled'], pair['ratio'][tl.idx:tl.idx + 1],
+                                     self.flat_p.view_of(g_a, wl).view(-1), self.flat_p.view_of(g_a, self.tail_lin.bias).view(-1),
+                                     self.flat_p.view_of(g_b, wl).view(-1), self.flat_p.view_of(g_b, self.tail_lin.bias).view(-1))
             for bi in reversed(range(1, len(self.res))):
                 b, bc = self.res[bi], ctx['blocks'][bi]
                 x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']

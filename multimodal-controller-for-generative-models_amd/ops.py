@@ -452,6 +452,16 @@ def dtail_bwd(dlogit: Tensor, x: Tensor, code, w, sigma, pooled, dw: Optional[Te
     return dx
 
 
+def dtail_pair_wgrad(dlogit: Tensor, pooled: Tensor, ratio: Tensor, dw1: Tensor, db1: Tensor, dw2: Tensor, db2: Tensor):
+    """Tail weight / bias gradients of the two halves of a paired discriminator pass (dw2 divided by ratio[0])."""
+    n2, c = pooled.shape
+    for t in (dw1, db1, dw2, db2):
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise _lib.McgenError('dtail_pair_wgrad: outputs must be contiguous fp32')
+    check(_lib.load().mcgen_dtail_pair_wgrad(_f32(dlogit), _f32(pooled), _f32(ratio), n2 // 2, c,
+                                             _f32(dw1), _f32(db1), _f32(dw2), _f32(db2), _stream()), 'dtail_pair_wgrad')
+
+
 def hinge_d(real: Tensor, fake: Tensor):
     n = real.numel()
     out = torch.empty(1 + 2 * n, dtype=torch.float32, device=real.device)
