@@ -426,7 +426,7 @@ class DiscriminatorEngine:
         ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None}
         return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
 
-    def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor):
+    def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None):
         """D(real) and D(fake) of one discriminator update (train_gan.py:144-150) as ONE pass over the 2N batch.
         The two forwards of the reference differ only in the spectral-norm state (each runs its own power iteration,
         which depends on the weights alone): conv(x; W / sigma_2) = (sigma_1 / sigma_2) * conv(x; W / sigma_1), so the
@@ -436,7 +436,8 @@ class DiscriminatorEngine:
         sigma1, uv1 = self._power_iter(True)
         sigma2, uv2 = self._power_iter(True)
         ratio = sigma1 / sigma2
-        ind2 = torch.cat([indicator, indicator])
+        if ind2 is None:
+            ind2 = torch.cat([indicator, indicator])
         uses = self._code_uses()
         if getattr(self, '_codes_pair', None) is None:
             # one job per convolution input: the MC's codebook (an all-ones table for the image inputs, which have no

@@ -462,11 +462,15 @@ def dtail_pair_wgrad(dlogit: Tensor, pooled: Tensor, ratio: Tensor, dw1: Tensor,
                                              _f32(dw1), _f32(db1), _f32(dw2), _f32(db2), _stream()), 'dtail_pair_wgrad')
 
 
-def hinge_d(real: Tensor, fake: Tensor):
+def hinge_d(real: Tensor, fake: Tensor, both: bool = False):
+    """(loss, d loss / d real, d loss / d fake) of the discriminator hinge loss; `both`: also the two gradients as one
+    contiguous [2N] tensor (they are views of it)."""
     n = real.numel()
     out = torch.empty(1 + 2 * n, dtype=torch.float32, device=real.device)
     check(_lib.load().mcgen_hinge_d(_f32(real), _f32(fake), n, out.data_ptr(), out[1:1 + n].data_ptr(),
                                     out[1 + n:].data_ptr(), _stream()), 'hinge_d')
+    if both:
+        return out[0], out[1:1 + n], out[1 + n:], out[1:]
     return out[0], out[1:1 + n], out[1 + n:]
 
 

@@ -82,16 +82,17 @@ class GANTrainer:
             allreduce_mean_(g, self.world, self.group)
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
-    def d_compute(self, img, ind, z):
+    def d_compute(self, img, ind, z, ind2=None):
+        """`ind2` (optional): the indicator twice, [2N, modes] -- constant over the D updates of an iteration, so the caller
+        builds it once instead of one concatenation per update."""
         if _PAIR_D:
             # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
             # power iterations of the two reference forwards depend on the weights alone and run first, in order
             fake, _ = self.geng.forward(z, ind, True)
-            logits, ctx = self.deng.forward_pair(img, fake, ind)
+            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2)
             n = img.shape[0]
             lg = logits.view(-1)
-            loss, dreal, dfake = ops.hinge_d(lg[:n], lg[n:])
-            dboth = torch.cat([dreal, dfake])
+            loss, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) sit side by side
             self.deng.backward(ctx, dboth, self.grad_d, False, False)
             return loss
         d_real, ctx_r = self.deng.forward(img, ind, True)
@@ -117,8 +118,8 @@ class GANTrainer:
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
 
-    def d_update(self, img, ind, z):
-        loss = self.d_compute(img, ind, z)
+    def d_update(self, img, ind, z, ind2=None):
+        loss = self.d_compute(img, ind, z, ind2)
         self._allreduce(self.grad_d)
         self.d_apply()
         return loss
@@ -135,12 +136,13 @@ class GANTrainer:
         last D and G update, as the reference logs them (train_gan.py:177)."""
         self.model.train(True)
         n = img.shape[0]
-        ind = F.one_hot(label, self.classes).float()
+        ind2 = F.one_hot(label, self.classes).float().repeat(2, 1)
+        ind = ind2[:n]
         zi = iter(zs) if zs is not None else None
         draw = (lambda: next(zi)) if zi is not None else (lambda: torch.randn(n, self.latent, device=img.device))
         d_loss = g_loss = None
         for _ in range(self.d_iters):
-            d_loss = self.d_update(img, ind, draw())
+            d_loss = self.d_update(img, ind, draw(), ind2)
         for _ in range(self.g_iters):
             g_loss = self.g_update(ind, draw())
         return d_loss, g_loss
@@ -160,14 +162,15 @@ class GraphedGANTrainer(GANTrainer):
         n = img.shape[0]
         dev = img.device
         self.s_img = img.clone()
-        self.s_ind = F.one_hot(label, self.classes).float()
+        self.s_ind2 = F.one_hot(label, self.classes).float().repeat(2, 1)
+        self.s_ind = self.s_ind2[:n]
         self.s_z = torch.randn(n, self.latent, device=dev)
         self.model.train(True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                self.d_update(self.s_img, self.s_ind, self.s_z)
+                self.d_update(self.s_img, self.s_ind, self.s_z, self.s_ind2)
                 self.g_update(self.s_ind, self.s_z)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -175,7 +178,7 @@ class GraphedGANTrainer(GANTrainer):
         self.g_gc, self.g_ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_dc, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
-            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z)
+            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z, self.s_ind2)
         pool = self.g_dc.pool()
         with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.d_apply()
@@ -193,7 +196,9 @@ class GraphedGANTrainer(GANTrainer):
         if self._graphs is None or zs is not None:
             return super().train_iteration(img, label, zs)
         self.s_img.copy_(img, non_blocking=True)
-        self.s_ind.copy_(F.one_hot(label, self.classes).float(), non_blocking=True)
+        oh = F.one_hot(label, self.classes).float()
+        n = oh.shape[0]
+        self.s_ind2[:n].copy_(oh, non_blocking=True); self.s_ind2[n:].copy_(oh, non_blocking=True)
         for _ in range(self.d_iters):
             self.g_dc.replay()
             self._allreduce(self.grad_d)
