@@ -843,8 +843,29 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
     // the role split only pays when a workgroup walks several tiles (staging of tile i+1 overlaps tile i)
     const bool pc = mode ? (mode[0] == '1') : (m_tiles >= 4 * p->splits);
+    if constexpr (sizeof(T) == 2 && (1 << LGW) <= WG_BM) {
+        // ring form: bf16, every tile inside one image, and the rings fit in LDS.  First choice, also for 1x1 gradients with
+        // many chunks (measured against the chunk groups below: 128->128 at 16x16 47 -> 24 us, 256->256 at 32x32 134 -> 118)
+        static const int ring = getenv("MCGEN_WGRAD_RING") ? atoi(getenv("MCGEN_WGRAD_RING")) : 1;
+        const int nix = (PP * 4 + WG_NT - 1) / WG_NT;
+        const int ldsr = std::max(2 * a_bytes + WG_NR * nix * WG_NT * 16 + WG_ND * WG_DSLOT + WG_NR * 4 * 128, KS * KS * 8192);
+        // (upsampled reads need tiles that start on even rows: at least two rows per tile)
+        const bool ups_ok = (!p->seg.ups && !p->dy_ups) || (WG_BM / (1 << LGW)) % 2 == 0;
+        if (pc && ring && (long)p->H * p->W >= WG_BM && ups_ok && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
+            auto kr = wgrad_ring_kernel<KS, LGW>;
+            static bool raisedr = false;
+            if (!raisedr) {
+                raisedr = true;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, ldsr);
+                if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(kr, grid, dim3(2 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
+            MCGEN_LAUNCH_CHECK("wgrad(ring)");
+            return 0;
+        }
+    }
     if constexpr (KS == 1) {
-        // 1x1: chunk groups of 4 when there are enough chunks (see wgrad_pc_kernel)
+        // 1x1 on small maps (no ring form): chunk groups of 4 when there are enough chunks (see wgrad_pc_kernel)
         constexpr int NCH = 4;
         const char* g = getenv("MCGEN_WGRAD_GROUP");
         const int lds4 = 2 * NCH * a_bytes + 2 * WG_BM * TR::DPITCH;     // bf16: 136 KB; fp32 does not fit -> plain path
@@ -877,26 +898,6 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
             }
             hipLaunchKernelGGL(kd, grid, dim3(2 * WG_NT), ldsd, st, *p, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(pc, dy dma)");
-            return 0;
-        }
-    }
-    if constexpr (sizeof(T) == 2 && (1 << LGW) <= WG_BM) {
-        // ring form: bf16, every tile inside one image, and the rings fit in LDS
-        static const int ring = getenv("MCGEN_WGRAD_RING") ? atoi(getenv("MCGEN_WGRAD_RING")) : 1;
-        const int nix = (PP * 4 + WG_NT - 1) / WG_NT;
-        const int ldsr = std::max(2 * a_bytes + WG_NR * nix * WG_NT * 16 + WG_ND * WG_DSLOT + WG_NR * 4 * 128, KS * KS * 8192);
-        // (upsampled reads need tiles that start on even rows: at least two rows per tile)
-        const bool ups_ok = (!p->seg.ups && !p->dy_ups) || (WG_BM / (1 << LGW)) % 2 == 0;
-        if (pc && ring && (long)p->H * p->W >= WG_BM && ups_ok && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
-            auto kr = wgrad_ring_kernel<KS, LGW>;
-            static bool raisedr = false;
-            if (!raisedr) {
-                raisedr = true;
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, ldsr);
-                if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
-            }
-            hipLaunchKernelGGL(kr, grid, dim3(2 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
-            MCGEN_LAUNCH_CHECK("wgrad(ring)");
             return 0;
         }
     }

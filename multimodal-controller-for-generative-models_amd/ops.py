@@ -268,7 +268,10 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     nchunk = (seg.x.shape[-1] + 31) // 32
     if splits is None:
         # 1x1 gradients with >= 4 chunks run as chunk groups of 4 (wgrad.hip): a quarter of the workgroups per split
-        blocks = ((pad16(cout) + 63) // 64) * ((nchunk + 3) // 4 if (seg.ksize == 1 and nchunk >= 4 and dtype == torch.bfloat16) else nchunk)
+        # (wgrad.hip: the ring form -- bf16, tiles inside one image -- comes first; chunk groups are for the small maps)
+        ring = dtype == torch.bfloat16 and h * w >= 128 and w <= 64 and (n * h * w) % 128 == 0
+        grouped = seg.ksize == 1 and nchunk >= _WG_GROUP_MIN and dtype == torch.bfloat16 and not ring
+        blocks = ((pad16(cout) + 63) // 64) * ((nchunk + 3) // 4 if grouped else nchunk)
         # enough workgroups to fill the chip matters more than the slab traffic (measured: 8x8 layers lose
         # 20 % with 16 instead of 64 splits)
         target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL
@@ -340,6 +343,7 @@ class _nullctx:
         return False
 
 
+_WG_GROUP_MIN = 1 << 30 if _os.environ.get('MCGEN_WGRAD_GROUP', '1') == '0' else 4      # chunks from which a 1x1 gradient runs as chunk groups
 _WG_TARGET = int(_os.environ.get('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
 _WG_TARGET_SMALL = int(_os.environ.get('MCGEN_WGRAD_TARGET_SMALL', '256'))
 _WG_BIG_TILES = int(_os.environ.get('MCGEN_WGRAD_BIG_TILES', '256'))
