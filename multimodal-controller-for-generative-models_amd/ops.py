@@ -275,7 +275,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         # enough workgroups to fill the chip matters more than the slab traffic (measured: 8x8 layers lose
         # 20 % with 16 instead of 64 splits)
         target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL
-        splits = max(1, min(m_tiles, (target + blocks - 1) // blocks, 64))
+        splits = max(1, min(m_tiles, (target + blocks - 1) // blocks, _WG_MAX_SPLITS))
         if second is not None:
             splits = max(2, splits + (splits & 1))
     if second is not None and ((n * h * w) % 256 != 0 or splits % 2):
@@ -344,6 +344,7 @@ class _nullctx:
 
 
 _WG_GROUP_MIN = 1 << 30 if _os.environ.get('MCGEN_WGRAD_GROUP', '1') == '0' else 4      # chunks from which a 1x1 gradient runs as chunk groups
+_WG_MAX_SPLITS = int(_os.environ.get('MCGEN_WGRAD_MAX_SPLITS', '128'))   # (64 left the thin image layers -- 2 blocks -- on half the chip)
 _WG_TARGET = int(_os.environ.get('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
 _WG_TARGET_SMALL = int(_os.environ.get('MCGEN_WGRAD_TARGET_SMALL', '256'))
 _WG_BIG_TILES = int(_os.environ.get('MCGEN_WGRAD_BIG_TILES', '256'))
