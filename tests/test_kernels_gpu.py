@@ -255,6 +255,29 @@ def test_wgrad(case, dtype):
     _assert_close(bg2 - 3.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad (second output)')
 
 
+def test_dtail_pair_wgrad_and_hinge_both():
+    """Paired discriminator pass: tail weight / bias gradients of both halves in one launch (the second half divided by
+    sigma_1 / sigma_2), and the hinge gradients as one [2N] tensor."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    n, c = 24, 40
+    dlogit, pooled = _rnd(g, 2 * n), _rnd(g, 2 * n, c)
+    ratio = torch.tensor([1.25])
+    outs = [torch.full((c,), 7.0, device='cuda'), torch.full((1,), 7.0, device='cuda'),
+            torch.full((c,), 7.0, device='cuda'), torch.full((1,), 7.0, device='cuda')]
+    ops.dtail_pair_wgrad(dlogit.cuda(), pooled.cuda(), ratio.cuda(), *outs)
+    gp = dlogit.view(-1, 1).double() * pooled.double()
+    np.testing.assert_allclose(outs[0].cpu().numpy(), gp[:n].sum(0).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outs[2].cpu().numpy(), (gp[n:].sum(0) / 1.25).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outs[1].cpu().numpy(), dlogit[:n].double().sum().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outs[3].cpu().numpy(), dlogit[n:].double().sum().numpy(), rtol=1e-5, atol=1e-5)
+    real, fake = _rnd(g, n).cuda(), _rnd(g, n).cuda()
+    loss, dr, df, both = ops.hinge_d(real, fake, both=True)
+    assert both.shape == (2 * n,) and torch.equal(both[:n], dr) and torch.equal(both[n:], df)
+    loss3, dr3, df3 = ops.hinge_d(real, fake)
+    assert torch.equal(loss, loss3) and torch.equal(dr, dr3) and torch.equal(df, df3)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_linear_as_conv_rowperm(dtype):
     """Generator Linear(128 -> C*16) viewed [N, C, 4, 4] (mcgan.py:51,66-67) as a 1x1 conv whose
