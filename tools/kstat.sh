@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: rocprofv3 kernel stats of a short bench run; prints the conv / wgrad rows (tools/kstat.sh <tag>)
+set -e
+TAG=${1:-k}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/kstat_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
+f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:14]:
+    print(r['Name'][:86].ljust(86), r['Calls'].rjust(5), ('%.1f' % (float(r['AverageNs']) / 1e3)).rjust(8), r['Percentage'])
+PY
