@@ -196,7 +196,6 @@ template <typename T, int BM, int BN, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(64 * WM * WN)
 void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
-    using E = Elem<T>;
     using M = Mma<T>;
     constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW, EP = C::EP;
     constexpr int UPR = C::UPR, NU = C::NU;

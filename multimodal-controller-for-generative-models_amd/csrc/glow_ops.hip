@@ -513,8 +513,10 @@ extern "C" int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float
                                  const float* dW, int C, int ldw, float ld_coef, float* dw_l, float* dw_u, float* dw_s,
                                  int accumulate, void* stream) {
     MCGEN_CHECK(w_p && w_l && w_u && w_s && s_sign && dW && dw_l && dw_u && dw_s && C > 0 && C <= 64 && ldw >= C, "invconv_bwd: bad arguments");
-    if (6 * C * C * sizeof(float) > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(invconv_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * sizeof(float));
+    if (6 * C * C * sizeof(float) > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(invconv_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * sizeof(float));
+        if (e != hipSuccess) return mcgen_fail("invconv_bwd: cannot raise LDS limit: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(invconv_bwd_kernel, dim3(1), dim3(1024), 6 * C * C * sizeof(float), STREAM(stream),
                        w_p, w_l, w_u, w_s, s_sign, dW, C, ldw, ld_coef, dw_l, dw_u, dw_s, accumulate);
     MCGEN_LAUNCH_CHECK("invconv_bwd"); return 0;
