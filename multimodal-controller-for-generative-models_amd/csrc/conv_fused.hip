@@ -1408,6 +1408,10 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
         // staging latency (measured: MCGlow step -5 %); large maps keep 128 (MCGAN's 32x32 head)
         int bm16 = (M <= 32768) ? 64 : 128;
         if (const char* e = getenv("MCGEN_CONV_BM16")) bm16 = atoi(e);
+        // very large maps (MCGAN's 32x32 image head at batch 128: 1024 tiles of 128 pixels, three resident per CU = two
+        // rounds): 256-pixel tiles run as one round (dma3 form, 8 waves)
+        static const long big16 = getenv("MCGEN_CONV_BIG16") ? atol(getenv("MCGEN_CONV_BIG16")) : 131072;
+        if (dtype == MCGEN_BF16 && !getenv("MCGEN_CONV_BM16") && big16 > 0 && M >= big16 && 256 >= 2 * p->W) return {256, 16, 5};
         const int HW16 = p->H * p->W;
         // the chunk-pipelined form (12) wins on these K-deep, latency-bound launches (-15..20 %); elsewhere the extra LDS of
         // its two-step weight ring costs more occupancy than the prefetch gains (measured), so dma3 stays

@@ -181,11 +181,12 @@ def test_conv_dgrad_gate_bnstats(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_conv_tanh_small_cout(dtype):
+@pytest.mark.parametrize('n', [4, 128])        # 128 images of 32x32 = 131072 pixels: the 256-pixel skinny tile of large maps
+def test_conv_tanh_small_cout(dtype, n):
     """G head: BN->ReLU->MC->conv3x3(C->3)->tanh (mcgan.py:55-60)."""
     ops = _ops()
     g = torch.Generator().manual_seed(19)
-    n, c = 4, 32
+    c = 32
     x = _rnd(g, n, c, 32, 32)
     scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
     code = (torch.rand(n, c, generator=g) < 0.5).float()
