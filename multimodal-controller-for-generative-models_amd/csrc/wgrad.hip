@@ -502,11 +502,12 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 //    of a tile past the end is clamped).  The prologue is then an LDS -> LDS pass over the thread's own units, and
 //    everything tile-independent is a per-thread constant (LDS offset, element offset from the tile's first pixel, row
 //    offset): per tile an item costs a row-range test and an address add.
-//  * consumers: LDS, not MFMA.  PMC on this kernel: LDS busy 80 % of the kernel, ~12 cycles per ds_read_b64_tr_b16 (a
-//    third of the plain read rate), MFMA busy 24 %.  Each consumer wave owns ALL 64 output channels x 16 input channels
-//    over HALF of the tile's pixels (13 fragment reads per 36 MFMAs instead of 11 per 18; the halves are added once,
-//    through LDS, after the last tile).  Ordering the reads ahead of the MFMAs (sched_group_barrier) was slower.
-// Measured 598 -> 628 TFLOP/s on that layer (525 -> 548, 506 -> 524 on the next two): the transposing reads are the floor.
+//  * consumers: each consumer wave owns ALL 64 output channels x 16 input channels over HALF of the tile's pixels (13
+//    fragment reads per 36 MFMAs instead of 11 per 18; the halves are added once, through LDS, after the last tile).
+//    PMC: MFMA pipe 24 % busy, waves waiting 41 %, 2.9 SQ_LDS_IDX_ACTIVE counts per LDS instruction; reading fragments
+//    2-6 taps ahead of their MFMAs (sched_group_barrier) changed nothing -- what holds a lone consumer wave per SIMD at
+//    ~1.3 us per tile (0.48 us of MFMA) is not understood yet.
+// Measured 598 -> 628 TFLOP/s on that layer (525 -> 548, 506 -> 524 on the next two).
 constexpr int WG_DSLOT = WG_BM * WG_BCO * 2;      // one dy tile, unpadded bf16 rows
 constexpr int WG_ND = 4, WG_NR = 3;               // ring depths: dy tiles, raw windows
 template <int KS, int LGW>

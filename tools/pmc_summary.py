@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Average the PMC counters of the conv kernels in rocprofv3 counter_collection CSVs."""
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 for d in sys.argv[1:]:
-    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+    files = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                      # a directory accumulates one file per run: the newest
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
