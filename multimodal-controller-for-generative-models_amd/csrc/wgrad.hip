@@ -502,16 +502,16 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 //    of a tile past the end is clamped).  The prologue is then an LDS -> LDS pass over the thread's own units, and
 //    everything tile-independent is a per-thread constant (LDS offset, element offset from the tile's first pixel, row
 //    offset): per tile an item costs a row-range test and an address add.
-//  * consumers: each consumer wave owns ALL 64 output channels x 16 input channels over HALF of the tile's pixels (13
-//    fragment reads per 36 MFMAs instead of 11 per 18; the halves are added once, through LDS, after the last tile).
-//    PMC: MFMA pipe 24 % busy, waves waiting 41 %, 2.9 SQ_LDS_IDX_ACTIVE counts per LDS instruction; reading fragments
-//    2-6 taps ahead of their MFMAs (sched_group_barrier) changed nothing -- what holds a lone consumer wave per SIMD at
-//    ~1.3 us per tile (0.48 us of MFMA) is not understood yet.
-// Measured 598 -> 628 TFLOP/s on that layer (525 -> 548, 506 -> 524 on the next two).
+//  * consumers: EIGHT consumer waves, two per SIMD (a lone wave issues bare v_mfma_f32_16x16x32_bf16 at 55 % of the
+//    nominal peak on this part, two waves at 82 %: tools/micro/mfma_peak.hip), each 32 output channels x 16 input
+//    channels over HALF of the tile's pixels; the halves are added once, through LDS, after the last tile.  Tried on
+//    the way and neutral: all 64 output channels per wave (fewer LDS reads per MFMA), reading fragments 2-6 taps ahead
+//    of their MFMAs (sched_group_barrier) -- LDS is ~20 % busy, it was never the limit.
+// Measured 598 -> 641 TFLOP/s on that layer (525 -> 576, 506 -> 539 on the next two).
 constexpr int WG_DSLOT = WG_BM * WG_BCO * 2;      // one dy tile, unpadded bf16 rows
 constexpr int WG_ND = 4, WG_NR = 3;               // ring depths: dy tiles, raw windows
 template <int KS, int LGW>
-__global__ __launch_bounds__(2 * WG_NT, 1)
+__global__ __launch_bounds__(3 * WG_NT, 1)
 void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
     typedef bf16_t T;
     using E = Elem<T>;
@@ -519,7 +519,7 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     using TR = WgTraits<T>;
     using KF = KFrag<T>;
     constexpr int ESZ = 2, APITCH = TR::APITCH;
-    constexpr int NTAP = KS * KS, NV = NTAP, NCF = WG_BCO / 16;
+    constexpr int NTAP = KS * KS, NV = NTAP, NCF = WG_BCO / 32;      // output-channel fragments per consumer wave
     constexpr int W = 1 << LGW, halo = KS >> 1, PC = W + 2 * halo;
     constexpr int TH = WG_BM / W, PR = TH + 2 * halo, PP = PR * PC;     // tile rows, window rows, window pixels
     static_assert(WG_BM % W == 0 && TH >= 1, "tiles inside one image");
@@ -536,9 +536,11 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     char* const ldsC0 = ldsD0 + WG_ND * WG_DSLOT;                      // [WG_NR][4 waves][32 floats] code rows (per producer wave)
 
     const int tid = threadIdx.x;
-    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    // waves 0-7 consume (two per SIMD: a lone wave issues bare MFMAs at 55 % of peak on this part, two at 82 %,
+    // tools/micro/mfma_peak.hip), waves 8-11 produce
+    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 9) != 0;
     const int rtid = tid & 255;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const int lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6), wave = cw & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H;
     const WgIdx wi = wg_remap(xcd_map);
@@ -552,7 +554,7 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     const int cnt = (mt - wi.bz % zs + zs - 1) / zs;                   // tiles of this workgroup (>= 1)
     const bool do_bias = (p.bias_slabs != nullptr) && (q == 0);
     const int lgHW = 31 - __builtin_clz(H << LGW);
-    const int kh = wave >> 1, wb = wave & 1;                           // consumers: pixel half, input-channel half
+    const int kh = (cw >> 2) & 1, wa = (cw >> 1) & 1, wb = cw & 1;     // consumers: pixel half, output-channel half, input-channel half
 
     f32x4 acc[NV][NCF];
     float bsum = 0.f;
@@ -690,13 +692,13 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
                 const int fh = (m >> 1) & 3;
 #pragma unroll
                 for (int cf = 0; cf < NCF; ++cf)
-                    offD[ks][cf][j] = m * DROW + (((colb >> 4) + 2 * (cf ^ fh)) << 4) + (colb & 15);
+                    offD[ks][cf][j] = m * DROW + (((colb >> 4) + 2 * ((wa * NCF + cf) ^ fh)) << 4) + (colb & 15);
             }
         for (int i = 0; i < cnt; ++i) {
             __syncthreads();
             const char* ldsA = ldsA0 + (i & 1) * a_bytes;
             const char* ldsD = ldsD0 + (i % WG_ND) * WG_DSLOT;
-            if (do_bias) {
+            if (do_bias && tid < WG_NT) {
                 const int col = rtid & 63, part = rtid >> 6;
 #pragma unroll 8
                 for (int r = 0; r < WG_BM / 4; ++r) {
@@ -722,12 +724,13 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     }
     __syncthreads();                                 // every tile is consumed and every DMA has landed: LDS is free
     // the two pixel halves meet in LDS: waves 2/3 park their accumulators, waves 0/1 add them and write the slab
-    f32x4* park = reinterpret_cast<f32x4*>(smem);     // [wb][plane][cf][lane]: NV * 8 KB
+    f32x4* park = reinterpret_cast<f32x4*>(smem);     // [wa][wb][plane][cf][lane]: NV * 8 KB
+    const int pw = wa * 2 + wb;
     if (!producer && kh == 1) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int cf = 0; cf < NCF; ++cf) park[((wb * NV + j) * NCF + cf) * 64 + lane] = acc[j][cf];
+            for (int cf = 0; cf < NCF; ++cf) park[((pw * NV + j) * NCF + cf) * 64 + lane] = acc[j][cf];
     }
     __syncthreads();
     if (producer) return;
@@ -740,17 +743,17 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
             const int col = wb * 16 + l15;
 #pragma unroll
             for (int cf = 0; cf < NCF; ++cf) {
-                const f32x4 o = park[((wb * NV + j) * NCF + cf) * 64 + lane];
+                const f32x4 o = park[((pw * NV + j) * NCF + cf) * 64 + lane];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + cf * 16 + lg * 4 + r;
+                    const int co = co0 + (wa * NCF + cf) * 16 + lg * 4 + r;
                     if (co < p.Cout_w)
                         out[(((size_t)q * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][cf][r] + o[r];
                 }
             }
         }
     }
-    if (do_bias) {
+    if (do_bias && tid < WG_NT) {
         const int col = rtid & 63, part = rtid >> 6;
         if (co0 + col < p.Cout_w) p.bias_slabs[((size_t)wi.bz * 4 + part) * p.Cout_w + co0 + col] = bsum;
     }
@@ -860,7 +863,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, ldsr);
                 if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
             }
-            hipLaunchKernelGGL(kr, grid, dim3(2 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
+            hipLaunchKernelGGL(kr, grid, dim3(3 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(ring)");
             return 0;
         }
