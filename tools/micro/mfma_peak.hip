@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 int main() {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-    for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {        // 256-thread blocks: 1 or 2 waves per SIMD
+    for (int wg_per_cu = 1; wg_per_cu <= 4; ++wg_per_cu) {        // 256-thread blocks: 1 to 4 waves per SIMD
         const int blocks = 256 * wg_per_cu, iters = 20000;
         hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 1000);
         hipDeviceSynchronize();
