@@ -47,9 +47,11 @@ def build_model(dtype, device, data_name='CIFAR10'):
 
 
 def host_cores():
-    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (a GPU box
-    hands each job a share of a many-core host; oversubscribing it makes the baseline meaningless)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    """(threads to use, os.cpu_count(), cap) -- the threads this process may really use: affinity, capped by the
+    cgroup CPU quota and by MCGEN_CPU_THREADS (default 16 = the CPU share a one-GPU box hands a job; oversubscribing
+    a shared many-core host makes the baseline meaningless)."""
+    total = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else total
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
         if quota != 'max':
@@ -62,24 +64,30 @@ def host_cores():
                 n = min(n, max(1, int(q / p + 0.5)))
         except Exception:
             pass
-    return max(1, min(n, int(os.environ.get('MCGEN_CPU_THREADS', '16'))))
+    cap = int(os.environ.get('MCGEN_CPU_THREADS', '16'))
+    return max(1, min(n, cap)), total, cap
 
 
-def cpu_baseline(sd, batch, budget_s=40.0):
-    """The CPU oracle (oracle/mcgan_oracle.py, a port pinned to the reference by golden vectors)
-    on this host's cores: one full iteration at the benchmark's batch size."""
+def cpu_baseline(sd, batch, timed=2):
+    """The CPU oracle (oracle/mcgan_oracle.py, a port pinned to the reference by golden vectors) on this host's
+    cores, as BASELINE.md section 4 prescribes: 1 warm-up + `timed` timed iterations (5 D + 1 G updates each) at
+    the benchmark's batch size, same synthetic inputs."""
     import golden_util as gu
     from oracle import mcgan_oracle as O
-    cores = host_cores()
+    cores, total, cap = host_cores()
     torch.set_num_threads(cores)
     img, lab = gu.synthetic_batch(batch, 10, seed=1)
-    zs = gu.latent_batches(6, batch, 128, seed=2)
+    zs = gu.latent_batches(6 * (timed + 1), batch, 128, seed=2)
     m = O.OracleMCGAN(sd, classes=10)
+    m.train_iteration(img, lab, zs[:6])                       # warm-up: thread pool, first-touch, oneDNN primitives
     t0 = time.time()
-    m.train_iteration(img, lab, zs)
-    dt = time.time() - t0
+    for i in range(timed):
+        m.train_iteration(img, lab, zs[6 * (i + 1):6 * (i + 2)])
+    dt = (time.time() - t0) / timed
     return {'value': batch / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 iteration (5 D + 1 G updates) at batch {batch}, fp32, {dt:.1f} s'}
+            'host_cpu_count': total, 'thread_cap': cap,
+            'sample': f'1 warm-up + {timed} timed iterations (5 D + 1 G updates each) at batch {batch}, fp32, '
+                      f'{dt:.1f} s per iteration on {cores} threads (host reports {total} CPUs; cap MCGEN_CPU_THREADS={cap})'}
 
 
 def try_capture(capture, world, dev):
@@ -100,21 +108,46 @@ def try_capture(capture, world, dev):
     return bool(ok)
 
 
-def attach_traffic(roofline):
+def attach_traffic(roofline, workload, batch, dtype):
     """roofline.traffic = HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
-    command (profiles/traffic.json, written by tools/profile_summary.py: FETCH_SIZE x2 + WRITE_SIZE); None when the
-    table has no entry for that kernel.  PMC counters cannot be collected from inside the timed process."""
+    command (profiles/traffic.json, written by tools/profile_summary.py: FETCH_SIZE x2 + WRITE_SIZE).  The table
+    records the workload / batch / dtype / commit it was measured at; it is attached only on an exact match of the
+    first three (None otherwise): PMC counters cannot be collected from inside the timed process."""
     if not roofline:
         return roofline
     try:
         table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        meta = table.get('_meta', {})
         e = table.get(roofline['kernel'])
-        if e:
+        if e and (meta.get('workload'), meta.get('batch'), meta.get('dtype')) == (workload, batch, dtype):
             roofline['traffic'] = e['bytes_per_launch']
-            roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)'
+            roofline['traffic_source'] = ('profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE; '
+                                          f'measured at commit {meta.get("commit", "?")})')
     except Exception:
         pass
     return roofline
+
+
+def finish(world):
+    """Every rank leaves together: a rank that tore the group down while another still had a collective queued
+    would strand it."""
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def profile_alone(tr, fn, peak):
+    """The per-launch HIP-event pass runs on rank 0 only, so it must not contain a collective: the trainer is
+    switched to a single-rank view for its duration (the kernels are the same; only the all-reduce is skipped)."""
+    from mcgen_amd import ops
+    world, group = tr.world, tr.group
+    tr.world, tr.group = 1, None
+    try:
+        return ops.profile_step(fn, peak)
+    finally:
+        tr.world, tr.group = world, group
 
 
 def log(msg):
@@ -138,16 +171,18 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
     np.random.seed(0)
     torch.manual_seed(0)
     model = models.mcglow().to(dev).set_compute_dtype(dtype)
-    if world > 1:
-        import torch.distributed as dist
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     img = torch.rand(a.batch, chans, 32, 32, device=dev, generator=g) * 2 - 1
     lab = torch.randint(0, classes, (a.batch,), device=dev, generator=g)
     with torch.no_grad():
         model.train(True)
         model({'img': img, 'label': lab})                 # data-dependent ActNorm init (train_glow.py:60-67)
+    if world > 1:
+        # AFTER the data-dependent init (each rank ran it on its own shard): every replica starts from rank 0's
+        # parameters and ActNorm loc / scale, as train_glow.py initialises before wrapping in DataParallel (:60-67,82-83)
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
     tr = GlowTrainer(model, dist_group=group, world_size=world)
     graphed = False
     if not a.no_graph:
@@ -178,7 +213,7 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
     value = a.batch * world * a.steps / dt
     roofline = None
     if not a.no_roofline and rank == 0:
-        roofline = ops.profile_step(lambda: tr.train_iteration(img, lab, torch.rand_like(img)), PEAK_TFLOPS[a.dtype])
+        roofline = profile_alone(tr, lambda: tr._eager(img, lab, torch.rand_like(img)), PEAK_TFLOPS[a.dtype])
     if rank == 0:
         print(json.dumps({
             'metric': f'images/sec (train step) MCGlow {data_name} 32x32', 'value': value, 'unit': 'images/s', 'n_gpus': world,
@@ -188,9 +223,7 @@ def bench_mcglow(a, dev, dtype, world, rank, group):
                                    'forward + backward + clip_grad_norm_(1) + Adam (train_glow.py:108-121)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': graphed},
             'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    finish(world)
 
 
 def bench_mcvae(a, dev, dtype, world, rank, group):
@@ -243,7 +276,7 @@ def bench_mcvae(a, dev, dtype, world, rank, group):
     roofline = None
     if not a.no_roofline and rank == 0:
         eps = torch.randn(a.batch, model.latent_size, device=dev)
-        roofline = ops.profile_step(lambda: tr._eager(img, lab, eps), PEAK_TFLOPS[a.dtype])
+        roofline = profile_alone(tr, lambda: tr._eager(img, lab, eps), PEAK_TFLOPS[a.dtype])
     if rank == 0:
         print(json.dumps({
             'metric': 'images/sec (train step) MCVAE CIFAR-10 32x32', 'value': value, 'unit': 'images/s',
@@ -253,9 +286,7 @@ def bench_mcvae(a, dev, dtype, world, rank, group):
                                    'forward + backward + clip_grad_norm_(1) + Adam (train_vae.py:98-126)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': graphed},
             'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    finish(world)
 
 
 def bench_mcpixelcnn(a, dev, dtype, world, rank, group):
@@ -307,7 +338,7 @@ def bench_mcpixelcnn(a, dev, dtype, world, rank, group):
     value = a.batch * world * a.steps / dt
     roofline = None
     if not a.no_roofline and rank == 0:
-        roofline = ops.profile_step(lambda: tr._eager(codes, lab), PEAK_TFLOPS[a.dtype])
+        roofline = profile_alone(tr, lambda: tr._eager(codes, lab), PEAK_TFLOPS[a.dtype])
     if rank == 0:
         print(json.dumps({
             'metric': 'images/sec (train step) MCPixelCNN CIFAR-10 8x8 code maps', 'value': value, 'unit': 'images/s',
@@ -317,9 +348,7 @@ def bench_mcpixelcnn(a, dev, dtype, world, rank, group):
                                    f'batch {a.batch}/GPU, forward + backward + clip_grad_norm_(1) + Adam (train_pixelcnn.py:108-121)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}', 'graph_replay': graphed},
             'last_loss': float(loss), 'roofline': roofline, 'cpu_baseline': None}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    finish(world)
 
 
 def main():
@@ -334,6 +363,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--sustain-steps', type=int, default=100,
+                    help='extra untimed-for-the-headline steps after the timed region, reported as sustained_ms_per_step')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -410,10 +441,20 @@ def main():
     value = a.batch * world * a.steps / dt
     log(f'timed region done: {value:.1f} images/s')
     losses = (float(dl), float(gl))
+    # self-check that the short timed region ran at sustained clocks: the same step for >= 1 s more (extra key only)
+    sustained = None
+    if a.sustain_steps > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.sustain_steps):
+            tr.train_iteration(img, lab)
+        barrier()
+        sustained = 1e3 * (time.perf_counter() - t1) / a.sustain_steps
+        log(f'sustained check: {sustained:.3f} ms/step over {a.sustain_steps} steps')
 
     roofline = None
     if not a.no_roofline and rank == 0:
-        roofline = ops.profile_step(lambda: tr.eager_iteration(img, lab), PEAK_TFLOPS[a.dtype])
+        roofline = profile_alone(tr, lambda: tr.eager_iteration(img, lab), PEAK_TFLOPS[a.dtype])
     log('roofline pass done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == 'cifar10':
@@ -429,17 +470,15 @@ def main():
                                          'D [64,128,256,512], 100 modes, ')
                        + f'batch {a.batch}/GPU, 5 D + 1 G updates per step (train_gan.py:139-176)',
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}',
-                       'graph_replay': graphed},
+                       'graph_replay': graphed, 'workload_key': a.workload, 'batch_per_gpu': a.batch},
             'd_steps_per_s': 5 * a.steps * world / dt / world, 'g_steps_per_s': a.steps / dt,     # per replica
             'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
-            'last_losses': losses,
-            'roofline': attach_traffic(roofline), 'cpu_baseline': cpu,
+            'last_losses': losses, 'sustained_ms_per_step': sustained, 'sustain_steps': a.sustain_steps,
+            'roofline': attach_traffic(roofline, a.workload, a.batch, a.dtype), 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    finish(world)
 
 
 if __name__ == '__main__':

@@ -38,10 +38,20 @@ def process_control():
         raise ValueError('Not valid dataset')
     cfg['data_shape'], cfg['generate_per_mode'] = list(shapes[name][0]), shapes[name][1]
     if name in _CLASSES:
-        cfg.setdefault('classes_size', _CLASSES[name])      # the reference takes it from the dataset object
+        # the reference takes it from the dataset object (utils.py:99-101, process_dataset).  Derived here on every call:
+        # a value this function derived for ANOTHER data_name is replaced, a value the caller set by hand is kept.
+        derived = cfg.get('_classes_size_derived')
+        stale = derived is not None and derived[0] != name and cfg.get('classes_size') == derived[1]
+        if 'classes_size' not in cfg or stale:
+            cfg['classes_size'] = _CLASSES[name]
+            cfg['_classes_size_derived'] = (name, _CLASSES[name])
     side = cfg['data_shape'][1]
     if side not in (32, 128):
         raise ValueError('Not valid data shape')
+    if cfg.get('ae_name') in ('vqvae',):                     # utils.py:127-137
+        cfg['vqvae'] = {'hidden_size': [128, 128] if side == 32 else [128, 128, 128, 128], 'num_res_block': 2,
+                        'embedding_size': 64, 'num_embedding': 512, 'vq_commit': 0.25}
+    cfg['classifier'] = {'hidden_size': [8, 16, 32, 64]}      # utils.py:183
     model = cfg['model_name']
     if model in ('cgan', 'mcgan'):
         gan = {'latent_size': 128, 'embedding_size': 32}

@@ -50,18 +50,27 @@ def _f32(t: Optional[Tensor]) -> Optional[int]:
 
 # ---- per-launch profiling (bench.py roofline): HIP events on the launch stream -------------------------
 _PROF = None
+TILE_LOG = None        # tests set this to a list: every conv_fused launch appends the (BM, BN) tile the policy picked
 
 
-def _timed(name_fn, flops: float, launch):
-    """Run `launch()`; when profiling is on, bracket it with events on the current stream."""
+def _timed(name_fn, flops: float, launch, nbytes_fn=None):
+    """Run `launch()`; when profiling is on, bracket it with events on the current stream.  `nbytes_fn()` = the
+    launch's algorithmic HBM bytes (operands read once + results written once)."""
     if _PROF is None:
         return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = launch()
     e.record()
-    _PROF.append((name_fn(), flops, s, e))
+    _PROF.append((name_fn(), flops, s, e, float(nbytes_fn()) if nbytes_fn is not None else 0.0))
     return r
+
+
+HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def _nbytes(*ts) -> int:
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def profile_step(fn, peak_tflops: float):
@@ -88,21 +97,31 @@ def profile_step(fn, peak_tflops: float):
     torch.cuda.synchronize()
     over_ms = sorted(s.elapsed_time(e) for s, e in pairs)[len(pairs) // 2]
     agg = {}
-    for name, flops, s, e in rec:
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for name, flops, s, e, nbytes in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
         raw = s.elapsed_time(e)
-        a[0] += 1; a[1] += max(raw - over_ms, 0.1 * raw) * 1e-3; a[2] += flops; a[3] += raw * 1e-3
+        a[0] += 1; a[1] += max(raw - over_ms, 0.1 * raw) * 1e-3; a[2] += flops; a[3] += raw * 1e-3; a[4] += nbytes
     if not agg:
         return None
     top = max(agg, key=lambda k: agg[k][1])
-    cnt, secs, flops, raw_secs = agg[top]
+    cnt, secs, flops, raw_secs, nbytes = agg[top]
     ach = flops / secs / 1e12
-    return {'bound': 'mfma', 'kernel': top, 'achieved': ach, 'peak': peak_tflops, 'unit': 'TFLOP/s',
-            'frac': ach / peak_tflops, 'traffic': None, 'launches_per_step': cnt,
-            'avg_launch_us': secs / cnt * 1e6, 'avg_launch_us_uncorrected': raw_secs / cnt * 1e6,
-            'event_pair_overhead_us': over_ms * 1e3, 'flops_per_launch': flops / cnt,
-            'by_kernel': {k: {'launches': v[0], 'total_ms': v[1] * 1e3, 'tflops': v[2] / v[1] / 1e12}
-                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    # which roof bounds the kernel: its algorithmic intensity against the machine balance (MFMA peak / HBM peak)
+    intensity = flops / nbytes if nbytes > 0 else float('inf')
+    balance = peak_tflops * 1e12 / HBM_PEAK_BYTES_PER_S
+    out = {'bound': 'mfma' if intensity >= balance else 'hbm', 'kernel': top, 'achieved': ach, 'peak': peak_tflops,
+           'unit': 'TFLOP/s', 'frac': ach / peak_tflops, 'traffic': None, 'launches_per_step': cnt,
+           'avg_launch_us': secs / cnt * 1e6, 'avg_launch_us_uncorrected': raw_secs / cnt * 1e6,
+           'event_pair_overhead_us': over_ms * 1e3, 'flops_per_launch': flops / cnt,
+           'algorithmic_bytes_per_launch': nbytes / cnt, 'intensity_flop_per_byte': intensity,
+           'machine_balance_flop_per_byte': balance,
+           'by_kernel': {k: {'launches': v[0], 'total_ms': v[1] * 1e3, 'tflops': v[2] / v[1] / 1e12,
+                             'gbytes_per_s': v[4] / v[1] / 1e9}
+                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    if out['bound'] == 'hbm':                      # an HBM-bound dominant kernel is priced in bytes
+        out.update(achieved=nbytes / secs / 1e9, peak=HBM_PEAK_BYTES_PER_S / 1e9, unit='GB/s',
+                   frac=nbytes / secs / HBM_PEAK_BYTES_PER_S)
+    return out
 
 
 def pad8(c: int) -> int:
@@ -248,7 +267,12 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')
         return base
-    _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'))
+    if TILE_LOG is not None:
+        bm, bn = C.c_int(), C.c_int()
+        check(lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn)), 'conv_tile')
+        TILE_LOG.append((bm.value, bn.value))
+    _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'),
+           lambda: _nbytes(wimg, y, res, gate_x, *[s.x for s in segs]))
     return y, stats
 
 
@@ -312,7 +336,8 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>' + (
             f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _os.environ.get('MCGEN_PROF_SHAPES') else ''),
                2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
-               lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'))
+               lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'),
+               lambda: _nbytes(seg.x, dy, slabs))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     if second is None:

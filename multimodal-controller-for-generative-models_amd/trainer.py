@@ -150,13 +150,34 @@ class GANTrainer:
 
 class GraphedGANTrainer(GANTrainer):
     """Same step, captured once into HIP graphs and replayed: the step is a few hundred short
-    launches, so replay removes the host launch cost.  Four graphs -- D compute, D apply, G compute,
-    G apply -- so that the gradient all-reduce of a multi-rank run sits BETWEEN replays, on the same
-    stream, and no collective is ever captured."""
+    launches, so replay removes the host launch cost.  Five graphs -- latent refresh, D compute, D apply,
+    G compute, G apply -- so that the gradient all-reduce of a multi-rank run sits BETWEEN replays, on the
+    same stream, and no collective is ever captured; the latent refresh is its own graph so that a parity run
+    can inject latents (`zs`) into the very replays the benchmark times.
+
+    `capture` leaves the model, the optimizer state and every buffer exactly as it found them: its warm-up
+    updates run on a snapshot that is restored before the capture (a capture records launches, it does not
+    execute them)."""
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._graphs = None
+
+    # ---- state snapshot around the warm-up --------------------------------------------------------
+    def _snapshot(self):
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        opt = [(o.m.clone(), o.v.clone(), o.step_count.clone()) for o in (self.opt_g, self.opt_d)]
+        return sd, opt
+
+    def _restore(self, snap):
+        sd, opt = snap
+        with torch.no_grad():
+            self.model.load_state_dict(sd)
+            for o, (m, v, st) in zip((self.opt_g, self.opt_d), opt):
+                o.m.copy_(m); o.v.copy_(v); o.step_count.copy_(st)
+        self.geng.flat_p.ensure()
+        self.deng._ensure_flat()
+        self.geng.refresh_images(force=True)
 
     def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 1):
         n = img.shape[0]
@@ -166,6 +187,7 @@ class GraphedGANTrainer(GANTrainer):
         self.s_ind = self.s_ind2[:n]
         self.s_z = torch.randn(n, self.latent, device=dev)
         self.model.train(True)
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -174,16 +196,19 @@ class GraphedGANTrainer(GANTrainer):
                 self.g_update(self.s_ind, self.s_z)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._restore(snap)
+        torch.cuda.synchronize()
+        self.g_z = torch.cuda.CUDAGraph()
         self.g_dc, self.g_da = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.g_gc, self.g_ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_dc, capture_error_mode=_CAPTURE_MODE):
-            self.s_z.normal_()
             self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z, self.s_ind2)
         pool = self.g_dc.pool()
+        with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            self.s_z.normal_()
         with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.d_apply()
         with torch.cuda.graph(self.g_gc, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self.s_z.normal_()
             self.loss_g = self.g_compute(self.s_ind, self.s_z)
         with torch.cuda.graph(self.g_ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.g_apply()
@@ -193,17 +218,27 @@ class GraphedGANTrainer(GANTrainer):
         return GANTrainer.train_iteration(self, img, label)
 
     def train_iteration(self, img, label, zs=None):
-        if self._graphs is None or zs is not None:
+        """Replays the captured step; `zs` (d_iters + g_iters latent batches) replaces the in-graph latent draws."""
+        if self._graphs is None:
             return super().train_iteration(img, label, zs)
         self.s_img.copy_(img, non_blocking=True)
         oh = F.one_hot(label, self.classes).float()
         n = oh.shape[0]
         self.s_ind2[:n].copy_(oh, non_blocking=True); self.s_ind2[n:].copy_(oh, non_blocking=True)
+        zi = iter(zs) if zs is not None else None
+
+        def latent():
+            if zi is None:
+                self.g_z.replay()
+            else:
+                self.s_z.copy_(next(zi), non_blocking=True)
         for _ in range(self.d_iters):
+            latent()
             self.g_dc.replay()
             self._allreduce(self.grad_d)
             self.g_da.replay()
         for _ in range(self.g_iters):
+            latent()
             self.g_gc.replay()
             self._allreduce(self.grad_g)
             self.g_ga.replay()
@@ -250,9 +285,14 @@ class _FlatTrainer:
             allreduce_mean_(self.gflat, self.world, self.group)
 
     def _capture(self, statics, warmup: int):
+        """`statics`: the step's inputs followed by its per-step random tensor (if the subclass has one, `_refresh`
+        redraws it).  The warm-up steps run on a snapshot of model + optimizer state that is restored before the
+        capture, so capturing does not advance training."""
         self.model.train(True)
         self._bind_grads()
         self.statics = statics
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        opt = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -262,18 +302,33 @@ class _FlatTrainer:
                 self._apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_c, self.g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            self.model.load_state_dict(sd)
+            self.opt.m.copy_(opt[0]); self.opt.v.copy_(opt[1]); self.opt.step_count.copy_(opt[2])
+        self.fs.ensure()
+        self._bind_grads()
+        torch.cuda.synchronize()
+        self.g_r, self.g_c, self.g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.no_grad():
             with torch.cuda.graph(self.g_c, capture_error_mode=_CAPTURE_MODE):
-                self._refresh()
                 self.loss = self._compute(*statics)
+            self._has_refresh = type(self)._refresh is not _FlatTrainer._refresh
+            if self._has_refresh:
+                with torch.cuda.graph(self.g_r, pool=self.g_c.pool(), capture_error_mode=_CAPTURE_MODE):
+                    self._refresh()
             with torch.cuda.graph(self.g_a, pool=self.g_c.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._apply()
         self._graphs = True
 
-    def _replay(self, *inputs):
+    def _replay(self, *inputs, rand=None):
+        """`inputs` fill the leading statics; `rand` (optional) replaces the in-graph redraw of the last one."""
         for s, v in zip(self.statics, inputs):
             s.copy_(v, non_blocking=True)
+        if self._has_refresh:
+            if rand is not None:
+                self.statics[-1].copy_(rand, non_blocking=True)
+            else:
+                self.g_r.replay()
         self.g_c.replay()
         self._allreduce()
         self.g_a.replay()
@@ -313,8 +368,8 @@ class GlowTrainer(_FlatTrainer):
         self._capture((img.clone(), label.clone(), torch.rand_like(img)), warmup)
 
     def train_iteration(self, img, label, noise=None):
-        if self._graphs and noise is None:
-            return self._replay(img, label)
+        if self._graphs:
+            return self._replay(img, label, rand=noise)
         return self._eager(img, label, torch.rand_like(img) if noise is None else noise)
 
 
@@ -358,8 +413,8 @@ class VAETrainer(_FlatTrainer):
         self._capture((img.clone(), label.clone(), eps), warmup)
 
     def train_iteration(self, img, label, eps=None):
-        if self._graphs and eps is None:
-            return self._replay(img, label)
+        if self._graphs:
+            return self._replay(img, label, rand=eps)
         if eps is None:
             eps = torch.randn(img.shape[0], self.model.latent_size, device=img.device)
         return self._eager(img, label, eps)

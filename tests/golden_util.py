@@ -113,6 +113,55 @@ def procedural_state_generic(shapes: Dict[str, tuple], seed: int) -> Dict[str, t
     return sd
 
 
+
+def procedural_state_glow(shapes: Dict[str, tuple], dtypes: Dict[str, str], seed: int) -> Dict[str, torch.Tensor]:
+    """Stand-in weights for a reference-format MCGlow state dict (models/mcglow.py:24-130), from key -> shape /
+    dtype tables alone: coupling convolutions ~ N(0, 0.05) (mcglow.py:148-151), ZeroConv2d weights / scales small
+    but non-zero (so every path carries signal), LU factors of the invertible 1x1 convolutions built structurally
+    (w_p a permutation matrix, strictly triangular w_l / w_u, masks and identity as the reference registers them),
+    ActNorm at (loc 0, scale 1, initialized 0) so that the first training forward runs the data-dependent init,
+    codebooks Bernoulli(0.5)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, torch.Tensor] = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        leaf = k.rsplit('.', 1)[-1]
+        zero_conv = k.endswith(('8.module.scale', 'prior.scale')) or '.module.conv.' in k or '.prior.conv.' in k
+        if leaf == 'codebook':
+            v = (rng.random(shp) < 0.5).astype(np.float32)
+        elif leaf == 'initialized':
+            v = np.zeros(shp, dtype=np.uint8)
+        elif leaf == 'w_p':
+            v = np.eye(shp[0], dtype=np.float32)[rng.permutation(shp[0])]
+        elif leaf in ('w_l', 'w_u'):
+            m = np.tril(np.ones(shp, dtype=np.float32), -1) if leaf == 'w_l' else np.triu(np.ones(shp, dtype=np.float32), 1)
+            v = (0.2 * rng.standard_normal(shp)).astype(np.float32) * m
+        elif leaf == 'w_s':
+            v = (0.1 * rng.standard_normal(shp)).astype(np.float32)
+        elif leaf == 's_sign':
+            v = np.where(rng.random(shp) < 0.5, -1.0, 1.0).astype(np.float32)
+        elif leaf == 'u_mask':
+            v = np.triu(np.ones(shp, dtype=np.float32), 1)
+        elif leaf == 'l_mask':
+            v = np.tril(np.ones(shp, dtype=np.float32), -1)
+        elif leaf == 'l_eye':
+            v = np.eye(shp[0], dtype=np.float32)
+        elif leaf == 'loc':
+            v = np.zeros(shp, dtype=np.float32)
+        elif leaf == 'scale':
+            v = (0.05 * rng.standard_normal(shp)).astype(np.float32) if zero_conv else np.ones(shp, dtype=np.float32)
+        elif leaf == 'bias':
+            v = rng.uniform(-0.02, 0.02, shp).astype(np.float32)
+        elif leaf == 'weight':
+            v = ((0.01 if zero_conv else 0.05) * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            raise KeyError(f'procedural_state_glow: unexpected key {k}')
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        want = getattr(torch, dtypes[k])
+        sd[k] = t if t.dtype == want else t.to(want)
+    return sd
+
+
 def _codebook_owner(key: str) -> str:
     """Map an aliased codebook key to its owning module's key (mc_1 / mc_2)."""
     parts = key.split('.')

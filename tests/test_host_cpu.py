@@ -190,3 +190,27 @@ def test_other_model_trees_load_reference_state_dicts(fixture, model_name, extra
             m({'img': torch.zeros(2, 3, 32, 32), 'label': torch.zeros(2, dtype=torch.int64)})
         else:
             m.train(False).encode(torch.zeros(2, 3, 32, 32))
+
+
+def test_process_control_fills_vqvae_and_rederives_classes():
+    """utils.py:127-137,183: `ae_name == 'vqvae'` (the default) fills cfg['vqvae'], cfg['classifier'] is always set;
+    classes_size follows data_name across calls unless the caller pinned another value by hand."""
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg, process_control
+    cfg.update(data_name='CIFAR10', model_name='mcpixelcnn', ae_name='vqvae', device='cpu')
+    cfg.pop('classes_size', None); cfg.pop('vqvae', None)
+    process_control()
+    assert cfg['vqvae'] == {'hidden_size': [128, 128], 'num_res_block': 2, 'embedding_size': 64, 'num_embedding': 512,
+                            'vq_commit': 0.25}
+    assert cfg['classifier'] == {'hidden_size': [8, 16, 32, 64]} and cfg['classes_size'] == 10
+    ae = models.vqvae()                                   # the shipped config builds the frozen auto-encoder
+    assert sum(p.numel() for p in ae.parameters()) == 1868355          # SURVEY 8(c): VQ-VAE parameter count
+    assert ae.quantizer.embedding.shape == (64, 512)
+    cfg['data_name'] = 'Omniglot'
+    process_control()
+    assert cfg['classes_size'] == 1623                    # derived value follows the dataset
+    cfg['classes_size'] = 12                              # pinned by hand: kept
+    cfg['data_name'] = 'COIL100'
+    process_control()
+    assert cfg['classes_size'] == 12
+    _cfg_for('CIFAR10')

@@ -442,3 +442,225 @@ def test_dtail_hinge_tanh_adam():
         ops.adam(pg, gr.cuda(), m, v, step, 2e-4, (0.5, 0.999))
     assert int(step) == 3
     np.testing.assert_allclose(pg.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# The tile / pipeline instantiations the headline bench dispatches (conv_fused.hip pick_tile): every case runs
+# at a size that crosses the policy's thresholds, asserts which tile was picked and compares with F.conv2d on the
+# CPU.  bf16 reference: operands rounded to bf16, fp32 math.
+def _conv_logged(ops, *a, **k):
+    ops.TILE_LOG = []
+    try:
+        out = ops.conv_fused(*a, **k)
+        tiles = list(ops.TILE_LOG)
+    finally:
+        ops.TILE_LOG = None
+    return out, tiles
+
+
+BIG_A = [
+    # N, H(out), C, tile expected in bf16, tile expected in fp32
+    (128, 32, 256, (256, 256), (128, 128)),
+    (64, 32, 256, (256, 256), (128, 128)),
+    (128, 16, 256, (128, 256), (128, 128)),
+    (128, 16, 128, (64, 128), (128, 128)),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', BIG_A)
+def test_big_conv_a_upsample_bn_code_stats(case, dtype):
+    """G.conv_a at the bench's sizes: BN -> ReLU -> x2 upsample -> MC code -> conv3x3 + bias, next-BN sums."""
+    ops = _ops()
+    n, h, c, t16, t32 = case
+    if dtype == torch.float32 and n * h * h > 65536:
+        pytest.skip('fp32 parity instantiation covered at N=64 (same tile, half the CPU reference time)')
+    g = torch.Generator().manual_seed(101 + n + h + c)
+    hs = h // 2
+    x = _rnd(g, n, c, hs, hs)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    wt, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
+    a = ref_prologue(_q(x, dtype), scale, shift, True, code, True)
+    ref = F.conv2d(_q(a, dtype) if dtype != torch.float32 else a, _q(wt, dtype), b, padding=1)
+    seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=True, relu=True)
+    (y, st), tiles = _conv_logged(ops, [seg], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda(), stats_mode=1)
+    assert tiles == [t16 if dtype == torch.bfloat16 else t32], tiles
+    yq = ops.to_nchw(y, c).cpu()
+    _assert_close(yq, ref, dtype, 'big conv_a')
+    s = st.double().sum(0).cpu()
+    tol = dict(rtol=1e-3, atol=1e-3 * float(ref.abs().sum((0, 2, 3)).max())) if dtype == torch.float32 else \
+        dict(rtol=2e-2, atol=4e-3 * float(ref.abs().sum((0, 2, 3)).max()))
+    np.testing.assert_allclose(s[0, :c], ref.double().sum((0, 2, 3)), **tol)
+    np.testing.assert_allclose(s[1, :c], (ref.double() ** 2).sum((0, 2, 3)), rtol=tol['rtol'] * 2,
+                               atol=tol['atol'] * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n,h,c,t16', [(128, 32, 256, (256, 256)), (128, 16, 256, (128, 256))])
+def test_big_conv_b_with_shortcut_segment(n, h, c, t16, dtype):
+    """G.conv_b at the bench's sizes: conv3x3(BN/ReLU/MC2(h)) + conv1x1(MC1(Up(x))) as one K-concatenated launch."""
+    ops = _ops()
+    if dtype == torch.float32:
+        n //= 2
+    g = torch.Generator().manual_seed(211 + h)
+    hs = h // 2
+    h_in, x = _rnd(g, n, c, h, h), _rnd(g, n, c, hs, hs)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code1 = (torch.rand(n, c, generator=g) < 0.5).float()
+    code2 = (torch.rand(n, c, generator=g) < 0.5).float()
+    w2, ws, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c, c, 1, 1) * 0.08, _rnd(g, c)
+    a2 = ref_prologue(_q(h_in, dtype), scale, shift, True, code2, False)
+    a1 = ref_prologue(_q(x, dtype), None, None, False, code1, True)
+    if dtype != torch.float32:
+        a2, a1 = _q(a2, dtype), _q(a1, dtype)
+    ref = F.conv2d(a2, _q(w2, dtype), b, padding=1) + F.conv2d(a1, _q(ws, dtype))
+    img = torch.cat([ops.prep_weight(w2.cuda(), dtype), ops.prep_weight(ws.cuda(), dtype)])
+    segs = [ops.Seg(_nhwc(ops, h_in, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code2.cuda(), relu=True),
+            ops.Seg(_nhwc(ops, x, dtype), ksize=1, code=code1.cuda(), ups=True)]
+    (y, _), tiles = _conv_logged(ops, segs, img, c, bias=b.cuda())
+    assert tiles == [t16 if dtype == torch.bfloat16 else ((128, 128) if n * h * h > 16384 else (64, 64))], tiles
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'big conv_b + shortcut')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('pool', [False, True])
+def test_big_dgrad_gate_bnstats(dtype, pool):
+    """Input-gradient launches of G's 32x32 layers at the bench's batch: transposed weights, MC code on the output
+    channels, ReLU-after-BN gate, the two BatchNorm-backward sums; pool=True is conv_a's form (x2-upsample adjoint)."""
+    ops = _ops()
+    n, h, c = (128 if dtype == torch.bfloat16 else 64), 32, 256
+    g = torch.Generator().manual_seed(307 + pool)
+    ho = h // 2 if pool else h
+    dy = _rnd(g, n, c, h, h)
+    wt = _rnd(g, c, c, 3, 3) * 0.03
+    xin = _rnd(g, n, c, ho, ho)
+    mean, rstd = _rnd(g, c) * 0.2, torch.rand(c, generator=g) + 0.5
+    gamma, beta = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    gscale, gshift = gamma * rstd, beta - mean * gamma * rstd
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    dm = F.conv_transpose2d(_q(dy, dtype), _q(wt, dtype), padding=1) * code.view(n, c, 1, 1)
+    da = F.avg_pool2d(dm, 2) * 4 if pool else dm
+    xq = _q(xin, dtype)
+    dz = da * ((xq * gscale.view(1, -1, 1, 1) + gshift.view(1, -1, 1, 1)) > 0)
+    xhat = (xq - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    (y, st), tiles = _conv_logged(ops, [ops.Seg(_nhwc(ops, dy, dtype))], ops.prep_weight(wt.cuda(), dtype, transpose=True), c,
+                                  pool=pool, alpha=1.0, ocode=code.cuda(), gate_x=_nhwc(ops, xin, dtype), gscale=gscale.cuda(),
+                                  gshift=gshift.cuda(), gmean=mean.cuda(), grstd=rstd.cuda(), stats_mode=2)
+    assert tiles == [(256, 256) if dtype == torch.bfloat16 else (128, 128)], tiles
+    _assert_close(ops.to_nchw(y, c), dz, dtype, 'big dz')
+    s = st.double().sum(0).cpu()
+    mag = float(dz.abs().sum((0, 2, 3)).max())
+    tol = dict(rtol=1e-3, atol=2e-4 * mag) if dtype == torch.float32 else dict(rtol=3e-2, atol=4e-3 * mag)
+    np.testing.assert_allclose(s[0, :c], dz.double().sum((0, 2, 3)), **tol)
+    np.testing.assert_allclose(s[1, :c], (dz * xhat).double().sum((0, 2, 3)), rtol=tol['rtol'], atol=tol['atol'] * 3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n,h,t16', [(128, 32, (128, 128)), (256, 32, (128, 128)), (256, 16, (128, 128)), (128, 16, (64, 128))])
+def test_big_conv_pool_residual(n, h, t16, dtype):
+    """D's 128-channel layers at the bench's batch (128 images, 256 for the paired real + fake pass):
+    ReLU -> MC -> conv3x3 -> AvgPool2 + residual."""
+    ops = _ops()
+    if dtype == torch.float32 and n > 128:
+        pytest.skip('fp32: same tile as the N=128 case')
+    g = torch.Generator().manual_seed(401 + n + h)
+    c = 128
+    x, res = _rnd(g, n, c, h, h), _rnd(g, n, c, h // 2, h // 2)
+    code = (torch.rand(n, c, generator=g) < 0.5).float() * (1.0 + 0.25 * (torch.arange(n) >= n // 2).float().view(n, 1))
+    wt, b = _rnd(g, c, c, 3, 3) * 0.04, _rnd(g, c)
+    a = ref_prologue(_q(x, dtype), None, None, True, code, False)
+    if dtype != torch.float32:
+        a = _q(a, dtype)
+    ref = F.avg_pool2d(F.conv2d(a, _q(wt, dtype), None, padding=1), 2) + b.view(1, -1, 1, 1) + _q(res, dtype)
+    (y, _), tiles = _conv_logged(ops, [ops.Seg(_nhwc(ops, x, dtype), code=code.cuda(), relu=True)], ops.prep_weight(wt.cuda(), dtype),
+                                 c, bias=b.cuda(), pool=True, alpha=0.25, res=_nhwc(ops, res, dtype))
+    want = t16 if dtype == torch.bfloat16 else ((128, 128) if n * h * h > 16384 else (64, 64))
+    assert tiles == [want], tiles
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'big pool+res')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_deep_1x1_grouped_form(dtype):
+    """K-deep pure 1x1 launches (MCGlow's 512 -> 512 coupling convolution, MCPixelCNN's head): in bf16 the 'dma3g'
+    form (three chunks per barrier round, conv_fused.hip) -- C = 512 >= 384."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(503)
+    n, h, c = 16, 16, 512
+    x = _rnd(g, n, c, h, h)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    wt, b = _rnd(g, c, c, 1, 1) * 0.05, _rnd(g, c)
+    a = ref_prologue(_q(x, dtype), scale, shift, True, code, False)
+    if dtype != torch.float32:
+        a = _q(a, dtype)
+    ref = F.conv2d(a, _q(wt, dtype), b)
+    seg = ops.Seg(_nhwc(ops, x, dtype), ksize=1, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), relu=True)
+    (y, _), tiles = _conv_logged(ops, [seg], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda())
+    assert tiles == [(64, 64)], tiles
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'deep 1x1')
+    # a ragged chunk count (13 chunks: four full groups of three + one single)
+    c2 = 416
+    x2, w2 = _rnd(g, n, c2, h, h), _rnd(g, 96, c2, 1, 1) * 0.05
+    ref2 = F.conv2d(_q(x2, dtype), _q(w2, dtype))
+    y2, _ = ops.conv_fused([ops.Seg(_nhwc(ops, x2, dtype), ksize=1)], ops.prep_weight(w2.cuda(), dtype), 96)
+    _assert_close(ops.to_nchw(y2, 96), ref2, dtype, 'deep 1x1 ragged')
+
+
+BIG_WG = [
+    # N, H, Cin, Cout, ksize, ups(x), dy_ups: the weight-gradient launches of the bench (default split policy)
+    (128, 32, 256, 256, 3, False, False),     # G block 2 conv_b
+    (128, 32, 256, 256, 3, True, False),      # G block 2 conv_a (x through the upsample)
+    (128, 32, 256, 256, 1, True, False),      # G block 2 shortcut
+    (128, 32, 128, 128, 3, False, True),      # D block 0 conv2 (pooled gradient)
+    (128, 16, 128, 128, 3, False, False),     # D block 1 conv1
+    (128, 8, 128, 128, 3, False, False),      # D blocks 2, 3 (8x8 maps: producer/consumer form)
+    (128, 32, 256, 3, 3, False, False),       # G head
+]
+
+
+@pytest.mark.parametrize('case', BIG_WG)
+def test_big_wgrad_bf16(case):
+    ops = _ops()
+    dtype = torch.bfloat16
+    n, h, ci, co, ks, ups, dy_ups = case
+    g = torch.Generator().manual_seed(601 + h + ci + co + ks)
+    hs = h // 2 if ups else h
+    x = _rnd(g, n, ci, hs, hs)
+    scale, shift = _rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3
+    code = (torch.rand(n, ci, generator=g) < 0.5).float()
+    hd = h // 2 if dy_ups else h
+    dy = _rnd(g, n, co, hd, hd) * 0.1
+    a = _q(ref_prologue(_q(x, dtype), scale, shift, True, code, ups), dtype)
+    dyf = _q(dy, dtype)
+    if dy_ups:
+        dyf = dyf.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = torch.nn.grad.conv2d_weight(a, (co, ci, ks, ks), dyf, padding=ks // 2)
+    grad = torch.zeros((co, ci, ks, ks), device='cuda')
+    seg = ops.Seg(_nhwc(ops, x, dtype), ksize=ks, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), ups=ups, relu=True)
+    bg = torch.zeros((co,), device='cuda')
+    ops.wgrad(seg, _nhwc(ops, dy, dtype), co, ci, grad, dy_ups=dy_ups, bias_grad=bg)
+    _assert_close(grad, ref, dtype, 'big wgrad')
+    _assert_close(bg, dyf.sum((0, 2, 3)), dtype, 'big wgrad bias')
+
+
+def test_big_wgrad_two_halves_bf16():
+    """The paired discriminator pass: one launch over 2N images, one slab set (and one gradient) per half."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    n, h, c = 256, 16, 128
+    g = torch.Generator().manual_seed(701)
+    x = _rnd(g, n, c, h, h)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    dy = _rnd(g, n, c, h, h) * 0.1
+    a = _q(ref_prologue(_q(x, dtype), None, None, True, code, False), dtype)
+    dyf = _q(dy, dtype)
+    refs = [torch.nn.grad.conv2d_weight(a[s], (c, c, 3, 3), dyf[s], padding=1) for s in (slice(0, n // 2), slice(n // 2, n))]
+    g1, g2 = torch.zeros((c, c, 3, 3), device='cuda'), torch.zeros((c, c, 3, 3), device='cuda')
+    b1, b2 = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    seg = ops.Seg(_nhwc(ops, x, dtype), code=code.cuda(), relu=True)
+    ops.wgrad(seg, _nhwc(ops, dy, dtype), c, c, g1, bias_grad=b1, second=(g2, b2, None))
+    _assert_close(g1, refs[0], dtype, 'first half')
+    _assert_close(g2, refs[1], dtype, 'second half')
+    _assert_close(b1, dyf[:n // 2].sum((0, 2, 3)), dtype, 'first half bias')
+    _assert_close(b2, dyf[n // 2:].sum((0, 2, 3)), dtype, 'second half bias')

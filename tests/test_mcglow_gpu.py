@@ -243,3 +243,65 @@ def test_mcglow_bf16_tracks_fp32():
     tr = GlowTrainer(m)
     losses = [float(tr.train_iteration(img, lab, torch.from_numpy(d[f'noise/{s}/0']).cuda())) for s in range(2)]
     assert abs(losses[0] - d['losses'][0]) < 2e-2 and abs(losses[1] - d['losses'][1]) < 3e-2, (losses, d['losses'])
+
+
+def _model_omniglot(sd, dtype=torch.float32):
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    cfg.update(model_name='mcglow', device='cuda', classes_size=1623, controller_rate=0.5, data_shape=[1, 32, 32],
+               compute_dtype='float32')
+    cfg['glow'] = {'hidden_size': 512, 'K': 16, 'L': 3, 'affine': True, 'conv_lu': True}
+    np.random.seed(0)
+    m = models.mcglow()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    return m.set_compute_dtype(dtype) if dtype != torch.float32 else m
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mcglow_omniglot_full_size(dtype):
+    """BASELINE configs[3] as the reference runs it (utils.py:110-112,172-184; data.py:40): [1,32,32], 1623 modes,
+    hidden 512, K=16, L=3 -- 15,844,992 parameters, label-gathered codes, the K-deep 512 -> 512 1x1 form -- against
+    the reference-generated mcglow_full_digest.npz (procedural weights, B=4): ActNorm data init, the likelihood and
+    latents of the first training forward, and the losses of two train_glow.py steps."""
+    import ast
+    from mcgen_amd.trainer import GlowTrainer
+    d = gu.load_npz('mcglow_full_digest.npz')
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(d['shape_keys'], d['shape_vals'])}
+    dtypes = {str(k): str(v) for k, v in zip(d['shape_keys'], d['dtype_vals'])}
+    sd = gu.procedural_state_glow(shapes, dtypes, seed=777)
+    m = _model_omniglot(sd, dtype)
+    assert sum(p.numel() for p in m.parameters()) == 15844992
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    f32 = dtype == torch.float32
+    m.train(True)
+    with torch.no_grad():
+        m({'img': img, 'label': lab, 'noise': torch.from_numpy(d['noise/init/0']).cuda()})
+    sdi = m.state_dict()
+    for k in d:
+        if k.startswith('init_digest/'):
+            got, ref = gu.checksum(sdi[k[len('init_digest/'):]].float().cpu()), d[k]
+            assert np.abs(got - ref).max() < (1e-3 if f32 else 3e-2) * ref[1], (k, got, ref)
+        if k.endswith('initialized') and k in sdi:
+            assert int(sdi[k]) == 1
+    with torch.no_grad():
+        out = m({'img': img, 'label': lab, 'noise': torch.from_numpy(d['noise/0/0']).cuda()})
+    print('first training-mode loss', float(out['loss']), 'reference', float(d['losses'][0]))
+    assert abs(float(out['loss']) - float(d['losses'][0])) < (1e-3 if f32 else 1.5e-1)
+    for i, z in enumerate(out['z']):
+        zs = z.float()[:, :, ::2, ::2]
+        assert _rel(zs, d[f'z0_sample/{i}']) < (2e-3 if f32 else 1e-1), i
+        got, ref = gu.checksum(z.float().cpu()), d[f'z0_digest/{i}']
+        assert np.abs(got - ref).max() < (5e-4 if f32 else 3e-2) * ref[1], (i, got, ref)
+    tr = GlowTrainer(m)
+    losses = [float(tr.train_iteration(img, lab, torch.from_numpy(d[f'noise/{s}/0']).cuda())) for s in range(2)]
+    print('train losses', losses, 'reference', d['losses'])
+    assert abs(losses[0] - d['losses'][0]) < (1e-3 if f32 else 1.5e-1)
+    assert abs(losses[1] - d['losses'][1]) < (5e-2 if f32 else 4e-1)
+    if f32:
+        fin = m.state_dict()
+        for k in d:
+            if k.startswith('final_digest/'):
+                got, ref = gu.checksum(fin[k[len('final_digest/'):]].float().cpu()), d[k]
+                assert np.abs(got - ref).max() < 2e-3 * ref[1], (k, got, ref)

@@ -454,6 +454,136 @@ def fx_vqvae_small():
 FIXTURES.update(vqvae=fx_vqvae_small)
 FIXTURES.update(mcvae_small=fx_mcvae_small, mcvae_full=fx_mcvae_full, mcpixelcnn=fx_mcpixelcnn_small, mcglow=fx_mcglow_small)
 
+
+def _hook_checksums(model, arrays, tag):
+    """Forward hooks on every top-level block of G and D: order-sensitive checksums of the block outputs
+    (NCHW, as the reference holds them) of the NEXT forward of each network."""
+    handles = []
+    for net_name in ('generator', 'discriminator'):
+        net = getattr(model, net_name)
+        for i, blk in enumerate(net.blocks.children()):
+            def hook(mod, inp, out, key=f'{tag}/{net_name}.blocks.{i}'):
+                t = out[0] if isinstance(out, (list, tuple)) else out
+                if torch.is_tensor(t) and t.dim() == 4 and key not in arrays:
+                    arrays[key] = gu.checksum(t)
+            handles.append(blk.register_forward_hook(hook))
+    return handles
+
+
+def fx_mcgan_full_b128():
+    """BASELINE configs[1] at its stated batch: full-size MCGAN (utils.py:156-162), procedural weights, B=128,
+    ONE train iteration (train_gan.py:139-176): losses, a strided sample + digest of the probe batch, per-block
+    activation digests of one G and one D forward, digests of a few final tensors."""
+    import models
+    g_hidden, d_hidden = [256] * 4, [128] * 4
+    set_gan_cfg(g_hidden, d_hidden, 10)
+    torch.manual_seed(0)
+    model = models.mcgan()
+    sd = gu.procedural_state(gu.mcgan_shapes(g_hidden, d_hidden, 10), seed=1234, num_mode=10)
+    model.load_state_dict(sd)
+    model.train(True)
+    B = 128
+    img, lab = gu.synthetic_batch(B, 10, seed=1)
+    zs = gu.latent_batches(6, B, 128, seed=2)
+    arrays = {}
+    hs = _hook_checksums(model, arrays, 'act')
+    with torch.no_grad():
+        gen0 = model.generate(lab, zs[0])
+        d0 = model.discriminate(img, lab)
+    for h in hs:
+        h.remove()
+    arrays['probe_generated'] = gen0.numpy()[:, :, ::4, ::4].copy()
+    arrays['probe_generated_digest'] = gu.checksum(gen0)
+    arrays['probe_d_real'] = d0.numpy()
+    model.load_state_dict(sd)
+    opt = make_opt(model)
+    arrays['losses'] = np.array([ref_train_iteration(model, opt, img, lab, zs)], dtype=np.float64)
+    fin = model.state_dict()
+    for k in ['generator.blocks.2.conv.8.module.weight', 'generator.blocks.1.conv.4.module.weight', 'generator.linear.module.bias',
+              'discriminator.blocks.0.conv.3.module.weight_orig', 'discriminator.blocks.1.conv.2.module.weight_orig',
+              'discriminator.blocks.3.conv.5.module.weight_u', 'generator.blocks.3.module.running_var',
+              'generator.blocks.2.conv.5.module.running_mean']:
+        arrays['digest/' + k] = gu.checksum(fin[k])
+    save('mcgan_full_digest_b128.npz', **arrays)
+
+
+def fx_mcgan_coil_full():
+    """BASELINE configs[2] as the reference runs it (utils.py:116-118,163-165; data.py:51): COIL100 at 32x32,
+    G [512,256,128,64], D [64,128,256,512], 100 modes, non-CIFAR block schedule; procedural weights, B=8,
+    one train iteration + probes."""
+    import models
+    g_hidden, d_hidden = [512, 256, 128, 64], [64, 128, 256, 512]
+    set_gan_cfg(g_hidden, d_hidden, 100, data_name='COIL100')
+    torch.manual_seed(0)
+    model = models.mcgan()
+    shapes = gu.mcgan_shapes(g_hidden, d_hidden, 100, cifar_layout=False)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes == ref_shapes, set(shapes.items()) ^ set(ref_shapes.items())
+    sd = gu.procedural_state(shapes, seed=4242, num_mode=100)
+    model.load_state_dict(sd)
+    model.train(True)
+    B = 8
+    img, lab = gu.synthetic_batch(B, 100, seed=5)
+    zs = gu.latent_batches(6, B, 128, seed=6)
+    arrays = {}
+    hs = _hook_checksums(model, arrays, 'act')
+    with torch.no_grad():
+        gen0 = model.generate(lab, zs[0])
+        d0 = model.discriminate(img, lab)
+    for h in hs:
+        h.remove()
+    arrays['probe_generated'] = gen0.numpy().copy()
+    arrays['probe_d_real'] = d0.numpy()
+    model.load_state_dict(sd)
+    opt = make_opt(model)
+    arrays['losses'] = np.array([ref_train_iteration(model, opt, img, lab, zs)], dtype=np.float64)
+    fin = model.state_dict()
+    for k in ['generator.blocks.0.conv.4.module.weight', 'generator.blocks.2.shortcut.2.module.weight',
+              'discriminator.blocks.3.conv.5.module.weight_orig', 'discriminator.blocks.2.shortcut.1.module.weight_u']:
+        arrays['digest/' + k] = gu.checksum(fin[k])
+    save('mcgan_coil_full_digest.npz', **arrays)
+
+
+def fx_mcglow_full():
+    """BASELINE configs[3] as the reference runs it (utils.py:110-112,172-184; data.py:40): MCGlow on Omniglot
+    [1,32,32], 1623 modes, hidden 512, K=16, L=3 (15,844,992 parameters); procedural weights (golden_util.
+    procedural_state_glow), B=4: ActNorm data init forward, then two train_glow.py steps; losses + z digests."""
+    import models
+    cfg['model_name'] = 'mcglow'; cfg['device'] = 'cpu'; cfg['classes_size'] = 1623; cfg['controller_rate'] = 0.5
+    cfg['data_shape'] = [1, 32, 32]
+    cfg['glow'] = {'hidden_size': 512, 'K': 16, 'L': 3, 'affine': True, 'conv_lu': True}
+    torch.manual_seed(0); np.random.seed(0)
+    model = models.mcglow(); model.train(True)
+    assert sum(p.numel() for p in model.parameters()) == 15844992
+    ref_sd = model.state_dict()
+    keys = sorted(ref_sd)
+    shapes = {k: tuple(ref_sd[k].shape) for k in keys}
+    dtypes = {k: str(ref_sd[k].dtype).replace('torch.', '') for k in keys}
+    sd = gu.procedural_state_glow(shapes, dtypes, seed=777)
+    model.load_state_dict(sd)
+    arrays = {'shape_keys': np.array(keys), 'shape_vals': np.array([str(shapes[k]) for k in keys]),
+              'dtype_vals': np.array([dtypes[k] for k in keys])}
+    img, lab = gu.synthetic_batch(4, 1623, seed=71, shape=(1, 32, 32))
+    arrays['img'] = img.numpy(); arrays['label'] = lab.numpy()
+    with _PatchedNoise(800) as pn, torch.no_grad():                       # train_glow.py:60-67 data-dependent init
+        model({'img': img.clone(), 'label': lab})
+    arrays['noise/init/0'] = pn.drawn[0].numpy()
+    init = model.state_dict()
+    for k in ['blocks.0.flows.0.actnorm.loc', 'blocks.0.flows.0.coupling.net.1.module.scale',
+              'blocks.1.flows.7.coupling.net.5.module.loc', 'blocks.2.flows.15.actnorm.scale']:
+        arrays['init_digest/' + k] = gu.checksum(init[k])
+    first = _single_opt_steps(model, {'img': img, 'label': lab}, 900, 2, arrays)
+    for i, z in enumerate(first['z']):
+        arrays[f'z0_digest/{i}'] = gu.checksum(z)
+        arrays[f'z0_sample/{i}'] = z.detach().numpy()[:, :, ::2, ::2].copy()
+    fin = model.state_dict()
+    for k in ['blocks.0.flows.3.coupling.net.4.module.weight', 'blocks.2.flows.9.invconv.w_l', 'blocks.1.prior.conv.weight']:
+        arrays['final_digest/' + k] = gu.checksum(fin[k])
+    save('mcglow_full_digest.npz', **arrays)
+
+
+FIXTURES.update(mcgan_full_b128=fx_mcgan_full_b128, mcgan_coil_full=fx_mcgan_coil_full, mcglow_full=fx_mcglow_full)
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)

@@ -54,9 +54,14 @@ def main():
     src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
     dst = os.path.join(ROOT, 'profiles')
     shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+    meta = {}
     for line in open(os.path.join(src, 'bench_trace.log')):
         if line.startswith('{"metric"'):
             open(os.path.join(dst, f'{tag}_bench.json'), 'w').write(line)
+            b = json.loads(line)
+            # what the table was measured on: bench.py attaches roofline.traffic only to a run of the same workload
+            meta = {'workload': b['config'].get('workload_key'), 'batch': b['config'].get('batch_per_gpu'), 'dtype': b['dtype'],
+                    'commit': os.popen(f'git -C {ROOT} rev-parse --short HEAD').read().strip(), 'tag': tag}
     fetch = pmc(os.path.join(src, 'fetch', 'f_counter_collection.csv'), 'FETCH_SIZE')
     write = pmc(os.path.join(src, 'write', 'w_counter_collection.csv'), 'WRITE_SIZE')
     table = {}
@@ -66,9 +71,12 @@ def main():
         table[k] = {'launches': len(f), 'fetch_size_kb': fk, 'write_size_kb': wk,
                     'bytes_per_launch': (2.0 * fk + wk) * 1024.0,
                     'note': 'FETCH_SIZE x2 (gfx950 half-count of wide reads) + WRITE_SIZE, averaged over the launches of one eager iteration'}
+    table['_meta'] = meta
     json.dump(table, open(os.path.join(dst, f'{tag}_traffic.json'), 'w'), indent=1)
     json.dump(table, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
     for k, v in table.items():
+        if k == '_meta':
+            continue
         print(f'{k:28s} n={v["launches"]:4d} fetch {v["fetch_size_kb"]:10.0f} KB  write {v["write_size_kb"]:10.0f} KB')
 
 
