@@ -1,0 +1,44 @@
+"""Drop-in for the names the reference's drivers import from src/utils.py (train_gan.py:14):
+save, load, to_device, process_control, process_dataset, collate, save_img, recur."""
+import _path  # noqa: F401
+import torch
+
+from mcgen_amd.checkpoint import save, load  # noqa: F401
+from mcgen_amd.config import cfg, process_control  # noqa: F401
+
+
+def to_device(input, device):
+    """utils.py:48-50 (recur over lists / dicts of tensors)."""
+    return recur(lambda x, y: x.to(y), input, device)
+
+
+def recur(fn, input, *args):
+    """utils.py:62-78."""
+    if isinstance(input, torch.Tensor):
+        return fn(input, *args)
+    if isinstance(input, (list, tuple)):
+        return type(input)(recur(fn, v, *args) for v in input)
+    if isinstance(input, dict):
+        return {k: recur(fn, v, *args) for k, v in input.items()}
+    raise ValueError('Not valid input type')
+
+
+def process_dataset(dataset):
+    """utils.py:98-101: the class count comes from the dataset object."""
+    cfg['classes_size'] = dataset.classes_size
+
+
+def collate(input):
+    """utils.py:195-198: lists of per-sample tensors -> one stacked tensor per key."""
+    for k in input:
+        input[k] = torch.stack(input[k], 0)
+    return input
+
+
+def save_img(img, path, nrow=10, padding=2, pad_value=0, range=None):
+    """utils.py:48-60 needs torchvision.utils.save_image, which this image does not ship: the grid is written as a
+    .npy next to the requested path instead (same tensor, NCHW)."""
+    import os
+    import numpy as np
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    np.save(os.path.splitext(path)[0] + '.npy', img.detach().cpu().numpy())

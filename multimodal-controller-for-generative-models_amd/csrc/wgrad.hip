@@ -834,6 +834,12 @@ __global__ void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
 
+#ifdef MCGEN_TUNING
+static long wg_env(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+#else
+static long wg_env(const char*, long dflt) { return dflt; }
+#endif
+
 template <typename T, int KS, int LGW>
 static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     using TR = WgTraits<T>;
@@ -843,14 +849,15 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
     dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
-    static const int xcd_map = getenv("MCGEN_WGRAD_XCD") ? atoi(getenv("MCGEN_WGRAD_XCD")) : 1;
-    const char* mode = getenv("MCGEN_WGRAD_MODE");            // tuning override: "0" single role, "1" producer/consumer
+    // tuning builds (-DMCGEN_TUNING) read these once per process; the shipped library has no environment-dependent dispatch
+    static const int xcd_map = (int)wg_env("MCGEN_WGRAD_XCD", 1);
+    static const int mode = (int)wg_env("MCGEN_WGRAD_MODE", -1);      // 0 single role, 1 producer/consumer, -1 policy
     // the role split only pays when a workgroup walks several tiles (staging of tile i+1 overlaps tile i)
-    const bool pc = mode ? (mode[0] == '1') : (m_tiles >= 4 * p->splits);
+    const bool pc = mode >= 0 ? (mode == 1) : (m_tiles >= 4 * p->splits);
     if constexpr (sizeof(T) == 2 && (1 << LGW) <= WG_BM) {
         // ring form: bf16, every tile inside one image, and the rings fit in LDS.  First choice, also for 1x1 gradients with
         // many chunks (measured against the chunk groups below: 128->128 at 16x16 47 -> 24 us, 256->256 at 32x32 134 -> 118)
-        static const int ring = getenv("MCGEN_WGRAD_RING") ? atoi(getenv("MCGEN_WGRAD_RING")) : 1;
+        static const int ring = (int)wg_env("MCGEN_WGRAD_RING", 1);
         const int nix = (PP * 4 + WG_NT - 1) / WG_NT;
         const int ldsr = std::max(2 * a_bytes + WG_NR * nix * WG_NT * 16 + WG_ND * WG_DSLOT + WG_NR * 4 * 128, KS * KS * 8192);
         // (upsampled reads need tiles that start on even rows: at least two rows per tile)
@@ -871,9 +878,9 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     if constexpr (KS == 1) {
         // 1x1 on small maps (no ring form): chunk groups of 4 when there are enough chunks (see wgrad_pc_kernel)
         constexpr int NCH = 4;
-        const char* g = getenv("MCGEN_WGRAD_GROUP");
+        static const int grp = (int)wg_env("MCGEN_WGRAD_GROUP", 1);
         const int lds4 = 2 * NCH * a_bytes + 2 * WG_BM * TR::DPITCH;     // bf16: 136 KB; fp32 does not fit -> plain path
-        if (pc && wgrad_chunks(p) >= NCH && lds4 <= 160 * 1024 && !(g && g[0] == '0')) {
+        if (pc && wgrad_chunks(p) >= NCH && lds4 <= 160 * 1024 && grp) {
             auto kern4 = wgrad_pc_kernel<T, 1, LGW, NCH, false>;
             static bool raised4 = false;
             if (lds4 > 64 * 1024 && !raised4) {
@@ -890,7 +897,7 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         // bf16, whole pixel tiles: the dy tile by LDS-DMA (opt-in: measured neutral -- 86.7 vs 87.5 us on the 128->128
         // 32x32 layer -- so the register path stays the default)
-        static const int dy_dma = getenv("MCGEN_WGRAD_DMA") ? atoi(getenv("MCGEN_WGRAD_DMA")) : 0;
+        static const int dy_dma = (int)wg_env("MCGEN_WGRAD_DMA", 0);
         if (pc && dy_dma && Mtot % WG_BM == 0) {
             const int ldsd = 2 * a_bytes + 2 * WG_BM * WG_BCO * 2;
             auto kd = wgrad_pc_kernel<T, KS, LGW, 1, true>;

@@ -123,17 +123,20 @@ class MCGatedPixelCNN(nn.Module):
         from .. import ops
         return {'loss': loss, 'logits': ops.to_nchw(logits, self.input_size)}
 
-    def generate(self, C, x=None):
-        """Ancestral sampling, one full forward per position (mcpixelcnn.py:103-112)."""
+    def generate(self, C, x=None, sampler=None):
+        """Ancestral sampling, one full forward per position (mcpixelcnn.py:103-112).  `sampler(probs [N, K]) -> [N]`
+        replaces the multinomial draw (parity tests decode greedily; the reference's call is the default)."""
         if x is None:
             x = torch.zeros((C.size(0), 8, 8), dtype=torch.long, device=cfg['device'])
+        if sampler is None:
+            sampler = lambda p: p.multinomial(1).squeeze(-1)                  # noqa: E731
         inp = {'img': x, 'label': C}
         with torch.no_grad():
             for i in range(x.size(1)):
                 for j in range(x.size(2)):
                     out = self.forward(inp)
                     probs = F.softmax(out['logits'][:, :, i, j], -1)
-                    inp['img'][:, i, j].copy_(probs.multinomial(1).squeeze(-1))
+                    inp['img'][:, i, j].copy_(sampler(probs))
         return inp['img']
 
 

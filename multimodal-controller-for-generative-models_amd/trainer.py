@@ -49,13 +49,50 @@ class FusedAdam:
         for p in self.fs.tensors:
             _bump(p)
 
+    # ---- torch.optim.Adam's state_dict format (train_gan.py:114-115,268-269: the reference checkpoints
+    # optimizer['generator'].state_dict() and loads it back with load_state_dict) --------------------------------
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'step': self.step_count, 'lr': self.lr, 'betas': self.betas,
-                'eps': self.eps, 'weight_decay': self.wd}
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} over the parameters in
+        `model.parameters()` order -- loads into a torch.optim.Adam built on the same parameters, and vice versa.
+        'state' is empty before the first step, as torch's is."""
+        self.fs.ensure()
+        state = {}
+        if int(self.step_count) > 0:
+            step = self.step_count.to(torch.float32).reshape(())
+            for i, t in enumerate(self.fs.tensors):
+                state[i] = {'step': step.clone(), 'exp_avg': self.fs.view_of(self.m, t).clone(),
+                            'exp_avg_sq': self.fs.view_of(self.v, t).clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(self.fs.tensors)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_count.copy_(sd['step'])
-        self.lr, self.betas, self.eps, self.wd = sd['lr'], tuple(sd['betas']), sd['eps'], sd['weight_decay']
+        self.fs.ensure()
+        if 'param_groups' not in sd:                     # round-1 private format {'m', 'v', 'step', ...}
+            self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_count.copy_(sd['step'])
+            self.lr, self.betas, self.eps, self.wd = sd['lr'], tuple(sd['betas']), sd['eps'], sd['weight_decay']
+            return
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.fs.tensors):
+            raise ValueError('Not valid optimizer state: expected one parameter group over the network\'s parameters')
+        g = groups[0]
+        if g.get('amsgrad') or g.get('maximize'):
+            raise ValueError('Not valid optimizer state: amsgrad / maximize are not supported')
+        self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+        self.m.zero_(); self.v.zero_(); self.step_count.zero_()
+        steps = set()
+        for key, t in zip(g['params'], self.fs.tensors):
+            st = sd['state'].get(key)
+            if st is None:
+                continue
+            self.fs.view_of(self.m, t).copy_(st['exp_avg'])
+            self.fs.view_of(self.v, t).copy_(st['exp_avg_sq'])
+            steps.add(int(st['step']))
+        if len(steps) > 1:
+            raise ValueError('Not valid optimizer state: parameters disagree on the step count')
+        if steps:
+            self.step_count.fill_(steps.pop())
 
 
 class GANTrainer:

@@ -1,0 +1,192 @@
+"""Checkpoint wire format (train_gan.py:111-122,258-282; utils.py:26-45) and the import-name shims under compat/
+(train_gan.py:3,10-14).  CPU tests: optimizer-state conversion both ways, file round trip, shim imports.
+GPU tests: resume reproduces the uninterrupted run; the driver counterpart runs and writes a reference-layout file."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small_model(device='cpu'):
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg, process_control
+    cfg.update(data_name='CIFAR10', model_name='mcgan', device=device)
+    cfg['control'] = {'controller_rate': '0.5'}
+    cfg.pop('classes_size', None)
+    process_control()
+    cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'] = [32] * 4, [16] * 4
+    d = gu.load_npz('mcgan_small.npz')
+    m = models.mcgan()
+    m.load_state_dict(gu.state_from_npz(d))
+    return m.to(device), d
+
+
+def test_fused_adam_state_is_torch_adam_state(tmp_path):
+    """FusedAdam.state_dict() loads into torch.optim.Adam over the same parameters and back (the reference
+    checkpoints optimizer.state_dict(), train_gan.py:114-115)."""
+    from mcgen_amd.gan_engine import FlatState
+    from mcgen_amd.trainer import FusedAdam
+    m, _ = _small_model()
+    params = list(m.generator.parameters())
+    fa = FusedAdam(FlatState(params), lr=2e-4, betas=(0.5, 0.999))
+    assert fa.state_dict()['state'] == {}                              # fresh optimizer: empty, as torch's
+    g = torch.Generator().manual_seed(0)
+    fa.m.copy_(torch.randn(fa.m.shape, generator=g)); fa.v.copy_(torch.rand(fa.v.shape, generator=g)); fa.step_count.fill_(7)
+    sd = fa.state_dict()
+    ref = torch.optim.Adam(params, lr=1.0)
+    ref.load_state_dict(sd)                                            # torch accepts the format
+    assert ref.param_groups[0]['lr'] == 2e-4 and tuple(ref.param_groups[0]['betas']) == (0.5, 0.999)
+    for i, p in enumerate(params):
+        st = ref.state[p]
+        assert int(st['step']) == 7
+        assert torch.equal(st['exp_avg'], fa.fs.view_of(fa.m, p)) and torch.equal(st['exp_avg_sq'], fa.fs.view_of(fa.v, p))
+    # and the other way: a torch.optim.Adam that has taken steps
+    ref2 = torch.optim.Adam(params, lr=3e-4, betas=(0.5, 0.999))
+    for _ in range(2):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g)
+        ref2.step()
+    fb = FusedAdam(FlatState(params))
+    fb.load_state_dict(ref2.state_dict())
+    assert int(fb.step_count) == 2 and fb.lr == 3e-4 and fb.betas == (0.5, 0.999)
+    for p in params:
+        assert torch.equal(fb.fs.view_of(fb.m, p), ref2.state[p]['exp_avg'])
+        assert torch.equal(fb.fs.view_of(fb.v, p), ref2.state[p]['exp_avg_sq'])
+    with pytest.raises(ValueError):
+        fb.load_state_dict({'state': {}, 'param_groups': [dict(ref2.state_dict()['param_groups'][0], params=[0, 1])]})
+
+
+def test_checkpoint_file_layout_round_trip(tmp_path):
+    """The dict train_gan.py:112-118 saves, through utils.save / utils.load (pickle protocol 2, CPU map_location)."""
+    from mcgen_amd import checkpoint as ck
+    from mcgen_amd.config import cfg
+    m, _ = _small_model()
+    opt = {'generator': torch.optim.Adam(m.generator.parameters(), lr=2e-4, betas=(0.5, 0.999)),
+           'discriminator': torch.optim.Adam(m.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999))}
+    sch = {k: torch.optim.lr_scheduler.MultiStepLR(o, milestones=[65535]) for k, o in opt.items()}   # train_gan.py:241
+    path = str(tmp_path / 'output' / 'model' / '0_CIFAR10_label_mcgan_0.5_checkpoint.pt')
+    ck.save_checkpoint(path, m, opt, 4, cfg, sch, logger=None)
+    raw = ck.load(path)
+    assert set(raw) == {'cfg', 'epoch', 'model_dict', 'optimizer_dict', 'scheduler_dict', 'logger'}
+    assert raw['epoch'] == 4 and raw['cfg']['model_name'] == 'mcgan'
+    assert set(raw['optimizer_dict']) == {'generator', 'discriminator'} == set(raw['scheduler_dict'])
+    assert set(raw['model_dict']) == set(m.state_dict())
+    m2, _ = _small_model()
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(1.0)
+    epoch, logger = ck.resume(path, m2, {'generator': torch.optim.Adam(m2.generator.parameters()),
+                                         'discriminator': torch.optim.Adam(m2.discriminator.parameters())})
+    assert epoch == 4 and logger is None
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_compat_shims_bind_reference_import_names():
+    """`import models`, `from config import cfg`, `import modules`, `from utils import ...` (train_gan.py:3,10-14)
+    resolve to this package when compat/ is on the path; the tree carries the reference's state_dict keys."""
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(ROOT, 'compat')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import models, modules
+from config import cfg
+from utils import save, load, to_device, process_control, process_dataset, collate, save_img
+import golden_util as gu, torch
+cfg.update(data_name='CIFAR10', model_name='mcgan', device='cpu'); cfg.pop('classes_size', None)
+process_control()
+cfg['gan']['generator_hidden_size'], cfg['gan']['discriminator_hidden_size'] = [32] * 4, [16] * 4
+m = models.mcgan()
+sd = gu.state_from_npz(gu.load_npz('mcgan_small.npz'))
+assert set(m.state_dict()) == set(sd)
+m.load_state_dict(sd)
+assert type(m.generator.blocks[0].mc_1) is modules.MultimodalController
+assert type(m.generator.blocks[0].mc_1).__name__ == 'MultimodalController'      # create / transit match by class name
+models.utils.create(m); models.utils.transit(m, 2, 0.5)
+for name in ('mcglow', 'mcpixelcnn', 'mcvae', 'vqvae', 'MCGAN', 'Generator', 'Discriminator', 'GenResBlock', 'DisResBlock'):
+    assert hasattr(models, name), name
+b = collate({'img': [torch.zeros(3, 4, 4), torch.ones(3, 4, 4)], 'label': [torch.tensor(1), torch.tensor(2)]})
+assert b['img'].shape == (2, 3, 4, 4) and to_device(b, 'cpu')['label'].tolist() == [1, 2]
+print('SHIMS-OK')
+'''.replace('ROOT', repr(ROOT))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'SHIMS-OK' in r.stdout, r.stderr[-3000:]
+
+
+def test_device_loader_matches_totensor_normalize():
+    """mcgen_amd.data: uint8 NHWC -> (x/255 - 0.5)/0.5 NCHW fp32 (data.py:31-33), every sample exactly once per epoch."""
+    from mcgen_amd.data import DeviceLoader, normalize_uint8, synthetic_uint8_dataset
+    img, lab = synthetic_uint8_dataset(100, [3, 32, 32], 10, seed=1, device='cpu')
+    x = normalize_uint8(img)
+    ref = (img.permute(0, 3, 1, 2).float() / 255 - 0.5) / 0.5
+    assert torch.equal(x, ref) and float(x.min()) >= -1 and float(x.max()) <= 1
+    seen = []
+    loader = DeviceLoader(img, lab, 32, shuffle=True, generator=torch.Generator().manual_seed(0))
+    assert len(loader) == 4
+    for b in loader:
+        assert b['img'].dtype == torch.float32 and b['label'].dtype == torch.int64
+        seen.append(b['img'])
+    allx = torch.cat(seen)
+    assert allx.shape[0] == 100
+    assert sorted(allx.flatten(1).sum(1).tolist()) == sorted(ref.flatten(1).sum(1).tolist())
+    assert len(DeviceLoader(img, lab, 32, drop_last=True)) == 3
+
+
+@pytest.mark.gpu
+def test_resume_reproduces_uninterrupted_run(tmp_path):
+    """Two iterations straight vs one iteration, checkpoint (reference layout), fresh model + trainer, resume, one
+    more iteration: same losses, same final parameters (FusedAdam state travels as torch.optim.Adam's)."""
+    from mcgen_amd import checkpoint as ck
+    from mcgen_amd.config import cfg
+    from mcgen_amd.trainer import GANTrainer
+    m, d = _small_model('cuda')
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    zs = [torch.from_numpy(z).cuda() for z in d['z']]
+    tr = GANTrainer(m, 10)
+    tr.train_iteration(img, lab, zs[0:6])
+    path = str(tmp_path / 'ck.pt')
+    ck.save_checkpoint(path, m, {'generator': tr.opt_g, 'discriminator': tr.opt_d}, 2, cfg)
+    l_straight = tr.train_iteration(img, lab, zs[6:12])
+    m2, _ = _small_model('cuda')
+    tr2 = GANTrainer(m2, 10)
+    epoch, _ = ck.resume(path, m2, {'generator': tr2.opt_g, 'discriminator': tr2.opt_d})
+    assert epoch == 2 and int(tr2.opt_d.step_count) == 5 and int(tr2.opt_g.step_count) == 1
+    tr2.geng.refresh_images(force=True)
+    l_resumed = tr2.train_iteration(img, lab, zs[6:12])
+    assert abs(float(l_straight[0]) - float(l_resumed[0])) < 1e-6 and abs(float(l_straight[1]) - float(l_resumed[1])) < 1e-6
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-6 * (1 + float(a.float().abs().max())), k
+    # a reference-side resume: the same file drives torch.optim.Adam on the module surface
+    m3, _ = _small_model('cuda')
+    opt3 = {'generator': torch.optim.Adam(m3.generator.parameters(), lr=1.0), 'discriminator': torch.optim.Adam(m3.discriminator.parameters(), lr=1.0)}
+    ck.resume(path, m3, opt3)
+    assert opt3['discriminator'].param_groups[0]['lr'] == 2e-4
+    p0 = next(iter(m3.discriminator.parameters()))
+    assert int(opt3['discriminator'].state[p0]['step']) == 5 and opt3['discriminator'].state[p0]['exp_avg'].is_cuda
+
+
+@pytest.mark.gpu
+def test_driver_counterpart_runs_and_resumes(tmp_path):
+    """compat/train_gan.py with the reference's CLI flags (train_gan.py:18-28) on a synthetic on-device dataset:
+    two epochs, then --resume_mode 1 picks the checkpoint up; the file has the reference's layout."""
+    from mcgen_amd import checkpoint as ck
+    out = str(tmp_path / 'output')
+    base = [sys.executable, os.path.join(ROOT, 'compat', 'train_gan.py'), '--data_name', 'CIFAR10', '--model_name', 'mcgan',
+            '--control_name', '0.5', '--init_seed', '0', '--synthetic_size', '256', '--output_dir', out, '--generate_per_mode', '2']
+    r = subprocess.run(base + ['--num_epochs', '1'], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'Train Epoch: 1' in r.stdout
+    path = os.path.join(out, 'model', '0_CIFAR10_label_mcgan_0.5_checkpoint.pt')
+    raw = ck.load(path)
+    assert raw['epoch'] == 2 and set(raw['optimizer_dict']) == {'generator', 'discriminator'}
+    assert int(raw['optimizer_dict']['discriminator']['state'][0]['step']) == 10     # 2 batches x 5 D updates
+    r = subprocess.run(base + ['--num_epochs', '2', '--resume_mode', '1'], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'Resume from 2' in r.stdout and 'Train Epoch: 2' in r.stdout and 'Train Epoch: 1' not in r.stdout
+    assert int(ck.load(path)['optimizer_dict']['discriminator']['state'][0]['step']) == 20
