@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);
+int mcgen_abi_version(void);      /* 2: mcgen_seg_t.group_n, mcgen_bn_finalize_groups */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -42,13 +42,18 @@ int mcgen_abi_version(void);
  */
 typedef struct {
     const void*  x;       /* [N, H>>ups, W>>ups, C]                                   */
-    const float* scale;   /* [C] or NULL                                              */
-    const float* shift;   /* [C] (read only when scale != NULL)                       */
+    const float* scale;   /* [C] ([N/group_n][C] when group_n > 0) or NULL            */
+    const float* shift;   /* same shape as scale (read only when scale != NULL)       */
     const float* code;    /* [N, C] = indicator @ codebook, or NULL                   */
     int32_t C;            /* channels of x (multiple of 8)                            */
     int32_t ups;          /* 1: x is at half the convolution's resolution             */
     int32_t relu;
     int32_t ksize;        /* 3 (padding 1) or 1 (padding 0); stride is always 1       */
+    int32_t group_n;      /* > 0: the batch is N/group_n independent BatchNorm batches of group_n images each
+                           * (several training-mode generator forwards run as one pass, train_gan.py:145-146):
+                           * image n is normalised with row n / group_n of scale / shift.  0: one batch.
+                           * Convolution launches only (mcgen_wgrad requires 0); a tile never straddles groups. */
+    int32_t reserved_;
 } mcgen_seg_t;
 
 /* Fused convolution  y = epilogue( sum_seg conv(prologue_seg(x_seg), W_seg) ).
@@ -192,6 +197,14 @@ int mcgen_bn_finalize(const float* partials, int tiles, int pitch, int fold, int
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
                       void* stream);
+/* `groups` consecutive, equally sized runs of tiles are independent BatchNorm batches (count = elements per channel
+ * of ONE group): outputs are [groups][C]; the running statistics take the groups' momentum updates one after the
+ * other, in order -- what `groups` successive training-mode forwards of the module would leave behind
+ * (train_gan.py:145-146 runs the generator once per discriminator update; its weights do not change in between). */
+int mcgen_bn_finalize_groups(const float* partials, int tiles, int pitch, int fold, int C, double count, int groups,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                             void* stream);
 /* eval mode: scale/shift from the running statistics */
 int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift, void* stream);

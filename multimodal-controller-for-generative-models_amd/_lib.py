@@ -12,7 +12,8 @@ F32, BF16 = 0, 1
 
 class Seg(C.Structure):
     _fields_ = [('x', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('code', C.c_void_p),
-                ('C', C.c_int32), ('ups', C.c_int32), ('relu', C.c_int32), ('ksize', C.c_int32)]
+                ('C', C.c_int32), ('ups', C.c_int32), ('relu', C.c_int32), ('ksize', C.c_int32),
+                ('group_n', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class Conv(C.Structure):
@@ -115,6 +116,7 @@ SYMBOLS = {
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_bn_finalize_groups': (_i, [_vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'mcgen_bn_eval_affine': (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'mcgen_bn_bwd_finalize': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),

@@ -259,7 +259,7 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
     // running several workgroups per CU (small LDS / register footprint)
     int blk = 0;
     for (int s = 0; s < p.nseg; ++s) {
-        const mcgen_seg_t sg = p.seg[s];
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
         const int halo = sg.ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         PatchStager<T, NT, C::NI, APITCH> stager;
@@ -412,7 +412,7 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     int gi = 0;
     G_dma(0);
     for (int s = 0; s < p.nseg; ++s) {
-        const mcgen_seg_t sg = p.seg[s];
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
         const int halo = sg.ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         PatchStager<T, NT, C::NI, APITCH> stager;
@@ -575,7 +575,7 @@ void conv_dma3g_kernel(const mcgen_conv_t p, const int a_bytes) {
     int gi = 0;
     G_dma(0);
     for (int s = 0; s < p.nseg; ++s) {
-        const mcgen_seg_t sg = p.seg[s];
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
         const int halo = sg.ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         PatchStager<T, NT, C::NI, APITCH> stager;
@@ -709,7 +709,7 @@ void conv_cp_kernel(const mcgen_conv_t p, const int a_bytes, const int subw) {
 
     int half = 0, blk_seg = 0;                                 // ring half of the step being consumed; first tile of the segment
     for (int s = 0; s < p.nseg; ++s) {
-        const mcgen_seg_t sg = p.seg[s];
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
         const int halo = sg.ksize >> 1;
         const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
         const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
@@ -1018,6 +1018,7 @@ static int validate(const mcgen_conv_t* p) {
         MCGEN_CHECK(g.x && g.C > 0 && g.C % 8 == 0, "conv_fused: segment %d: C must be a positive multiple of 8", s);
         MCGEN_CHECK(g.ksize == 1 || g.ksize == 3, "conv_fused: segment %d: ksize must be 1 or 3", s);
         MCGEN_CHECK(!g.ups || (p->H >= 2 && p->W >= 2), "conv_fused: upsampled segment needs H, W >= 2");
+        MCGEN_CHECK(g.group_n >= 0 && (g.group_n == 0 || p->N % g.group_n == 0), "conv_fused: segment %d: group_n must divide N", s);
     }
     if (p->pool) MCGEN_CHECK(p->H >= 2 && p->W >= 2, "conv_fused: pooling needs H, W >= 2");
     MCGEN_CHECK(p->stats_mode >= 0 && p->stats_mode <= 2, "conv_fused: bad stats_mode");
@@ -1047,6 +1048,11 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     const TilePick t = pick_tile(p, dtype);
     // pooling / whole-row tiles need at least two rows per tile
     MCGEN_CHECK(t.BM >= 2 * p->W || p->H * p->W <= t.BM, "conv_fused: tile of %d pixels too small for W=%d", t.BM, p->W);
+    for (int s = 0; s < p->nseg; ++s) {
+        const int ti = t.BM > p->H * p->W ? t.BM / (p->H * p->W) : 1;          // images per tile
+        MCGEN_CHECK(p->seg[s].group_n == 0 || p->seg[s].group_n % ti == 0,
+                    "conv_fused: a tile of %d images would straddle BatchNorm groups of %d images", ti, p->seg[s].group_n);
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype != MCGEN_F32 && dtype != MCGEN_BF16) return mcgen_fail("conv_fused: unknown dtype %d", dtype);
     return dispatch(p, dtype, t, st);

@@ -42,6 +42,16 @@ static __device__ __forceinline__ Geo make_geo(int BM, int tile_m, int H, int W)
     return g;
 }
 
+// The segment as THIS tile sees it: with BatchNorm statistics groups (mcgen_seg_t.group_n) the affine of the tile's group.
+static __device__ __forceinline__ mcgen_seg_t seg_for_tile(const mcgen_seg_t& s, const Geo& g) {
+    mcgen_seg_t r = s;
+    if (r.group_n > 0 && r.scale) {
+        const int grp = g.n0 / r.group_n;
+        r.scale += (size_t)grp * r.C; r.shift += (size_t)grp * r.C;
+    }
+    return r;
+}
+
 // Stages the tile's input window (tile + halo) for one chunk of 32 channels into LDS as
 // [window pixel][32 channels] with pitch APITCH, applying the segment's prologue:
 // nearest-x2 upsample by index, BatchNorm scale/shift, ReLU, MultimodalController code.

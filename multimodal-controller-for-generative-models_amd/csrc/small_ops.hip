@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 1; }
+extern "C" int mcgen_abi_version(void) { return 2; }
 
 namespace {
 
@@ -213,27 +213,34 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
         for (int w = 0; w < RED_SLOTS; ++w) { s1 += sh[w][0][ch]; s2 += sh[w][1][ch]; }
 }
 __global__ __launch_bounds__(64 * RED_WAVES)
-void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count,
+void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count, int groups,
                         const float* __restrict__ gamma, const float* __restrict__ beta,
                         float* rmean, float* rvar, float momentum, float eps,
                         float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
     __shared__ double sh[RED_SLOTS][2][RED_CPB];
     const int c = blockIdx.x * RED_CPB + (threadIdx.x % RED_CPB);
-    double s1, s2;
-    reduce_partials(part, tiles * fold, pitch, fold, C, c, c < C, s1, s2, sh);
-    if (threadIdx.x >= RED_CPB || c >= C) return;
-    s1 *= perturb1; s2 *= perturb2;                      // 1.0 unless the sensitivity probe (MCGEN_BN_PERTURB) is on
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
-    mean_o[c] = (float)mean; rstd_o[c] = rstd;
-    if (rmean) {
+    const bool owner = threadIdx.x < RED_CPB && c < C;
+    const int tpg = tiles / groups;                        // tiles per statistics group (host checks divisibility)
+    float rm = 0.f, rv = 0.f;
+    if (owner && rmean) { rm = rmean[c]; rv = rvar[c]; }
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        if (g > 0) __syncthreads();                        // the previous group's combine has read `sh`
+        reduce_partials(part + (size_t)g * tpg * 2 * pitch, tpg * fold, pitch, fold, C, c, c < C, s1, s2, sh);
+        if (!owner) continue;
+        s1 *= perturb1; s2 *= perturb2;                  // 1.0 unless the sensitivity probe (MCGEN_BN_PERTURB) is on
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        const size_t o = (size_t)g * C + c;
+        scale[o] = sc; shift[o] = beta[c] - (float)mean * sc;
+        mean_o[o] = (float)mean; rstd_o[o] = rstd;
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;      // the groups' updates in order, as successive forwards
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
     }
+    if (owner && rmean) { rmean[c] = rm; rvar[c] = rv; }
 }
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                       float eps, int C, float* scale, float* shift) {
@@ -649,15 +656,23 @@ extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dty
 
 // sensitivity probe (tools/digest_probe.py): MCGEN_BN_PERTURB=1e-7 nudges the batch sums by that relative amount
 static double bn_perturb() { static const double v = getenv("MCGEN_BN_PERTURB") ? atof(getenv("MCGEN_BN_PERTURB")) : 0.0; return v; }
+extern "C" int mcgen_bn_finalize_groups(const float* partials, int tiles, int pitch, int fold, int C, double count, int groups,
+                                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                        float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
+                "bn_finalize: bad arguments");
+    MCGEN_CHECK(groups >= 1 && tiles % groups == 0, "bn_finalize: %d tiles do not split into %d statistics groups", tiles, groups);
+    MCGEN_CHECK((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
+                       groups, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
+                       1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
+    MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
+}
 extern "C" int mcgen_bn_finalize(const float* partials, int tiles, int pitch, int fold, int C, double count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
-    MCGEN_CHECK(partials && gamma && beta && scale && shift && mean && rstd && tiles > 0 && fold >= 1 && pitch >= fold * C,
-                "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(64 * RED_WAVES), 0, STREAM(stream), partials, tiles, pitch, fold, C, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
-                       1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
-    MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
+    return mcgen_bn_finalize_groups(partials, tiles, pitch, fold, C, count, 1, gamma, beta, running_mean, running_var, momentum, eps,
+                                    scale, shift, mean, rstd, stream);
 }
 extern "C" int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                     float eps, int C, float* scale, float* shift, void* stream) {

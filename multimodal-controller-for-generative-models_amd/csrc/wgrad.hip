@@ -973,6 +973,7 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
     MCGEN_CHECK(WG_BM >= 2 * p->W || p->H * p->W <= WG_BM, "wgrad: W too large for the pixel tile");
     MCGEN_CHECK(p->seg.C > 0 && p->seg.C % 8 == 0 && p->Cdy % 8 == 0, "wgrad: channel pitches must be multiples of 8");
     MCGEN_CHECK(p->seg.ksize == 1 || p->seg.ksize == 3, "wgrad: ksize must be 1 or 3");
+    MCGEN_CHECK(p->seg.group_n == 0, "wgrad: BatchNorm statistics groups are a forward-only feature");
     MCGEN_CHECK(p->Cout > 0 && p->Cout_w == round_up(p->Cout, 16) && p->Cdy >= p->Cout, "wgrad: bad Cout/Cout_w/Cdy");
     MCGEN_CHECK(p->splits >= 1 && p->splits <= 65535, "wgrad: bad splits");
     MCGEN_CHECK(!p->halves || (p->splits % 2 == 0 && (((long)p->N * p->H * p->W + WG_BM - 1) / WG_BM) % 2 == 0 && ((long)p->N * p->H * p->W) % (2 * WG_BM) == 0),

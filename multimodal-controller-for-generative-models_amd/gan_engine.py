@@ -86,24 +86,27 @@ class _BN:
 
 
 _PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
-_pending_counters: List[Tensor] = []
+_pending_counters: Dict[int, List[Tensor]] = {}
 
 
 def _flush_counters():
-    if _pending_counters:
-        torch._foreach_add_(_pending_counters, 1)
-        _pending_counters.clear()
+    for k, ts in _pending_counters.items():
+        if ts:
+            torch._foreach_add_(ts, k)
+    _pending_counters.clear()
 
 
-def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: bool, fold: int = 1) -> _BN:
+def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: bool, fold: int = 1, groups: int = 1) -> _BN:
+    """`groups` > 1: the batch is `groups` independent BatchNorm batches (`count` elements per channel each): the affine
+    comes back as [groups, C], the running statistics and num_batches_tracked advance `groups` times."""
     s = _BN()
     s.count = count
     if train:
         mom = 0.1 if bn.momentum is None else bn.momentum
         s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
-                                                           bn.running_var, mom, bn.eps, fold=fold)
+                                                           bn.running_var, mom, bn.eps, fold=fold, groups=groups)
         _bump(bn.running_mean); _bump(bn.running_var)
-        _pending_counters.append(bn.num_batches_tracked)      # bumped together at the end of the forward (one launch)
+        _pending_counters.setdefault(groups, []).append(bn.num_batches_tracked)   # bumped together at the end of the forward
     else:
         s.scale, s.shift = ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         s.mean, s.rstd = None, None
@@ -198,14 +201,38 @@ class GeneratorEngine:
         self._prep_bwd.run()
 
     # ---- forward ---------------------------------------------------------------------------------
-    def forward(self, z: Tensor, indicator: Tensor, train: bool):
+    def groups_supported(self, n_total: int, groups: int) -> bool:
+        """Can `groups` training-mode forwards of n_total / groups images each run as ONE pass?  Every launch's tile
+        must lie inside one statistics group: the tiles of the Linear layer and of the 4x4 maps hold several images."""
+        if groups <= 1:
+            return True
+        if n_total % groups:
+            return False
+        gn = n_total // groups
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        shapes = [(1, lin.out_features)]                                      # (map side, output channels) per launch
+        side = 4
+        for b in res:
+            side *= 2
+            shapes += [(side, b.conv[4].module.out_channels)] * 2
+        shapes.append((side, head_conv.out_channels))
+        return all(gn % ops.tile_images(n_total, sd, sd, co, self.dtype) == 0 for sd, co in shapes)
+
+    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1):
+        """`groups` > 1 (training mode, forward only): z / indicator hold `groups` batches back to back, each normalised
+        with its OWN BatchNorm batch statistics -- `groups` successive generator forwards on unchanged weights
+        (the five discriminator updates of train_gan.py:139-158) as one pass over groups * N images."""
         self.flat_p.ensure()
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype
         n = z.shape[0]
+        if groups > 1 and not (train and self.groups_supported(n, groups)):
+            raise RuntimeError(f'generator forward: {groups} statistics groups over {n} images is not supported')
+        gn = n // groups if groups > 1 else 0          # images per statistics group (0: one batch)
+        ng = n // groups                               # BatchNorm batch size
         self.refresh_images()
         st_mode = 1 if train else 0
-        ctx = {'train': train, 'n': n}
+        ctx = {'train': train, 'n': n, 'groups': groups}
         zt = ops.to_nhwc(z.detach().reshape(n, -1, 1, 1), dt)                 # [N,1,1,L]
         c0 = lin.out_features // 16
         x0, st = ops.conv_fused([Seg(zt, ksize=1)], self.img['lin'], 16 * c0, bias=self.img['lin_bias'],
@@ -218,22 +245,22 @@ class GeneratorEngine:
         for i, b in enumerate(res):
             s = x.shape[1]
             code1, code2 = codes[2 * i], codes[2 * i + 1]
-            bn1 = _bn_forward(b.conv[0].module, st, n * s * s, train, fold)
+            bn1 = _bn_forward(b.conv[0].module, st, ng * s * s, train, fold, groups)
             fold = 1
             co = b.conv[4].module.out_channels
-            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
+            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True, group_n=gn)
             h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1'], co, bias=b.conv[4].module.bias, stats_mode=st_mode)
-            bn2 = _bn_forward(b.conv[5].module, st_h, n * 4 * s * s, train)
-            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
+            bn2 = _bn_forward(b.conv[5].module, st_h, ng * 4 * s * s, train, 1, groups)
+            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)
             seg_s = Seg(x, ksize=1, code=code1, ups=True)
             y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],
                                    stats_mode=st_mode)
             blocks_ctx.append(dict(x=x, h=h, code1=code1, code2=code2, bn1=bn1, bn2=bn2))
             x = y
         s = x.shape[1]
-        bnh = _bn_forward(head_bn, st, n * s * s, train, fold)
+        bnh = _bn_forward(head_bn, st, ng * s * s, train, fold, groups)
         codeh = codes[-1]
-        seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
+        seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True, group_n=gn)
         out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
         _flush_counters()
@@ -245,6 +272,8 @@ class GeneratorEngine:
         `gflat`, a flat fp32 buffer laid out like ``flat_p``."""
         if not ctx['train']:
             raise RuntimeError('generator backward needs a training-mode forward (batch statistics)')
+        if ctx.get('groups', 1) != 1:
+            raise RuntimeError('a grouped generator pass is forward-only (its images feed discriminator updates detached)')
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype
         n = ctx['n']

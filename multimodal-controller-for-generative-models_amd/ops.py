@@ -142,12 +142,18 @@ class Seg:
     code: Optional[Tensor] = None   # [N, C] MC code
     ups: bool = False
     relu: bool = False
+    group_n: int = 0                # > 0: scale / shift are [N // group_n, C], one BatchNorm batch per group_n images
 
     def fill(self, s: _lib.Seg):
         s.x = _p(self.x)
         s.scale, s.shift, s.code = _f32(self.scale), _f32(self.shift), _f32(self.code)
         s.C = self.x.shape[-1]
         s.ups, s.relu, s.ksize = int(self.ups), int(self.relu), self.ksize
+        s.group_n = int(self.group_n)
+        if self.group_n and self.scale is not None:
+            g = self.x.shape[0] // self.group_n
+            if self.x.shape[0] % self.group_n or tuple(self.scale.shape) != (g, s.C) or tuple(self.shift.shape) != (g, s.C):
+                raise _lib.McgenError(f'grouped BatchNorm affine must be {(g, s.C)}, got {tuple(self.scale.shape)}')
         if self.code is not None and tuple(self.code.shape) != (self.x.shape[0], self.x.shape[-1]):
             raise _lib.McgenError(f'code shape {tuple(self.code.shape)} does not match x {tuple(self.x.shape)}')
 
@@ -188,6 +194,16 @@ def mc_apply(x: Tensor, code: Tensor, channels_last: bool = True) -> Tensor:
     y = torch.empty_like(x)
     check(_lib.load().mcgen_mc_apply(_p(x), _f32(code), _p(y), _dt(x.dtype), n, hw, c, int(channels_last), _stream()), 'mc_apply')
     return y
+
+
+def tile_images(n: int, h: int, w: int, cout: int, dtype: torch.dtype) -> int:
+    """Images per output tile of a fused convolution over an [n, h, w] map with `cout` output channels, as the
+    launcher's tile policy picks it (1 when a tile lies inside one image)."""
+    p = _lib.Conv()
+    p.nseg, p.N, p.H, p.W, p.Cout, p.Cout_w = 1, n, h, w, cout, pad16(cout)
+    bm, bn = C.c_int(), C.c_int()
+    check(_lib.load().mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn)), 'conv_tile')
+    return max(1, bm.value // (h * w))
 
 
 def weight_image_elems(cout: int, cin: int, ksize: int, transpose: bool = False) -> int:
@@ -418,15 +434,18 @@ class deferred_reduces:
 
 def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
                 running_mean: Optional[Tensor], running_var: Optional[Tensor],
-                momentum: float = 0.1, eps: float = 1e-5, fold: int = 1):
-    """-> (scale, shift, mean, rstd), each [C]; running stats updated in place."""
+                momentum: float = 0.1, eps: float = 1e-5, fold: int = 1, groups: int = 1):
+    """-> (scale, shift, mean, rstd), each [C] ([groups, C] for groups > 1: `count` is per group and the running stats
+    take the groups' momentum updates in order); running stats updated in place."""
     tiles, _, pitch = partials.shape
     c = gamma.numel()
-    out = torch.empty((4, c), dtype=torch.float32, device=partials.device)
-    check(_lib.load().mcgen_bn_finalize(_f32(partials), tiles, pitch, fold, c, float(count), _f32(gamma), _f32(beta),
-                                        _f32(running_mean), _f32(running_var), momentum, eps,
-                                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-                                        _stream()), 'bn_finalize')
+    out = torch.empty((4, groups, c), dtype=torch.float32, device=partials.device)
+    check(_lib.load().mcgen_bn_finalize_groups(_f32(partials), tiles, pitch, fold, c, float(count), groups, _f32(gamma), _f32(beta),
+                                               _f32(running_mean), _f32(running_var), momentum, eps,
+                                               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                               _stream()), 'bn_finalize')
+    if groups == 1:
+        out = out.view(4, c)
     return out[0], out[1], out[2], out[3]
 
 

@@ -30,6 +30,7 @@ _CAPTURE_MODE = 'thread_local'
 
 import os as _os
 _PAIR_D = _os.environ.get('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
+_GROUP_G = _os.environ.get('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
 
 
 class FusedAdam:
@@ -118,14 +119,29 @@ class GANTrainer:
             from .dist import allreduce_mean_
             allreduce_mean_(g, self.world, self.group)
 
+    # ---- the generator passes of the discriminator updates -----------------------------------------
+    def fake_groups(self, n: int) -> int:
+        """How many of the d_iters generator forwards of an iteration run as ONE pass.  The generator's weights do not
+        change between the discriminator updates (train_gan.py:139-158), so G(z_1) ... G(z_5) is one forward over
+        5 N images with BatchNorm statistics kept per N-image group (GeneratorEngine.forward, groups): the 4x4 / 8x8 /
+        16x16 layers see five times the pixels per launch.  1 when the batch is too small for a tile to stay inside one
+        group (then each update runs its own forward, as the reference does)."""
+        if _GROUP_G and self.d_iters > 1 and self.geng.groups_supported(n * self.d_iters, self.d_iters):
+            return self.d_iters
+        return 1
+
+    def g_fakes(self, ind_rep, z_cat, groups: int):
+        """Training-mode generator forward(s) for `groups` discriminator updates: [groups * N, C, H, W], detached."""
+        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups)
+        return fake
+
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
-    def d_compute(self, img, ind, z, ind2=None):
-        """`ind2` (optional): the indicator twice, [2N, modes] -- constant over the D updates of an iteration, so the caller
-        builds it once instead of one concatenation per update."""
+    def d_compute(self, img, ind, fake, ind2=None):
+        """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
+        [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once."""
         if _PAIR_D:
             # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
             # power iterations of the two reference forwards depend on the weights alone and run first, in order
-            fake, _ = self.geng.forward(z, ind, True)
             logits, ctx = self.deng.forward_pair(img, fake, ind, ind2)
             n = img.shape[0]
             lg = logits.view(-1)
@@ -133,7 +149,6 @@ class GANTrainer:
             self.deng.backward(ctx, dboth, self.grad_d, False, False)
             return loss
         d_real, ctx_r = self.deng.forward(img, ind, True)
-        fake, _ = self.geng.forward(z, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
         loss, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
@@ -155,8 +170,8 @@ class GANTrainer:
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
 
-    def d_update(self, img, ind, z, ind2=None):
-        loss = self.d_compute(img, ind, z, ind2)
+    def d_update(self, img, ind, fake, ind2=None):
+        loss = self.d_compute(img, ind, fake, ind2)
         self._allreduce(self.grad_d)
         self.d_apply()
         return loss
@@ -178,8 +193,15 @@ class GANTrainer:
         zi = iter(zs) if zs is not None else None
         draw = (lambda: next(zi)) if zi is not None else (lambda: torch.randn(n, self.latent, device=img.device))
         d_loss = g_loss = None
-        for _ in range(self.d_iters):
-            d_loss = self.d_update(img, ind, draw(), ind2)
+        fg = self.fake_groups(n)
+        ind_rep = ind.repeat(fg, 1) if fg > 1 else ind
+        fakes = None
+        for k in range(self.d_iters):
+            if k % fg == 0:
+                z_cat = torch.cat([draw() for _ in range(fg)]) if fg > 1 else draw()
+                fakes = self.g_fakes(ind_rep, z_cat, fg)
+            j = k % fg
+            d_loss = self.d_update(img, ind, fakes[j * n:(j + 1) * n], ind2)
         for _ in range(self.g_iters):
             g_loss = self.g_update(ind, draw())
         return d_loss, g_loss
@@ -219,28 +241,39 @@ class GraphedGANTrainer(GANTrainer):
     def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 1):
         n = img.shape[0]
         dev = img.device
+        fg = self.fake_groups(n)
+        self._fg = fg
         self.s_img = img.clone()
         self.s_ind2 = F.one_hot(label, self.classes).float().repeat(2, 1)
         self.s_ind = self.s_ind2[:n]
-        self.s_z = torch.randn(n, self.latent, device=dev)
+        self.s_indg = self.s_ind.repeat(fg, 1) if fg > 1 else self.s_ind     # indicator of the generator pass(es)
+        self.s_z = torch.randn(n, self.latent, device=dev)                  # latent of the generator update
+        self.s_zd = torch.randn(fg * n, self.latent, device=dev)            # latents of fg discriminator updates
+        self.s_fake = torch.empty_like(self.s_img)                          # the generated batch of the current D update
         self.model.train(True)
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                self.d_update(self.s_img, self.s_ind, self.s_z, self.s_ind2)
+                fakes = self.g_fakes(self.s_indg, self.s_zd, fg)
+                self.s_fake.copy_(fakes[:n])
+                self.d_update(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
                 self.g_update(self.s_ind, self.s_z)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._restore(snap)
         torch.cuda.synchronize()
-        self.g_z = torch.cuda.CUDAGraph()
-        self.g_dc, self.g_da = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self.g_gc, self.g_ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_dc, capture_error_mode=_CAPTURE_MODE):
-            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_z, self.s_ind2)
-        pool = self.g_dc.pool()
+        G = torch.cuda.CUDAGraph
+        self.g_zd, self.g_gf, self.g_z = G(), G(), G()
+        self.g_dc, self.g_da, self.g_gc, self.g_ga = G(), G(), G(), G()
+        with torch.cuda.graph(self.g_gf, capture_error_mode=_CAPTURE_MODE):
+            self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg)
+        pool = self.g_gf.pool()
+        with torch.cuda.graph(self.g_dc, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
+        with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            self.s_zd.normal_()
         with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
         with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
@@ -260,22 +293,28 @@ class GraphedGANTrainer(GANTrainer):
             return super().train_iteration(img, label, zs)
         self.s_img.copy_(img, non_blocking=True)
         oh = F.one_hot(label, self.classes).float()
-        n = oh.shape[0]
+        n, fg = oh.shape[0], self._fg
         self.s_ind2[:n].copy_(oh, non_blocking=True); self.s_ind2[n:].copy_(oh, non_blocking=True)
+        if fg > 1:
+            self.s_indg.view(fg, n, -1).copy_(oh.unsqueeze(0).expand(fg, -1, -1), non_blocking=True)
         zi = iter(zs) if zs is not None else None
-
-        def latent():
-            if zi is None:
-                self.g_z.replay()
-            else:
-                self.s_z.copy_(next(zi), non_blocking=True)
-        for _ in range(self.d_iters):
-            latent()
+        for k in range(self.d_iters):
+            if k % fg == 0:
+                if zi is None:
+                    self.g_zd.replay()
+                else:
+                    self.s_zd.copy_(torch.cat([next(zi) for _ in range(fg)]) if fg > 1 else next(zi), non_blocking=True)
+                self.g_gf.replay()
+            j = k % fg
+            self.s_fake.copy_(self.s_fakes[j * n:(j + 1) * n], non_blocking=True)
             self.g_dc.replay()
             self._allreduce(self.grad_d)
             self.g_da.replay()
         for _ in range(self.g_iters):
-            latent()
+            if zi is None:
+                self.g_z.replay()
+            else:
+                self.s_z.copy_(next(zi), non_blocking=True)
             self.g_gc.replay()
             self._allreduce(self.grad_g)
             self.g_ga.replay()

@@ -1,7 +1,8 @@
 """Rehearsal of bench.py's N>1 path on ONE card: two ranks under torch.distributed.run share cuda:0 and exchange
 gradients through gloo (MCGEN_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  Checks the launch
 contract (env rendezvous on 127.0.0.1, graph capture with a live process group, all-reduce between replays,
-max-over-ranks timing, one JSON line from rank 0) -- not performance."""
+max-over-ranks timing, the collective-free roofline pass on rank 0 while the other rank waits at the final barrier,
+one JSON line from rank 0) -- not performance."""
 import json
 import os
 import subprocess
@@ -18,7 +19,7 @@ def test_bench_two_ranks_one_card(workload):
     env = dict(os.environ, MCGEN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', workload, '--steps', '2',
-           '--warmup', '1', '--no-roofline', '--batch', '16']
+           '--warmup', '1', '--batch', '16', '--sustain-steps', '0']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -664,3 +664,46 @@ def test_big_wgrad_two_halves_bf16():
     _assert_close(g2, refs[1], dtype, 'second half')
     _assert_close(b1, dyf[:n // 2].sum((0, 2, 3)), dtype, 'first half bias')
     _assert_close(b2, dyf[n // 2:].sum((0, 2, 3)), dtype, 'second half bias')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_grouped_batchnorm_pass_equals_separate_passes(dtype):
+    """mcgen_seg_t.group_n + mcgen_bn_finalize_groups: two training-mode BatchNorm batches pushed through
+    conv -> BN -> ReLU -> MC -> conv as ONE pass (statistics per group, running statistics updated group by group) give
+    bit-for-bit what two separate passes give -- the tiles, and so every partial sum, are the same."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(811)
+    n, gn, c, hw = 8, 4, 32, 8
+    x = _rnd(g, n, c, hw, hw)
+    w1, w2, b1 = _rnd(g, c, c, 3, 3) * 0.1, _rnd(g, c, c, 3, 3) * 0.1, _rnd(g, c)
+    gamma, beta = _rnd(g, c) * 0.2 + 1, _rnd(g, c) * 0.1
+    code = (torch.rand(n, c, generator=g) < 0.5).float().cuda()
+    i1, i2 = ops.prep_weight(w1.cuda(), dtype), ops.prep_weight(w2.cuda(), dtype)
+    xt = _nhwc(ops, x, dtype)
+
+    def run(xs, cd, rm, rv, groups):
+        nn_ = xs.shape[0]
+        h, st = ops.conv_fused([ops.Seg(xs)], i1, c, bias=b1.cuda(), stats_mode=1)
+        sc, sh, mean, rstd = ops.bn_finalize(st, (nn_ // groups) * hw * hw, gamma.cuda(), beta.cuda(), rm, rv, groups=groups)
+        seg = ops.Seg(h, scale=sc, shift=sh, code=cd, relu=True, group_n=(nn_ // groups if groups > 1 else 0))
+        y, _ = ops.conv_fused([seg], i2, c)
+        return y, sc, sh, mean, rstd
+
+    rm_a, rv_a = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    y_a, sc_a, sh_a, mean_a, rstd_a = run(xt, code, rm_a, rv_a, 2)
+    assert sc_a.shape == (2, c)
+    rm_b, rv_b = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    parts = [run(xt[i * gn:(i + 1) * gn].contiguous(), code[i * gn:(i + 1) * gn].contiguous(), rm_b, rv_b, 1) for i in range(2)]
+    assert torch.equal(y_a, torch.cat([p[0] for p in parts]))
+    for j, t in enumerate((sc_a, sh_a, mean_a, rstd_a), start=1):
+        assert torch.equal(t, torch.stack([p[j] for p in parts])), j
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    # and against the definition: per-group batch statistics of the first convolution's output
+    h_ref = F.conv2d(_q(x, dtype), _q(w1, dtype), b1, padding=1).view(2, gn, c, hw, hw)
+    np.testing.assert_allclose(mean_a.cpu(), h_ref.mean((1, 3, 4)), rtol=2e-3 if dtype == torch.float32 else 3e-2, atol=2e-3 if dtype == torch.float32 else 3e-2)
+    # a tile that would straddle two groups is refused before launch
+    from mcgen_amd import _lib
+    z = ops.to_nhwc(_rnd(g, 8, 16, 1, 1).cuda(), dtype)                      # 1x1 maps: 64 images per tile
+    sc1 = torch.ones(2, 16, device='cuda')
+    with pytest.raises(_lib.McgenError):
+        ops.conv_fused([ops.Seg(z, ksize=1, scale=sc1, shift=sc1, group_n=4)], ops.prep_weight((_rnd(g, 32, 16, 1, 1)).cuda(), dtype), 32)

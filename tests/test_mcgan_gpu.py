@@ -381,3 +381,45 @@ def test_gradients_vs_oracle(fixture, g_hidden, d_hidden, classes, data_name):
     (-m.discriminate(m.generate(lab.cuda(), z.cuda()), lab.cuda()).mean()).backward()
     got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     check(got, {k: v for k, v in ref.items()}, 'G-step')
+
+
+def test_grouped_generator_passes_match_per_update_passes():
+    """GANTrainer runs the five training-mode generator forwards of an iteration (train_gan.py:145-146, one per
+    discriminator update, on unchanged generator weights) as ONE pass over 5 N images with BatchNorm statistics per
+    N-image group.  Against the per-update schedule on the same state, latents and batch (N = 128, reduced width):
+    same losses, same generator BatchNorm running statistics / num_batches_tracked, same discriminator weights --
+    in the eager trainer and through graph replay."""
+    from mcgen_amd import trainer as T
+    d = gu.load_npz('mcgan_small.npz')
+    sd0 = gu.state_from_npz(d)
+    n = 128
+    img, lab = gu.synthetic_batch(n, 10, seed=3)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(6, n, 128, seed=4)]
+
+    def run(grouped, graphed):
+        old = T._GROUP_G
+        T._GROUP_G = grouped
+        try:
+            m = _build([32] * 4, [16] * 4, 10, 'CIFAR10', sd0)
+            tr = T.GraphedGANTrainer(m, 10) if graphed else T.GANTrainer(m, 10)
+            assert tr.fake_groups(n) == (5 if grouped else 1)
+            if graphed:
+                tr.capture(img, lab)
+            dl, gl = tr.train_iteration(img, lab, zs)
+            return (float(dl), float(gl)), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        finally:
+            T._GROUP_G = old
+
+    (ref_l, ref_sd) = run(False, False)
+    for grouped, graphed in ((True, False), (True, True)):
+        l, sd = run(grouped, graphed)
+        np.testing.assert_allclose(l, ref_l, rtol=0, atol=2e-5, err_msg=f'grouped={grouped} graphed={graphed}')
+        for k, v in ref_sd.items():
+            if v.dtype == torch.int64:
+                assert int(sd[k]) == int(v), k                                 # num_batches_tracked: 6 per BatchNorm
+            elif 'generator' in k and k.endswith(('running_mean', 'running_var')):
+                assert float((sd[k] - v).abs().max()) <= 1e-5 * (1 + float(v.abs().max())), k
+            elif k.startswith('discriminator.'):
+                assert float((sd[k] - v).abs().max()) <= 5e-4 * float(v.abs().max()) + 1e-5, k
+    assert int(ref_sd['generator.blocks.0.conv.0.module.num_batches_tracked']) == 6

@@ -212,21 +212,25 @@ def test_mcglow_two_training_steps_vs_reference():
 
 
 def test_mcglow_graphed_trainer_tracks_eager():
-    """HIP-graph replay of the train step against the eager path: same data, independent dequantisation
-    noise (the graph draws its own), so losses agree to the noise's effect (< 2e-3 bits/dim here)."""
+    """HIP-graph replay of the train step, pinned: capture leaves the weights untouched, and replays with the
+    fixture's dequantisation noise injected reproduce the reference's two logged losses and the eager trainer's."""
     from mcgen_amd.trainer import GlowTrainer
     d = gu.load_npz('mcglow_small.npz')
     img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
-    ma, mb = _model(gu.state_from_npz(d, 'sd_init/')), _model(gu.state_from_npz(d, 'sd_init/'))
+    init = gu.state_from_npz(d, 'sd_init/')
+    ma, mb = _model(init), _model(init)
     ta, tb = GlowTrainer(ma), GlowTrainer(mb)
-    # capture runs warm-up iterations that update the weights; give the eager trainer the same number of steps
     tb.capture(img, lab, warmup=1)
-    ta.train_iteration(img, lab)
-    la = [float(ta.train_iteration(img, lab)) for _ in range(3)]
-    lb = [float(tb.train_iteration(img, lab)) for _ in range(3)]
-    assert all(np.isfinite(la)) and all(np.isfinite(lb))
-    assert la[-1] < la[0] and lb[-1] < lb[0]
-    assert max(abs(x - y) for x, y in zip(la, lb)) < 5e-3, (la, lb)
+    for k, v in mb.state_dict().items():
+        assert torch.equal(v.cpu(), init[k]), k
+    noise = [torch.from_numpy(d[f'noise/{s}/0']).cuda() for s in range(2)]
+    la = [float(ta.train_iteration(img, lab, noise[s])) for s in range(2)]
+    lb = [float(tb.train_iteration(img, lab, noise[s])) for s in range(2)]
+    assert abs(lb[0] - d['losses'][0]) < 1e-4 and abs(lb[1] - d['losses'][1]) < 5e-4, (lb, d['losses'])
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 1e-5, (la, lb)
+    # without injected noise the graph draws its own
+    lc = [float(tb.train_iteration(img, lab)) for _ in range(2)]
+    assert all(np.isfinite(lc))
 
 
 def test_mcglow_bf16_tracks_fp32():
