@@ -227,6 +227,14 @@ typedef struct { int64_t w_off, u_off, v_off; int32_t rows, cols; } mcgen_sn_lay
 int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                         int do_iter, float* sigma, float* workspace /* nlayers * (32*max_cols + max_rows) floats */,
                         int max_rows, int max_cols, void* stream);
+/* `rounds` successive power iterations of every layer in ONE launch (one workgroup per layer; u, v, W v stay in LDS):
+ * sigma[r][l] and -- when uv_snap != NULL -- the whole u/v buffer as it stands after round r (uv_snap[r][uv_total]:
+ * torch's hook clones u, v for the backward, torch/nn/utils/spectral_norm.py) are written per round; uv_base holds the
+ * final state.  do_iter = 0 (evaluation mode): one round, sigma = u . (W v), nothing is updated.  The two
+ * training-mode forwards of a discriminator update (train_gan.py:144-150) are rounds = 2. */
+int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                              int rounds, int do_iter, float* sigma, float* uv_snap, int64_t uv_total,
+                              int max_rows, int max_cols, void* stream);
 /* gradient through W/sigma:  dst (+)= (g - <g, W/sigma> u v^T) / sigma per layer, where g (at g_src + w_off)
  * is the gradient w.r.t. the normalised weight; u, v, sigma are the values the FORWARD used (the caller
  * keeps a snapshot per forward, as torch's hook does by cloning u and v). g_src may equal g_dst.

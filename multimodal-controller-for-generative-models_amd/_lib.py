@@ -122,6 +122,7 @@ SYMBOLS = {
     'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),
     'mcgen_colsum': (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    'mcgen_sn_power_iter_fused': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i, _i, _vp]),
     'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

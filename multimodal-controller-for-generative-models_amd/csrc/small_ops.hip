@@ -384,6 +384,76 @@ __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
     } else if (threadIdx.x == 0) sigma[blockIdx.x] = a;
 }
 
+// ---- fused power iteration: ONE launch for `rounds` successive iterations over all layers ------------------------
+// One 1024-thread workgroup per layer keeps u, v and t = W v in LDS and streams W (L2-resident: the largest layer of
+// the headline model is 128 x 1152 floats) twice per round:  v <- normalize(W^T u);  t = W v;  u <- normalize(t);
+// sigma = u . t  (torch.nn.utils.spectral_norm's power iteration, models/utils.py:17-21).  After every round sigma and
+// (optionally) a snapshot of u, v go out, so the two training-mode forwards of a discriminator update (D(real), then
+// D(fake): train_gan.py:144-150) cost one launch instead of eight, and the snapshot copies disappear.
+constexpr int SNU_T = 1024;
+__global__ __launch_bounds__(SNU_T)
+void sn_fused_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer_t* __restrict__ layers, int nlayers,
+                     int rounds, int do_iter, float* __restrict__ sigma, float* __restrict__ uv_snap, long uv_total,
+                     int max_rows, int max_cols) {
+    extern __shared__ float sm[];
+    float* sv = sm; float* su = sm + max_cols; float* st = su + max_rows; float* red = st + max_rows;
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* W = wb + L.w_off;
+    float* ug = uvb + L.u_off; float* vg = uvb + L.v_off;
+    const int rows = L.rows, cols = L.cols, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = SNU_T >> 6;
+    for (int i = tid; i < rows; i += SNU_T) su[i] = ug[i];
+    if (!do_iter) for (int j = tid; j < cols; j += SNU_T) sv[j] = vg[j];
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        if (do_iter) {
+            float nn = 0.f;
+            for (int j = tid; j < cols; j += SNU_T) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int i = 0;
+                for (; i + 4 <= rows; i += 4) {
+                    a0 = fmaf(W[(size_t)(i + 0) * cols + j], su[i + 0], a0);
+                    a1 = fmaf(W[(size_t)(i + 1) * cols + j], su[i + 1], a1);
+                    a2 = fmaf(W[(size_t)(i + 2) * cols + j], su[i + 2], a2);
+                    a3 = fmaf(W[(size_t)(i + 3) * cols + j], su[i + 3], a3);
+                }
+                for (; i < rows; ++i) a0 = fmaf(W[(size_t)i * cols + j], su[i], a0);
+                const float s = (a0 + a1) + (a2 + a3);
+                sv[j] = s; nn += s * s;
+            }
+            nn = block_sum(nn, red);
+            const float inv = 1.f / fmaxf(sqrtf(nn), 1e-12f);
+            for (int j = tid; j < cols; j += SNU_T) sv[j] *= inv;
+            __syncthreads();
+        }
+        for (int i = wave; i < rows; i += nw) {
+            float s = 0.f;
+            for (int j = lane; j < cols; j += 64) s = fmaf(W[(size_t)i * cols + j], sv[j], s);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) st[i] = s;
+        }
+        __syncthreads();
+        float a = 0.f;
+        for (int i = tid; i < rows; i += SNU_T) a += do_iter ? st[i] * st[i] : su[i] * st[i];
+        a = block_sum(a, red);
+        if (do_iter) {
+            const float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
+            for (int i = tid; i < rows; i += SNU_T) su[i] = st[i] * inv;
+            if (tid == 0) sigma[(size_t)r * nlayers + blockIdx.x] = a * inv;
+        } else if (tid == 0) sigma[(size_t)r * nlayers + blockIdx.x] = a;
+        __syncthreads();
+        if (uv_snap) {
+            float* snap = uv_snap + (size_t)r * uv_total;
+            for (int i = tid; i < rows; i += SNU_T) snap[L.u_off + i] = su[i];
+            for (int j = tid; j < cols; j += SNU_T) snap[L.v_off + j] = sv[j];
+        }
+    }
+    if (do_iter) {
+        for (int i = tid; i < rows; i += SNU_T) ug[i] = su[i];
+        for (int j = tid; j < cols; j += SNU_T) vg[j] = sv[j];
+    }
+}
+
 constexpr int SNF_CHUNKS = 32;
 // pass 1: partial <G, W> per (layer, chunk)
 __global__ void sn_grad_dot_kernel(const float* __restrict__ gsrc, const float* __restrict__ wb,
@@ -443,6 +513,42 @@ __global__ void dtail_fwd_kernel(const T* __restrict__ x, const float* __restric
         s *= code ? code[(size_t)n * C + c] : 1.f;
         pooled[(size_t)n * C + c] = s;
         part = fmaf(s, w[c] / sigma[0], part);
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) logit[n] = part + b[0];
+}
+// Vector form (C % 8 == 0, C <= 2048): thread = (8-channel group, pixel lane); every thread sums its pixels with 16-byte
+// loads, the pixel lanes are combined through LDS in a fixed order, then one thread per channel finishes.
+template <typename T>
+__global__ __launch_bounds__(256)
+void dtail_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ code, const float* __restrict__ w,
+                          const float* __restrict__ b, const float* __restrict__ sigma, float* pooled, float* logit,
+                          int HW, int C) {
+    extern __shared__ float acc[];                       // [pixel lanes][C]
+    __shared__ float red[32];
+    const int n = blockIdx.x, cv = C / 8, pl = 256 / cv;
+    const int g = threadIdx.x % cv, lanep = threadIdx.x / cv;
+    if (lanep < pl) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int p = lanep; p < HW; p += pl) {
+            float v[8];
+            Elem<T>::load8(x + ((size_t)n * HW + p) * C + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += fmaxf(v[i], 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[lanep * C + g * 8 + i] = s[i];
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int l = 0; l < pl; ++l) t += acc[l * C + c];
+        t *= code ? code[(size_t)n * C + c] : 1.f;
+        pooled[(size_t)n * C + c] = t;
+        part = fmaf(t, w[c] / sigma[0], part);
     }
     part = block_sum(part, red);
     if (threadIdx.x == 0) logit[n] = part + b[0];
@@ -723,6 +829,18 @@ extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mc
     hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, do_iter, sigma);
     MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
 }
+extern "C" int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                         int rounds, int do_iter, float* sigma, float* uv_snap, int64_t uv_total,
+                                         int max_rows, int max_cols, void* stream) {
+    MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && nlayers > 0 && rounds >= 1 && max_rows > 0 && max_cols > 0,
+                "sn_power_iter_fused: bad arguments");
+    MCGEN_CHECK(do_iter || rounds == 1, "sn_power_iter_fused: an evaluation-mode call is one round");
+    const size_t lds = (size_t)(max_cols + 2 * max_rows + 32) * sizeof(float);
+    MCGEN_CHECK(lds <= 64 * 1024, "sn_power_iter_fused: layer of %d x %d does not fit the LDS plan", max_rows, max_cols);
+    hipLaunchKernelGGL(sn_fused_kernel, dim3(nlayers), dim3(SNU_T), lds, STREAM(stream), w_base, uv_base, layers_dev, nlayers, rounds,
+                       do_iter, sigma, uv_snap, (long)uv_total, max_rows, max_cols);
+    MCGEN_LAUNCH_CHECK("sn_power_iter_fused"); return 0;
+}
 extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
                                  const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate,
                                  float* workspace, void* stream) {
@@ -736,6 +854,14 @@ extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* 
 extern "C" int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b, const float* sigma,
                                float* pooled, float* logit, int N, int HW, int C, void* stream) {
     MCGEN_CHECK(x && w && b && sigma && pooled && logit, "dtail_fwd: null pointer");
+    if (C % 8 == 0 && C / 8 <= 256) {
+        const int pl = 256 / (C / 8);
+        const size_t lds = (size_t)pl * C * sizeof(float);            // <= 256 * 8 floats per lane row: 8 KB
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(dtail_fwd_vec_kernel<float>, dim3(N), dim3(256), lds, STREAM(stream), (const float*)x, code, w, b, sigma, pooled, logit, HW, C),
+            hipLaunchKernelGGL(dtail_fwd_vec_kernel<bf16_t>, dim3(N), dim3(256), lds, STREAM(stream), (const bf16_t*)x, code, w, b, sigma, pooled, logit, HW, C));
+        MCGEN_LAUNCH_CHECK("dtail_fwd"); return 0;
+    }
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(dtail_fwd_kernel<float>, dim3(N), dim3(128), 0, STREAM(stream), (const float*)x, code, w, b, sigma, pooled, logit, HW, C),
         hipLaunchKernelGGL(dtail_fwd_kernel<bf16_t>, dim3(N), dim3(128), 0, STREAM(stream), (const bf16_t*)x, code, w, b, sigma, pooled, logit, HW, C));

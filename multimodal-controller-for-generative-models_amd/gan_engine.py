@@ -270,6 +270,18 @@ class GeneratorEngine:
     def backward(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
         """dimg: [N, C, H, W] fp32.  Writes (or adds) every generator parameter's gradient into
         `gflat`, a flat fp32 buffer laid out like ``flat_p``."""
+        for _ in self.backward_iter(ctx, dimg, gflat, accumulate):
+            pass
+
+    def bucket_cut(self) -> int:
+        """First residual block of the LATE gradient bucket (see DiscriminatorEngine.bucket_cut): the backward pass
+        finishes the head and blocks cut .. last first."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        return max(1, len(res) // 2) if len(res) > 1 else 0
+
+    def backward_iter(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
+        """As `backward`, as a generator: yields (lo, hi) each time gflat[lo:hi] is final -- the head and the late
+        blocks mid-pass, the early blocks and the Linear layer at the end."""
         if not ctx['train']:
             raise RuntimeError('generator backward needs a training-mode forward (batch statistics)')
         if ctx.get('groups', 1) != 1:
@@ -278,57 +290,67 @@ class GeneratorEngine:
         dt = self.dtype
         n = ctx['n']
         acc = accumulate
-        G = lambda p: self.flat_p.view_of(gflat, p)                           # noqa: E731
         out = ctx['out']
         self._prep_backward_images()
         dout = ops.to_nhwc(dimg.contiguous(), dt, out.shape[-1])
         dtn = ops.tanh_bwd(dout, out)
         y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
         c_img, c = head_conv.out_channels, head_conv.in_channels
-        with ops.deferred_reduces():
-            self._backward_body(ctx, gflat, acc, dtn, y, bnh, codeh, c_img, c, lin, res, head_bn, head_conv, n)
-
-    def _backward_body(self, ctx, gflat, acc, dtn, y, bnh, codeh, c_img, c, lin, res, head_bn, head_conv, n):
+        cut = self.bucket_cut()
+        off_cut = self.flat_p.offset_of(next(p for p in res[cut].parameters())) if res else 0
         G = lambda p: self.flat_p.view_of(gflat, p)                           # noqa: E731
-        # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
-        seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
-        ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc, bias_grad=G(head_conv.bias))
-        wt = self.img_t['head']
-        dz, part = ops.conv_fused([Seg(dtn)], wt, c, ocode=codeh, gate_x=y, gscale=bnh.scale, gshift=bnh.shift,
-                                  gmean=bnh.mean, grstd=bnh.rstd, stats_mode=2)
-        dy = ops.bn_backward(part, dz, y, bnh.count, bnh.scale, bnh.mean, bnh.rstd,
-                             G(head_bn.weight), G(head_bn.bias), accumulate=acc)
-        for i in reversed(range(len(res))):
-            b, bc = res[i], ctx['blocks'][i]
-            x, h, code1, code2, bn1, bn2 = bc['x'], bc['h'], bc['code1'], bc['code2'], bc['bn1'], bc['bn2']
-            conv1, conv2, convs = b.conv[4].module, b.conv[8].module, b.shortcut[2].module
-            bnm1, bnm2 = b.conv[0].module, b.conv[5].module
-            ci, co = conv1.in_channels, conv1.out_channels
-            # second conv and the 1x1 shortcut both see dy
-            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
-            seg_s = Seg(x, ksize=1, code=code1, ups=True)
-            ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc, bias_grad=G(conv2.bias), bias_grad2=G(convs.bias))
-            ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
-            w2t = self.img_t[f'b{i}.w2']
-            dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
-                                        gmean=bn2.mean, grstd=bn2.rstd, stats_mode=2)
-            dh = ops.bn_backward(part2, dz2, h, bn2.count, bn2.scale, bn2.mean, bn2.rstd,
-                                 G(bnm2.weight), G(bnm2.bias), accumulate=acc)
-            # first conv: gradient goes through MC, the nearest-upsample adjoint (2x2 sum), ReLU, BN
-            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
-            ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc, bias_grad=G(conv1.bias))
-            wst = self.img_t[f'b{i}.ws']
-            dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
-            w1t = self.img_t[f'b{i}.w1']
-            dz1, part1 = ops.conv_fused([Seg(dh)], w1t, ci, pool=True, alpha=1.0, ocode=code1, gate_x=x,
-                                        gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)
-            dy = ops.bn_backward(part1, dz1, x, bn1.count, bn1.scale, bn1.mean, bn1.rstd,
-                                 G(bnm1.weight), G(bnm1.bias), add=dx_sc, accumulate=acc)
-        # linear layer: dy is [N,4,4,C0] == [N,1,1,16*C0] in the permuted row order
-        c0 = lin.out_features // 16
-        dflat = dy.view(n, 1, 1, 16 * c0)
-        ops.wgrad(Seg(ctx['zt'], ksize=1), dflat, 16 * c0, lin.in_features, G(lin.weight), row_perm=16, accumulate=acc,
-                  bias_grad=G(lin.bias))
+        red = ops.deferred_reduces()           # the split-K reductions of one bucket: one launch
+        red.__enter__()
+        try:
+            # head conv: bias / weight grads, then the input gradient through MC, ReLU and BN
+            seg_h = Seg(y, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True)
+            ops.wgrad(seg_h, dtn, c_img, c, G(head_conv.weight), accumulate=acc, bias_grad=G(head_conv.bias))
+            wt = self.img_t['head']
+            dz, part = ops.conv_fused([Seg(dtn)], wt, c, ocode=codeh, gate_x=y, gscale=bnh.scale, gshift=bnh.shift,
+                                      gmean=bnh.mean, grstd=bnh.rstd, stats_mode=2)
+            dy = ops.bn_backward(part, dz, y, bnh.count, bnh.scale, bnh.mean, bnh.rstd,
+                                 G(head_bn.weight), G(head_bn.bias), accumulate=acc)
+            for i in reversed(range(len(res))):
+                b, bc = res[i], ctx['blocks'][i]
+                x, h, code1, code2, bn1, bn2 = bc['x'], bc['h'], bc['code1'], bc['code2'], bc['bn1'], bc['bn2']
+                conv1, conv2, convs = b.conv[4].module, b.conv[8].module, b.shortcut[2].module
+                bnm1, bnm2 = b.conv[0].module, b.conv[5].module
+                ci, co = conv1.in_channels, conv1.out_channels
+                # second conv and the 1x1 shortcut both see dy
+                seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
+                seg_s = Seg(x, ksize=1, code=code1, ups=True)
+                ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc, bias_grad=G(conv2.bias), bias_grad2=G(convs.bias))
+                ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
+                w2t = self.img_t[f'b{i}.w2']
+                dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
+                                            gmean=bn2.mean, grstd=bn2.rstd, stats_mode=2)
+                dh = ops.bn_backward(part2, dz2, h, bn2.count, bn2.scale, bn2.mean, bn2.rstd,
+                                     G(bnm2.weight), G(bnm2.bias), accumulate=acc)
+                # first conv: gradient goes through MC, the nearest-upsample adjoint (2x2 sum), ReLU, BN
+                seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
+                ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc, bias_grad=G(conv1.bias))
+                wst = self.img_t[f'b{i}.ws']
+                dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
+                w1t = self.img_t[f'b{i}.w1']
+                dz1, part1 = ops.conv_fused([Seg(dh)], w1t, ci, pool=True, alpha=1.0, ocode=code1, gate_x=x,
+                                            gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)
+                dy = ops.bn_backward(part1, dz1, x, bn1.count, bn1.scale, bn1.mean, bn1.rstd,
+                                     G(bnm1.weight), G(bnm1.bias), add=dx_sc, accumulate=acc)
+                if i == cut and cut > 0:
+                    red.__exit__(None, None, None)           # head + blocks cut .. last are final
+                    yield (off_cut, gflat.numel())
+                    red = ops.deferred_reduces()
+                    red.__enter__()
+            # linear layer: dy is [N,4,4,C0] == [N,1,1,16*C0] in the permuted row order
+            c0 = lin.out_features // 16
+            dflat = dy.view(n, 1, 1, 16 * c0)
+            ops.wgrad(Seg(ctx['zt'], ksize=1), dflat, 16 * c0, lin.in_features, G(lin.weight), row_perm=16, accumulate=acc,
+                      bias_grad=G(lin.bias))
+        except BaseException as e:
+            red.__exit__(type(e), e, None)
+            raise
+        red.__exit__(None, None, None)
+        yield (0, off_cut if cut > 0 else gflat.numel())
 
 
 # ============================================================================================= #
@@ -438,16 +460,20 @@ class DiscriminatorEngine:
             self._build_preps()
 
     # ---- forward ---------------------------------------------------------------------------------
-    def _power_iter(self, train: bool):
+    def _power_iters(self, rounds: int, train: bool):
+        """`rounds` successive spectral-norm power iterations of every layer (one launch): [(sigma, u/v snapshot)] per
+        round -- torch's hook clones u, v for the backward pass, the snapshot is that clone."""
         fp, fuv = self._ensure_flat()
         nsn = len(self.sn)
-        sigma = torch.empty(nsn, dtype=torch.float32, device=fp.device)
-        ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sigma,
-                          max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
+        sigma, snap = ops.sn_power_iter_fused(fp, fuv, self._layers_dev, nsn, rounds, train,
+                                              max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
         if train:
             for s in self.sn:
                 _bump(s.m.weight_u); _bump(s.m.weight_v)
-        return sigma, fuv.clone()                              # torch's hook clones u, v too
+        return [(sigma[r], snap[r]) for r in range(rounds)]
+
+    def _power_iter(self, train: bool):
+        return self._power_iters(1, train)[0]
 
     def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
         sigma, uv = self._power_iter(train)
@@ -462,8 +488,7 @@ class DiscriminatorEngine:
         fake half runs on the first pass's weight images with sigma_1 / sigma_2 folded into its per-sample
         MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input)."""
         n = real_nchw.shape[0]
-        sigma1, uv1 = self._power_iter(True)
-        sigma2, uv2 = self._power_iter(True)
+        (sigma1, uv1), (sigma2, uv2) = self._power_iters(2, True)
         ratio = sigma1 / sigma2
         if ind2 is None:
             ind2 = torch.cat([indicator, indicator])
@@ -551,9 +576,49 @@ class DiscriminatorEngine:
 
     # ---- backward ----------------------------------------------------------------------------------
     def backward(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
+        """Runs `backward_iter` to its end; returns d(input image) as NCHW fp32, or None."""
+        it = self.backward_iter(ctx, dlogit, gflat, accumulate, need_input_grad)
+        while True:
+            try:
+                next(it)
+            except StopIteration as stop:
+                return stop.value
+
+    def bucket_cut(self) -> int:
+        """First residual block of the LATE gradient bucket: the backward pass finishes blocks cut .. last and the tail
+        first, so gflat[offset(block cut) :] is final while blocks cut-1 .. 0 are still running -- a data-parallel run
+        starts that bucket's all-reduce there (GANTrainer), under the rest of the backward."""
+        return max(1, len(self.res) // 2)
+
+    def _bucket_tables(self):
+        """Spectral-norm fix-up tables of the two buckets: SN layers with index >= the cut block's first layer + the plain
+        parameters stored behind the cut offset, and the rest."""
+        fp, _ = self._ensure_flat()
+        key = (self._layers_key, self.bucket_cut())
+        if getattr(self, '_bk_key', None) != key:
+            cut_block = self.res[self.bucket_cut()]
+            first = next(p for p in cut_block.parameters())
+            off_cut = self.flat_p.offset_of(first)
+            sn_hi = [sn for sn in self.sn if self.flat_p.offset_of(sn.m.weight_orig) >= off_cut]
+            i_cut = min(sn.idx for sn in sn_hi)
+            assert [sn.idx for sn in sn_hi] == list(range(i_cut, len(self.sn))), 'SN layers of the late bucket are not contiguous'
+
+            def table(sns, plains):
+                rows = [(self.flat_p.offset_of(sn.m.weight_orig), self.flat_uv.offset_of(sn.m.weight_u),
+                         self.flat_uv.offset_of(sn.m.weight_v), sn.m.weight_orig.shape[0], sn.m.weight_orig[0].numel()) for sn in sns]
+                rows += [(self.flat_p.offset_of(p), 0, 0, 0, p.numel()) for p in plains]
+                return ops.sn_layers_tensor(rows, fp.device), len(rows)
+            hi = table(sn_hi, [p for p in self.plain if self.flat_p.offset_of(p) >= off_cut])
+            lo = table([sn for sn in self.sn if sn.idx < i_cut], [p for p in self.plain if self.flat_p.offset_of(p) < off_cut])
+            self._bk = {'off_cut': off_cut, 'i_cut': i_cut, 'hi': hi, 'lo': lo}
+            self._bk_key = key
+        return self._bk
+
+    def backward_iter(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
         """dlogit [N] fp32.  Parameter gradients (w.r.t. weight_orig and the biases) are written or
         added into `gflat` (flat, laid out like ``flat_p``; None skips them, e.g. in the generator
-        step); returns d(input image) as NCHW fp32, or None.
+        step).  A generator: yields (lo, hi) each time gflat[lo:hi] is final -- the late bucket (tail + blocks
+        bucket_cut() ..) mid-pass, the early bucket at the end -- and returns d(input image) as NCHW fp32, or None.
         For a `forward_pair` context dlogit is [2N] (real half, fake half): input gradients run once over the 2N
         batch (sigma_1 / sigma_2 rides in the output codes), weight gradients are taken per half, because each half
         owns its spectral-norm state (u, v, sigma) in the fix-up from d/d(W/sigma) to d/d(weight_orig)."""
@@ -567,7 +632,6 @@ class DiscriminatorEngine:
 
         def U(i, sl):                                  # code rows matching the activation rows x[sl]
             return codes_full[i][sl]
-        nmc = len(self._codes.mcs)
         # raw gradients (w.r.t. the NORMALISED weights, and the biases) land here first: one buffer per pass
         if pair is None:
             passes = [(slice(None), torch.empty_like(fp) if want_w else None)]
@@ -589,13 +653,27 @@ class DiscriminatorEngine:
                 g1, b1, b12 = dests(gtmp)
                 ops.wgrad(seg_fn(sl), dy[sl], cout, cin, g1, bias_grad=b1, bias_grad2=b12, **kw)
 
+        def fix(tab, sg_off):
+            """d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used (biases are moved as is), for the
+            layers of one bucket table."""
+            table, nl = tab
+            if nl == 0:
+                return
+            ops.sn_grad_fix(passes[0][1], gflat, fp, uv, table, nl, sigma[sg_off:], accumulate=accumulate)
+            if pair is not None:
+                ops.sn_grad_fix(passes[1][1], gflat, fp, pair['uv2'], table, nl, pair['sigma2'][sg_off:], accumulate=True)
+
+        bk = self._bucket_tables() if want_w else None
+        cut = self.bucket_cut()
         self._ensure_preps()
         self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
         I = self.img
         tl = self.sn_of[self.tail_lin]
         sg_t = sigma[tl.idx:tl.idx + 1]
         wl = self.tail_lin.weight_orig
-        with ops.deferred_reduces():          # all split-K reductions of this pass: one launch, before the SN fix-up
+        red = ops.deferred_reduces()           # the split-K reductions of one bucket: one launch, before its SN fix-up
+        red.__enter__()
+        try:
             if pair is None:
                 gt = passes[0][1]
                 dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
@@ -630,6 +708,13 @@ class DiscriminatorEngine:
                 else:
                     res = dy
                 dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
+                if want_w and bi == cut:
+                    # blocks cut .. last and the tail are done: reduce their slabs, fix them up, hand the bucket out
+                    red.__exit__(None, None, None)
+                    fix(bk['hi'], bk['i_cut'])
+                    yield (bk['off_cut'], fp.numel())
+                    red = ops.deferred_reduces()
+                    red.__enter__()
             # FirstDisResBlock
             b0, bc = self.res[0], ctx['blocks'][0]
             c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
@@ -647,10 +732,11 @@ class DiscriminatorEngine:
                     raise RuntimeError('input gradients of a paired pass are not needed by the D update and not built')
                 dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
                 dimg = ops.to_nchw(dimg_t, c1m.cin)
+        except BaseException as e:
+            red.__exit__(type(e), e, None)
+            raise
+        red.__exit__(None, None, None)
         if want_w:
-            # d/d(W/sigma) -> d/d(weight_orig) with the u, v, sigma THIS forward used; biases are moved as is
-            nl = len(self.sn) + len(self.plain)
-            ops.sn_grad_fix(passes[0][1], gflat, fp, uv, self._layers_dev, nl, sigma, accumulate=accumulate)
-            if pair is not None:
-                ops.sn_grad_fix(passes[1][1], gflat, fp, pair['uv2'], self._layers_dev, nl, pair['sigma2'], accumulate=True)
+            fix(bk['lo'], 0)
+            yield (0, bk['off_cut'])
         return dimg

@@ -557,6 +557,17 @@ def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: 
                                           _f32(sigma), _f32(ws), max_rows, max_cols, _stream()), 'sn_power_iter')
 
 
+def sn_power_iter_fused(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, rounds: int, do_iter: bool,
+                        max_rows: int, max_cols: int, snapshot: bool = True):
+    """`rounds` power iterations of all layers in one launch -> (sigma [rounds, nlayers], u/v snapshots [rounds, uv] or None)."""
+    sigma = torch.empty((rounds, nlayers), dtype=torch.float32, device=w_base.device)
+    snap = torch.empty((rounds, uv_base.numel()), dtype=torch.float32, device=w_base.device) if snapshot else None
+    check(_lib.load().mcgen_sn_power_iter_fused(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, rounds, int(do_iter),
+                                                _f32(sigma), _f32(snap), uv_base.numel(), max_rows, max_cols, _stream()),
+          'sn_power_iter_fused')
+    return sigma, snap
+
+
 def sn_grad_fix(g_src: Tensor, g_dst: Tensor, w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int,
                 sigma: Tensor, accumulate: bool = False):
     ws = torch.empty(32 * nlayers, dtype=torch.float32, device=g_src.device)

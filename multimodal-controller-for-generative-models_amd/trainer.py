@@ -113,8 +113,33 @@ class GANTrainer:
         self.group, self.world = dist_group, world_size
         self.latent = model.latent_size
 
-    # ---- data-parallel gradient exchange: one flat bucket per network ----------------------------
+    # ---- data-parallel gradient exchange: two buckets per network, started under the backward pass -------------
+    # The engines' backward passes hand out each network's flat gradient in two contiguous buckets: the LATE layers
+    # (tail / head + the late residual blocks), final when about half of the backward is done, and the early layers at
+    # its end (gan_engine: backward_iter, bucket_cut).  A bucket's all-reduce (average, RCCL over xGMI) is launched on
+    # a communication stream the moment it is final, so the late bucket's exchange runs under the rest of the backward
+    # pass; the optimizer step waits for both.  (train_gan.py:96-98: the reference's nn.DataParallel sums replica
+    # gradients onto device 0 after the whole backward.)
+    def _comm_stream(self):
+        cs = getattr(self, '_comm', None)
+        if cs is None:
+            cs = self._comm = torch.cuda.Stream()
+        return cs
+
+    def _reduce_bucket(self, g: torch.Tensor, lo: int, hi: int):
+        if self.world > 1 and hi > lo:
+            from .dist import allreduce_mean_
+            cs = self._comm_stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                allreduce_mean_(g[lo:hi], self.world, self.group)
+
+    def _join_comm(self):
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self._comm_stream())
+
     def _allreduce(self, g: torch.Tensor):
+        """Whole-buffer exchange on the compute stream (kept for callers that do not bucket)."""
         if self.world > 1:
             from .dist import allreduce_mean_
             allreduce_mean_(g, self.world, self.group)
@@ -135,8 +160,9 @@ class GANTrainer:
         fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups)
         return fake
 
-    # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images)
-    def d_compute(self, img, ind, fake, ind2=None):
+    # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
+    # The *_iter forms are generators: they yield (lo, hi) whenever grad[lo:hi] is final (see _reduce_bucket).
+    def d_compute_iter(self, img, ind, fake, ind2=None):
         """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
         [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once."""
         if _PAIR_D:
@@ -145,42 +171,52 @@ class GANTrainer:
             logits, ctx = self.deng.forward_pair(img, fake, ind, ind2)
             n = img.shape[0]
             lg = logits.view(-1)
-            loss, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) sit side by side
-            self.deng.backward(ctx, dboth, self.grad_d, False, False)
-            return loss
+            self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
+            yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False)
+            return
         d_real, ctx_r = self.deng.forward(img, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
-        loss, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
+        self.loss_d, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
-        self.deng.backward(ctx_f, dfake, self.grad_d, True, False)
-        return loss
+        yield from self.deng.backward_iter(ctx_f, dfake, self.grad_d, True, False)     # final once the second pass added
+
+    def d_compute(self, img, ind, fake, ind2=None):
+        for _ in self.d_compute_iter(img, ind, fake, ind2):
+            pass
+        return self.loss_d
 
     def d_apply(self):
         self.opt_d.step(self.grad_d)
 
-    def g_compute(self, ind, z):
+    def g_compute_iter(self, ind, z):
         fake, gctx = self.geng.forward(z, ind, True)
         d_fake, dctx = self.deng.forward(fake, ind, True)
-        loss, dfake = ops.hinge_g(d_fake.view(-1))
+        self.loss_g, dfake = ops.hinge_g(d_fake.view(-1))
         dimg = self.deng.backward(dctx, dfake, None, False, True)
-        self.geng.backward(gctx, dimg, self.grad_g, False)
-        return loss
+        yield from self.geng.backward_iter(gctx, dimg, self.grad_g, False)
+
+    def g_compute(self, ind, z):
+        for _ in self.g_compute_iter(ind, z):
+            pass
+        return self.loss_g
 
     def g_apply(self):
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
 
     def d_update(self, img, ind, fake, ind2=None):
-        loss = self.d_compute(img, ind, fake, ind2)
-        self._allreduce(self.grad_d)
+        for lo, hi in self.d_compute_iter(img, ind, fake, ind2):
+            self._reduce_bucket(self.grad_d, lo, hi)
+        self._join_comm()
         self.d_apply()
-        return loss
+        return self.loss_d
 
     def g_update(self, ind, z):
-        loss = self.g_compute(ind, z)
-        self._allreduce(self.grad_g)
+        for lo, hi in self.g_compute_iter(ind, z):
+            self._reduce_bucket(self.grad_g, lo, hi)
+        self._join_comm()
         self.g_apply()
-        return loss
+        return self.loss_g
 
     def train_iteration(self, img: torch.Tensor, label: torch.Tensor, zs: Optional[Sequence[torch.Tensor]] = None):
         """One reference loop body on one batch.  `zs`: d_iters + g_iters latent batches to inject
@@ -266,20 +302,31 @@ class GraphedGANTrainer(GANTrainer):
         torch.cuda.synchronize()
         G = torch.cuda.CUDAGraph
         self.g_zd, self.g_gf, self.g_z = G(), G(), G()
-        self.g_dc, self.g_da, self.g_gc, self.g_ga = G(), G(), G(), G()
+        self.g_da, self.g_ga = G(), G()
         with torch.cuda.graph(self.g_gf, capture_error_mode=_CAPTURE_MODE):
             self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg)
         pool = self.g_gf.pool()
-        with torch.cuda.graph(self.g_dc, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self.loss_d = self.d_compute(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
+
+        def capture_buckets(gen):
+            """One graph per gradient bucket: graph k holds the launches up to the point where bucket k is final."""
+            graphs = []
+            while True:
+                gk = G()
+                try:
+                    with torch.cuda.graph(gk, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                        rng = next(gen)
+                except StopIteration:
+                    break                      # (the generator ends right behind its last yield: nothing was recorded)
+                graphs.append((gk, rng))
+            return graphs
+        self.g_dc = capture_buckets(self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_zd.normal_()
         with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
         with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.d_apply()
-        with torch.cuda.graph(self.g_gc, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self.loss_g = self.g_compute(self.s_ind, self.s_z)
+        self.g_gc = capture_buckets(self.g_compute_iter(self.s_ind, self.s_z))
         with torch.cuda.graph(self.g_ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.g_apply()
         self._graphs = True
@@ -307,16 +354,20 @@ class GraphedGANTrainer(GANTrainer):
                 self.g_gf.replay()
             j = k % fg
             self.s_fake.copy_(self.s_fakes[j * n:(j + 1) * n], non_blocking=True)
-            self.g_dc.replay()
-            self._allreduce(self.grad_d)
+            for gk, (lo, hi) in self.g_dc:
+                gk.replay()
+                self._reduce_bucket(self.grad_d, lo, hi)
+            self._join_comm()
             self.g_da.replay()
         for _ in range(self.g_iters):
             if zi is None:
                 self.g_z.replay()
             else:
                 self.s_z.copy_(next(zi), non_blocking=True)
-            self.g_gc.replay()
-            self._allreduce(self.grad_g)
+            for gk, (lo, hi) in self.g_gc:
+                gk.replay()
+                self._reduce_bucket(self.grad_g, lo, hi)
+            self._join_comm()
             self.g_ga.replay()
         return self.loss_d, self.loss_g
 

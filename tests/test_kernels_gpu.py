@@ -393,6 +393,20 @@ def test_spectral_norm_kernels():
         k = m.weight_orig.numel()
         np.testing.assert_allclose(G[off:off + k].cpu(), m.weight_orig.grad.reshape(-1), rtol=2e-4, atol=2e-5)
         off += k
+    # the fused form: two rounds in one launch == two launches of the four-kernel form, snapshots included
+    UVa, UVb = UV.clone(), UV.clone()
+    sa1, sa2 = torch.zeros_like(sigma), torch.zeros_like(sigma)
+    ops.sn_power_iter(W, UVa, ld, len(sn), True, sa1, 24, 144)
+    snap1 = UVa.clone()
+    ops.sn_power_iter(W, UVa, ld, len(sn), True, sa2, 24, 144)
+    sf, snap = ops.sn_power_iter_fused(W, UVb, ld, len(sn), 2, True, 24, 144)
+    np.testing.assert_allclose(sf[0].cpu(), sa1.cpu(), rtol=1e-5)
+    np.testing.assert_allclose(sf[1].cpu(), sa2.cpu(), rtol=1e-5)
+    np.testing.assert_allclose(UVb.cpu(), UVa.cpu(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(snap[0].cpu(), snap1.cpu(), rtol=1e-4, atol=1e-6)
+    assert torch.equal(snap[1], UVb)
+    se, _ = ops.sn_power_iter_fused(W, UVb, ld, len(sn), 1, False, 24, 144, snapshot=False)
+    np.testing.assert_allclose(se[0].cpu(), sf[1].cpu(), rtol=1e-5)
     # eval mode: no iteration, same sigma formula
     sig2 = torch.zeros_like(sigma)
     UV2 = UV.clone()

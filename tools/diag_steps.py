@@ -58,10 +58,23 @@ def main():
         print(f'D update {k}: hip {float(loss):.7f} oracle {float(ol):.7f} diff {float(loss) - float(ol):+.2e}; '
               f'fake batch max diff {float((fake.cpu() - fk.detach()).abs().max()):.2e}')
         cmp_state(f'after D update {k}')
+    # the generator loss on the HIP weights, evaluated by the ORACLE: separates "the weights drifted" from "the G-step
+    # forward differs"
+    hip_sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     with torch.no_grad():
-        zq = zs[5]
-        fake, _ = tr.geng.forward(zq.cuda(), ind, True)
-        # evaluate both discriminators on the SAME (oracle) fake batch, eval-free: training-mode forward on copies
+        indc = O.one_hot(lab, classes)
+        fk_h = O.generator_forward({k: v.clone() for k, v in hip_sd.items()}, zs[5], indc, True)
+        og_h = -O.discriminator_forward({k: v.clone() for k, v in hip_sd.items()}, fk_h, indc, True, cifar_layout=cifar).mean()
+        fk_o = O.generator_forward({k: v.detach().clone() for k, v in orc.sd.items()}, zs[5], indc, True)
+        og_o = -O.discriminator_forward({k: v.detach().clone() for k, v in orc.sd.items()}, fk_o, indc, True, cifar_layout=cifar).mean()
+        # mixed: oracle G weights with HIP D weights and vice versa
+        mix1 = {k: (hip_sd[k] if k.startswith('discriminator.') else orc.sd[k].detach()).clone() for k in hip_sd}
+        og_m1 = -O.discriminator_forward(mix1, O.generator_forward(mix1, zs[5], indc, True), indc, True, cifar_layout=cifar).mean()
+    print(f'oracle forward of the G loss: on HIP weights {float(og_h):.7f}, on oracle weights {float(og_o):.7f}, '
+          f'HIP D + oracle G {float(og_m1):.7f}')
+    for key in ('weight_u', 'weight_v'):
+        worst = max((float((hip_sd[k] - orc.sd[k].detach()).abs().max()), k) for k in hip_sd if k.endswith(key))
+        print(f'  largest {key} difference: {worst}')
     gl = tr.g_update(ind, zs[5].cuda())
     orc._zero()
     fk = orc.generate(lab, zs[5])
