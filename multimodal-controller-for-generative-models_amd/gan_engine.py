@@ -86,6 +86,8 @@ class _BN:
 
 
 _PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
+_SN_FUSED = __import__('os').environ.get('MCGEN_SN_FUSED', '1') != '0'      # A/B switch: fused multi-round power iteration
+_BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # A/B switch: two gradient buckets per network
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -338,7 +340,8 @@ class GeneratorEngine:
                                      G(bnm1.weight), G(bnm1.bias), add=dx_sc, accumulate=acc)
                 if i == cut and cut > 0:
                     red.__exit__(None, None, None)           # head + blocks cut .. last are final
-                    yield (off_cut, gflat.numel())
+                    if _BUCKETS:
+                        yield (off_cut, gflat.numel(), False)
                     red = ops.deferred_reduces()
                     red.__enter__()
             # linear layer: dy is [N,4,4,C0] == [N,1,1,16*C0] in the permuted row order
@@ -350,7 +353,7 @@ class GeneratorEngine:
             red.__exit__(type(e), e, None)
             raise
         red.__exit__(None, None, None)
-        yield (0, off_cut if cut > 0 else gflat.numel())
+        yield (0, off_cut if (cut > 0 and _BUCKETS) else gflat.numel(), True)
 
 
 # ============================================================================================= #
@@ -465,6 +468,17 @@ class DiscriminatorEngine:
         round -- torch's hook clones u, v for the backward pass, the snapshot is that clone."""
         fp, fuv = self._ensure_flat()
         nsn = len(self.sn)
+        if not _SN_FUSED:                                   # the four-kernel form, one round per call
+            out = []
+            for _ in range(rounds):
+                sg = torch.empty(nsn, dtype=torch.float32, device=fp.device)
+                ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sg,
+                                  max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
+                out.append((sg, fuv.clone()))
+            if train:
+                for s in self.sn:
+                    _bump(s.m.weight_u); _bump(s.m.weight_v)
+            return out
         sigma, snap = ops.sn_power_iter_fused(fp, fuv, self._layers_dev, nsn, rounds, train,
                                               max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
         if train:
@@ -712,7 +726,8 @@ class DiscriminatorEngine:
                     # blocks cut .. last and the tail are done: reduce their slabs, fix them up, hand the bucket out
                     red.__exit__(None, None, None)
                     fix(bk['hi'], bk['i_cut'])
-                    yield (bk['off_cut'], fp.numel())
+                    if _BUCKETS:
+                        yield (bk['off_cut'], fp.numel(), False)
                     red = ops.deferred_reduces()
                     red.__enter__()
             # FirstDisResBlock
@@ -738,5 +753,5 @@ class DiscriminatorEngine:
         red.__exit__(None, None, None)
         if want_w:
             fix(bk['lo'], 0)
-            yield (0, bk['off_cut'])
+            yield ((0, bk['off_cut'], True) if _BUCKETS else (0, fp.numel(), True))
         return dimg

@@ -161,7 +161,7 @@ class GANTrainer:
         return fake
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
-    # The *_iter forms are generators: they yield (lo, hi) whenever grad[lo:hi] is final (see _reduce_bucket).
+    # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
     def d_compute_iter(self, img, ind, fake, ind2=None):
         """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
         [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once."""
@@ -205,14 +205,14 @@ class GANTrainer:
         self.geng.refresh_images(force=True)
 
     def d_update(self, img, ind, fake, ind2=None):
-        for lo, hi in self.d_compute_iter(img, ind, fake, ind2):
+        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2):
             self._reduce_bucket(self.grad_d, lo, hi)
         self._join_comm()
         self.d_apply()
         return self.loss_d
 
     def g_update(self, ind, z):
-        for lo, hi in self.g_compute_iter(ind, z):
+        for lo, hi, _last in self.g_compute_iter(ind, z):
             self._reduce_bucket(self.grad_g, lo, hi)
         self._join_comm()
         self.g_apply()
@@ -308,16 +308,15 @@ class GraphedGANTrainer(GANTrainer):
         pool = self.g_gf.pool()
 
         def capture_buckets(gen):
-            """One graph per gradient bucket: graph k holds the launches up to the point where bucket k is final."""
+            """One graph per gradient bucket: graph k holds the launches up to the point where bucket k is final (the
+            generators flag their last bucket, behind which they launch nothing more)."""
             graphs = []
-            while True:
+            last = False
+            while not last:
                 gk = G()
-                try:
-                    with torch.cuda.graph(gk, pool=pool, capture_error_mode=_CAPTURE_MODE):
-                        rng = next(gen)
-                except StopIteration:
-                    break                      # (the generator ends right behind its last yield: nothing was recorded)
-                graphs.append((gk, rng))
+                with torch.cuda.graph(gk, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                    lo, hi, last = next(gen)
+                graphs.append((gk, (lo, hi)))
             return graphs
         self.g_dc = capture_buckets(self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):

@@ -51,7 +51,7 @@ def _worker(rank, world, port, q):
         # (a) discriminator update gradient, exchanged bucket by bucket on the communication stream
         fake, _ = tr.geng.forward(z[0][sh], ind, True)
         buckets = []
-        for lo, hi in tr.d_compute_iter(img[sh], ind, fake):
+        for lo, hi, _last in tr.d_compute_iter(img[sh], ind, fake):
             buckets.append((lo, hi))
             tr._reduce_bucket(tr.grad_d, lo, hi)
         tr._join_comm(); torch.cuda.synchronize()
@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
         # generator update gradient, from the same starting state
         m.load_state_dict(sd)
         gb = []
-        for lo, hi in tr.g_compute_iter(ind, z[1][sh]):
+        for lo, hi, _last in tr.g_compute_iter(ind, z[1][sh]):
             gb.append((lo, hi))
             tr._reduce_bucket(tr.grad_g, lo, hi)
         tr._join_comm(); torch.cuda.synchronize()
