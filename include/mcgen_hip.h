@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 2: mcgen_seg_t.group_n, mcgen_bn_finalize_groups */
+int mcgen_abi_version(void);      /* 3: + mcgen_seg_t.cmap, mcgen_conv_t.w_layout (mode-compacted convolutions) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -45,6 +45,10 @@ typedef struct {
     const float* scale;   /* [C] ([N/group_n][C] when group_n > 0) or NULL            */
     const float* shift;   /* same shape as scale (read only when scale != NULL)       */
     const float* code;    /* [N, C] = indicator @ codebook, or NULL                   */
+    const int16_t* cmap;  /* per-sample compaction map built by mcgen_mc_cmap from `code` (see there), or NULL:
+                           * the K loop then visits only the channels whose code is non-zero -- with
+                           * controller_rate 0.5 half of them (modules.py:58-76); bf16 launches on K-major
+                           * weight images (mcgen_conv_t.w_layout = 1) whose tiles lie inside one image     */
     int32_t C;            /* channels of x (multiple of 8)                            */
     int32_t ups;          /* 1: x is at half the convolution's resolution             */
     int32_t relu;
@@ -53,7 +57,7 @@ typedef struct {
                            * (several training-mode generator forwards run as one pass, train_gan.py:145-146):
                            * image n is normalised with row n / group_n of scale / shift.  0: one batch.
                            * Convolution launches only (mcgen_wgrad requires 0); a tile never straddles groups. */
-    int32_t reserved_;
+    int32_t cmap_stride;  /* int16 elements per sample record of cmap                 */
 } mcgen_seg_t;
 
 /* Fused convolution  y = epilogue( sum_seg conv(prologue_seg(x_seg), W_seg) ).
@@ -92,6 +96,9 @@ typedef struct {
     int32_t tanh_out;
     float*  stats;         /* [m_tiles][2][Cy] partial sums, or NULL                       */
     int32_t stats_mode;
+    int32_t w_layout;      /* 0: `w` is the [chunk][tap][cout][32] image of mcgen_prep_weight;
+                            * 1: the K-major image of mcgen_prep_weight_k (mode-compacted launches:
+                            *    every segment carries a cmap)                                     */
 } mcgen_conv_t;
 
 /* number of M tiles (rows of `stats`) the launch of `p` will use */
@@ -169,9 +176,25 @@ int mcgen_prep_weight_ex_batch(const mcgen_prepex_t* jobs, int n, int dtype, voi
 typedef struct {
     const float* w; void* image;
     int32_t Cout, Cin, ksize, transpose, row_perm, sigma_idx;
-    float wscale; int32_t _pad;
+    float wscale; int32_t layout;   /* 0: chunked image (mcgen_prep_weight); 1: K-major (mcgen_prep_weight_k, transpose = 0) */
 } mcgen_prep_t;
 int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream);
+
+/* K-major weight image for mode-compacted launches: image[tap][k][co_w], k = 0 .. round_up(Cin, 8) (the last row,
+ * index round_up(Cin, 8), is all zeros: padded K slots point at it), co_w = Cout rounded up to 16; bf16 or fp32,
+ * multiplied by wscale / (*sigma if sigma != NULL).  A compacted K step gathers 32 rows of this image by index. */
+int64_t mcgen_weight_image_k_elems(int Cout, int Cin, int ksize);
+int mcgen_prep_weight_k(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                        const float* sigma, float wscale, void* stream);
+
+/* Per-sample compaction map of one MultimodalController code tensor code[N, C] (C a multiple of 8): record n
+ * (cmap + n * stride, int16 elements, stride = mcgen_cmap_stride(C)) holds
+ *     cpos[C]       position of channel c among the sample's active channels (code != 0), -1 if inactive
+ *     cidx[C + 32]  the active channels in order, padded with C (the K-major image's zero row)
+ *     cpre[C/32+1]  (int32 entries) number of active channels below each 32-channel boundary; the last = their count
+ * modules.py:71-76: out = x * code -- a zero code entry removes the channel from every product that follows. */
+int32_t mcgen_cmap_stride(int C);
+int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream);
 
 /* layout / dtype conversion at the module boundary (the reference works on NCHW fp32) */
 int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);

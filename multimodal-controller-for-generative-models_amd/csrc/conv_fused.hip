@@ -799,6 +799,268 @@ void conv_cp_kernel(const mcgen_conv_t p, const int a_bytes, const int subw) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "mc" form: mode-compacted K loop ---------------------------------------------------------------------------
+// MultimodalController (modules.py:71-76) multiplies every conv input by a per-sample 0/1 code: with controller_rate
+// 0.5 half of the input channels of a sample are exact zeros.  A tile that lies inside one image therefore needs only
+// the K slices of that sample's ACTIVE channels.  This form visits them alone:
+//   * activations: the window of a dense 32-channel chunk is loaded and run through the prologue as in the dma3 form, but
+//     each value is written to the LDS window at its COMPACTED position (mcgen_mc_cmap: cpos), into a ring of two
+//     32-slot halves; an MFMA K step (9 taps) fires whenever a half is full -- on average after two dense chunks;
+//   * weights: the image is K-major ([tap][k][cout], mcgen_prep_weight_k), so a compacted K step is a gather of 32
+//     ROWS: each 1 KB LDS-DMA piece takes its rows' indices from the map (cidx, scalar loads).  In LDS a tap tile is
+//     [32 k][BN cout] with the 32-byte cout slots XOR-swizzled by (k & 7); the MFMA A fragments come out of it through
+//     ds_read_b64_tr_b16 (conflict-free: the 8 rows of a half-wave read fall on 8 distinct bank groups);
+//   * the k order inside a 32-slot step is permuted (slot s = 8*lg + 4*a + b holds logical k = 16*a + 4*lg + b) so that
+//     one transposing read covers 8 consecutive rows; the activation scatter applies the same permutation.
+// Padded slots of the last step point at the image's zero row; the window is zeroed once so they multiply finite data.
+// FLOP accounting stays dense (roofline fractions are quoted on 2*N*H*W*Cout*K with K = all channels).
+// wave-uniform dword through the scalar cache (constant address space): no vmcnt entry, so it neither waits for nor
+// drains the LDS-DMAs in flight
+static __device__ __forceinline__ uint32_t mc_sload(const void* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p));
+}
+static __device__ __forceinline__ s16x4 mc_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using T = bf16_t;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, APITCH = C::APITCH;
+    constexpr int NW = WM * WN;
+    constexpr int ROWB = BN * 2;                           // bytes per k row of a tap tile
+    constexpr int RPP = 1024 / ROWB;                       // k rows per 1 KB DMA piece (2 or 4)
+    constexpr int LPR = 64 / RPP;                          // lanes (16-byte units) per row
+    constexpr int NPIECE = 32 / RPP;                       // pieces per tap tile
+    constexpr int PPW = (NPIECE + NW - 1) / NW;            // pieces per wave per tap
+    constexpr int TAPB = 32 * ROWB;                        // bytes per tap tile
+    constexpr int TPS = 3, SLOT = TPS * TAPB;
+    constexpr int NI = C::NI;
+    static_assert(BN == 128 || BN == 256, "k-major tap tiles: 2 or 4 rows per DMA piece");
+    static_assert(NPIECE % NW == 0 || NPIECE < NW, "pieces are dealt evenly to the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;                               // two window halves of a_bytes each
+    char* const ldsB0 = smem + 2 * a_bytes;                // two weight slots
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);          // host guarantees TI == 1: the tile lies inside image g.n0
+    const int n_img = g.n0 < N ? g.n0 : N - 1;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // zero both window halves once (padded slots / first use): 16 bytes per thread per step
+    for (int o = tid * 16; o < 2 * a_bytes; o += NT * 16) *reinterpret_cast<u32x4*>(ldsA + o) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- per-segment bookkeeping (wave-uniform) -------------------------------------------------------------
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const int16_t* rec0 = p.seg[0].cmap + (size_t)n_img * p.seg[0].cmap_stride;
+    const int C0 = p.seg[0].C, nd0 = (C0 + 31) >> 5;
+    const int cnt0 = (int)mc_sload(rec0 + 2 * C0 + 32 + 2 * nd0);                 // cpre[nd]: the sample's active channels
+    const int nt0 = p.seg[0].ksize * p.seg[0].ksize, gpc0 = (nt0 == 9) ? 3 : 1;
+    const int nks0 = (cnt0 + 31) >> 5;
+    const size_t tapstride0 = (size_t)(C0 + 1) * p.Cout_w * 2;                     // bytes per tap of segment 0's image
+    const size_t seg1_off = (size_t)nt0 * tapstride0;
+    int C1 = 8, nd1 = 0, cnt1 = 0, nt1 = 1, gpc1 = 1, nks1 = 0;
+    const int16_t* rec1 = rec0;
+    size_t tapstride1 = 0;
+    if (p.nseg > 1) {
+        rec1 = p.seg[1].cmap + (size_t)n_img * p.seg[1].cmap_stride;
+        C1 = p.seg[1].C; nd1 = (C1 + 31) >> 5;
+        cnt1 = (int)mc_sload(rec1 + 2 * C1 + 32 + 2 * nd1);
+        nt1 = p.seg[1].ksize * p.seg[1].ksize; gpc1 = (nt1 == 9) ? 3 : 1;
+        nks1 = (cnt1 + 31) >> 5;
+        tapstride1 = (size_t)(C1 + 1) * p.Cout_w * 2;
+    }
+    const int G0 = nks0 * gpc0, GT = G0 + nks1 * gpc1;     // DMA groups of segment 0 / of the launch
+
+    // ---- weight DMA: group gi -> slot gi & 1 ----------------------------------------------------------------
+    // lane -> (row inside the piece, 16-byte unit inside the row); the unit's 32-byte slot is XOR-swizzled by the row
+    const int rsub = lane / LPR, ci = lane % LPR;
+    auto G_dma = [&](int gi) {
+        if (gi >= GT) return;
+        const bool s1 = gi >= G0;
+        const int gl = s1 ? gi - G0 : gi;
+        const int gpc = s1 ? gpc1 : gpc0;
+        const int t = gl / gpc, gq = gl - t * gpc;                                  // K step, tap group of the step
+        const int ntg = (gpc == 3) ? 3 : 1;
+        const int16_t* cidx = (s1 ? rec1 + C1 : rec0 + C0) + 32 * t;
+        const size_t tapstride = s1 ? tapstride1 : tapstride0;
+        const char* wseg = wimg + (s1 ? seg1_off : 0);
+        char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = wave * PPW + k;
+            if (piece < NPIECE) {
+                // the RPP row indices of this piece: consecutive int16 entries, read as dwords (wave-uniform address)
+                const uint32_t d01 = mc_sload(cidx + RPP * piece);
+                uint32_t sel = d01;
+                if constexpr (RPP == 4) {
+                    const uint32_t d23 = mc_sload(cidx + RPP * piece + 2);
+                    sel = (rsub & 2) ? d23 : d01;
+                }
+                const int dense = (int)((rsub & 1) ? (sel >> 16) : (sel & 0xffffu));   // dense channel = image row
+                const int kk = RPP * piece + rsub;                                      // logical k inside the step
+                int co = cout0 + 16 * ((ci >> 1) ^ (kk & 7)) + 8 * (ci & 1);
+                if (co > p.Cout_w - 8) co = p.Cout_w - 8;                               // partial N tile: stay in bounds
+                const size_t roff = ((size_t)dense * p.Cout_w + co) * 2;
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt) {
+                    const int tap = gq * ntg + (tt < ntg ? tt : ntg - 1);               // short group: re-load the last tap
+                    const char* src = wseg + (size_t)tap * tapstride + roff;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(slot + tt * TAPB + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    // A-fragment (weights) read offsets: rows 4*lg + q (+16 for the second half), 32-byte slot (c0/16) ^ (row & 7)
+    int w_off[FN];
+    {
+        const int q = l15 >> 2, pq = l15 & 3, r0 = 4 * lg + q;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int c0 = wn * (BN / WN) + fn * 16;
+            w_off[fn] = r0 * ROWB + 32 * ((c0 >> 4) ^ (r0 & 7)) + 8 * pq;
+        }
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // the zero fill is complete before any scatter write
+    int gi = 0;
+    G_dma(0);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
+        const int16_t* rec = s ? rec1 : rec0;
+        const int Cs = sg.C, nd = (Cs + 31) >> 5, cnt = s ? cnt1 : cnt0;
+        const int16_t* cpre = rec + 2 * Cs + 32;          // int32 entries (two int16 slots each)
+        const int halo = sg.ksize >> 1;
+        const int PC = W + 2 * halo;
+        PatchStager<T, NT, NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = (r * PC + c) * APITCH + lg * 16;
+        }
+        const int ntap = sg.ksize * sg.ksize;
+        const int gpc = (ntap == 9) ? 3 : 1, ntg = (ntap == 9) ? 3 : 1;
+        int consumed = 0;                                  // compacted slots the MFMA steps have used (multiple of 32)
+        int filled = 0;
+        int filled_next = (int)mc_sload(cpre + 2);       // cpre[1], fetched one chunk ahead of its use
+#pragma unroll 1
+        for (int dq = 0; dq < nd && cnt > 0; ++dq) {
+            const int c0 = dq * MCGEN_CK;
+            const int filled0 = filled;
+            filled = filled_next;
+            if (dq + 2 <= nd) filled_next = (int)mc_sload(cpre + 2 * (dq + 2));
+            const bool last = (dq == nd - 1);
+            if (filled > filled0) {
+                __builtin_amdgcn_s_barrier();              // everyone is past the window reads of the previous K step
+                // ---- stage dense chunk dq: loads, prologue, scatter to the compacted positions ---------------------
+                typename PatchStager<T, NT, NI, APITCH>::raw_t raw;
+                stager.load(sg, c0, raw);
+                const int c = c0 + stager.it_sub[0];
+                const bool cok = c < Cs;
+                u32x4 cp4 = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                if (cok) cp4 = *reinterpret_cast<const u32x4*>(rec + c);             // cpos of this thread's 8 channels
+                float sc[8], sh[8], cd[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; cd[i] = 1.f; }
+                if (sg.scale && cok) { load8f(sg.scale + c, sc); load8f(sg.shift + c, sh); }
+                if (sg.code && cok) load8f(sg.code + (size_t)n_img * Cs + c, cd);
+                int soff[8];                               // byte offset of each channel's slot inside a window pixel, -1: inactive
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kabs = (int)(int16_t)((i & 1) ? (cp4[i >> 1] >> 16) : (cp4[i >> 1] & 0xffffu));
+                    const int kk = kabs & 31;
+                    const int slot = 8 * ((kk >> 2) & 3) + 4 * (kk >> 4) + (kk & 3);
+                    soff[i] = (kabs < 0) ? -1 : (((kabs >> 5) & 1) * a_bytes + slot * 2);
+                }
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    if (stager.it_lds[k] < 0) continue;
+                    float v[8];
+                    PatchStager<T, NT, NI, APITCH>::unpack(raw[k], v);
+                    const bool inside = stager.it_src[k] >= 0 && cok;
+                    char* px = ldsA + (stager.it_lds[k] - stager.it_sub[0] * 2);      // the window pixel's first slot
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float a = 0.f;
+                        if (inside) {
+                            a = sg.scale ? fmaf(v[i], sc[i], sh[i]) : v[i];
+                            if (sg.relu) a = fmaxf(a, 0.f);
+                            if (sg.code) a *= cd[i];
+                        }
+                        if (soff[i] >= 0) *reinterpret_cast<T*>(px + soff[i]) = (T)a;
+                    }
+                }
+            }
+            // ---- MFMA K steps on every half that is now complete (the last chunk flushes the partial one) ---------------
+#pragma unroll 1
+            while (filled - consumed >= 32 || (last && consumed < cnt)) {
+                const char* win = ldsA + ((consumed >> 5) & 1) * a_bytes;
+#pragma unroll 1
+                for (int gq = 0; gq < gpc; ++gq) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this group's weight pieces (and nothing newer) landed
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's window writes are in LDS
+                    __builtin_amdgcn_s_barrier();
+                    G_dma(gi + 1);                        // slot (gi+1)&1: its readers (group gi-1) passed the barrier
+                    const char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+                    for (int t = 0; t < TPS; ++t) {
+                        if (t < ntg) {
+                            const int tap = gq * ntg + t;
+                            const int kh = (ntap == 9) ? tap / 3 : 0, kw = (ntap == 9) ? tap % 3 : 0;
+                            const int tapoff = (kh * PC + kw) * APITCH;
+                            const char* ldsB = slot + t * TAPB;
+                            bf16x8 af[FM], wf[FN];
+#pragma unroll
+                            for (int fm = 0; fm < FM; ++fm)
+                                af[fm] = *reinterpret_cast<const bf16x8*>(win + a_base[fm] + tapoff);
+#pragma unroll
+                            for (int fn = 0; fn < FN; ++fn) {
+                                union { bf16x8 v; s16x4 h[2]; } u;
+                                u.h[0] = mc_tr16(ldsB + w_off[fn]);
+                                u.h[1] = mc_tr16(ldsB + w_off[fn] + 16 * ROWB);
+                                wf[fn] = u.v;
+                            }
+#pragma unroll
+                            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                                for (int fm = 0; fm < FM; ++fm)
+                                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+                        }
+                    }
+                    ++gi;
+                }
+                consumed += 32;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct TilePick { int BM, BN, pipe; };
 
@@ -965,6 +1227,56 @@ static int launch_cp(const mcgen_conv_t* p, hipStream_t st) {
     return 0;
 }
 
+// K-major, mode-compacted launches (conv_mc_kernel).  Tile: 256 x 256 where the map has the pixels for it, else
+// 128 x 256 / 128 x 128; always inside one image.
+static bool mc_tile(const mcgen_conv_t* p, int* bm, int* bn) {
+    const long M = (long)p->N * p->H * p->W;
+    const int HW = p->H * p->W;
+    *bn = p->Cout_w > 128 ? 256 : 128;
+    int b = (M >= 65536 && HW >= 256 && 256 >= 2 * p->W) ? 256 : 128;
+    if (*bn == 128 && b == 256) b = 128;                   // instantiated: 256x256, 128x256, 128x128
+    if (HW < b || b < 2 * p->W) return false;
+    *bm = b;
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_mc(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    MCGEN_CHECK(Mtot % BM == 0 && p->H * p->W >= BM, "conv_fused(mc): tiles of %d pixels must lie inside one %dx%d image", BM, p->H, p->W);
+    const int mt = (int)(Mtot / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused(mc): patch of %d pixels exceeds the staging plan", PP);
+    const int a_bytes = round_up(PP * C::APITCH, 16);
+    int lds = 2 * a_bytes + 2 * 3 * 32 * BN * 2;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(mc): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_mc_kernel<BM, BN, WM, WN>;
+    static int raised = 0;
+    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised)) return rc;
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(mc)");
+    return 0;
+}
+
+static int dispatch_mc(const mcgen_conv_t* p, int dtype, hipStream_t st) {
+    MCGEN_CHECK(dtype == MCGEN_BF16, "conv_fused: K-major (mode-compacted) launches are bf16");
+    for (int s = 0; s < p->nseg; ++s) {
+        MCGEN_CHECK(p->seg[s].cmap && p->seg[s].cmap_stride >= 2 * p->seg[s].C + 32, "conv_fused: K-major launch: segment %d has no compaction map", s);
+        MCGEN_CHECK(p->seg[s].C <= 2048, "conv_fused(mc): at most 2048 channels per segment");
+    }
+    MCGEN_CHECK(p->Cout_w % 8 == 0 && p->Cout_w >= 64, "conv_fused(mc): at least 64 output channels");
+    int bm = 0, bn = 0;
+    MCGEN_CHECK(mc_tile(p, &bm, &bn), "conv_fused(mc): no tile of a %dx%d map lies inside one image", p->H, p->W);
+    if (bm == 256 && bn == 256) return launch_mc<256, 256, 2, 4>(p, st);
+    if (bm == 128 && bn == 256) return launch_mc<128, 256, 2, 4>(p, st);
+    return launch_mc<128, 128, 2, 2>(p, st);
+}
+
 typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
 struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
 
@@ -1024,6 +1336,7 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->stats_mode >= 0 && p->stats_mode <= 2, "conv_fused: bad stats_mode");
     MCGEN_CHECK(p->stats_mode != 2 || (p->gate_x && p->gmean && p->grstd), "conv_fused: stats_mode 2 needs gate_x, gmean, grstd");
     MCGEN_CHECK(p->stats_mode == 0 || p->stats, "conv_fused: stats_mode set without a stats buffer");
+    MCGEN_CHECK(p->w_layout == 0 || p->w_layout == 1, "conv_fused: unknown weight layout %d", p->w_layout);
     return 0;
 }
 
@@ -1031,6 +1344,11 @@ static int validate(const mcgen_conv_t* p) {
 
 extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
     if (!p) return 0;
+    if (p->w_layout == 1) {
+        int bm = 0, bn = 0;
+        if (!mc_tile(p, &bm, &bn)) return 0;
+        return (int)(((long)p->N * p->H * p->W + bm - 1) / bm);
+    }
     const TilePick t = pick_tile(p, dtype);
     const long Mtot = (long)p->N * p->H * p->W;
     return (int)((Mtot + t.BM - 1) / t.BM);
@@ -1038,6 +1356,10 @@ extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
 
 extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn) {
     if (!p || !bm || !bn) return mcgen_fail("conv_tile: null pointer");
+    if (p->w_layout == 1) {
+        MCGEN_CHECK(mc_tile(p, bm, bn), "conv_tile: no K-major tile for a %dx%d map", p->H, p->W);
+        return 0;
+    }
     const TilePick t = pick_tile(p, dtype);
     *bm = t.BM; *bn = t.BN;
     return 0;
@@ -1045,6 +1367,10 @@ extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* b
 
 extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) {
     if (int rc = validate(p)) return rc;
+    if (p->w_layout == 1) {
+        return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
+    }
+    for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs w_layout = 1");
     const TilePick t = pick_tile(p, dtype);
     // pooling / whole-row tiles need at least two rows per tile
     MCGEN_CHECK(t.BM >= 2 * p->W || p->H * p->W <= t.BM, "conv_fused: tile of %d pixels too small for W=%d", t.BM, p->W);

@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 2; }
+extern "C" int mcgen_abi_version(void) { return 3; }
 
 namespace {
 
@@ -121,6 +121,19 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
     const float* __restrict__ w = d.w;
     T* __restrict__ img = reinterpret_cast<T*>(d.image);
     const int ntap = KS * KS;
+    if (d.layout == 1) {                                   // K-major image [tap][k][co_w] + zero row (mcgen_prep_weight_k)
+        const int cow = (Cout + 15) / 16 * 16, krows = (Cin + 7) / 8 * 8 + 1;
+        const size_t totalk = (size_t)ntap * krows * cow;
+        const float sck = (d.sigma_idx >= 0) ? d.wscale / sigma_base[d.sigma_idx] : d.wscale;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < totalk; i += (size_t)gridDim.x * blockDim.x) {
+            const int co = (int)(i % cow); size_t t = i / cow;
+            const int k = (int)(t % krows); const int tap = (int)(t / krows);
+            float v = 0.f;
+            if (co < Cout && k < Cin) v = w[((size_t)co * Cin + k) * ntap + tap] * sck;
+            img[i] = Elem<T>::from_f(v);
+        }
+        return;
+    }
     const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
     const int rows_w = (rows + 15) / 16 * 16;
     const int nchunk = (((kdim + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
@@ -140,6 +153,22 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
             const int mtap = transpose ? ((KS - 1 - kh) * KS + (KS - 1 - kw)) : tap;
             v = w[((size_t)co * Cin + ci) * ntap + mtap] * sc;
         }
+        img[i] = Elem<T>::from_f(v);
+    }
+}
+
+// K-major weight image [tap][k][co_w] with a trailing zero row per tap (single-descriptor form of the layout == 1 branch)
+template <typename T>
+__global__ void prep_weight_k_kernel(const float* __restrict__ w, T* __restrict__ img, int Cout, int Cin, int KS,
+                                     const float* __restrict__ sigma, float wscale) {
+    const int ntap = KS * KS, cow = (Cout + 15) / 16 * 16, krows = (Cin + 7) / 8 * 8 + 1;
+    const size_t total = (size_t)ntap * krows * cow;
+    const float sc = sigma ? wscale / sigma[0] : wscale;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cow); size_t t = i / cow;
+        const int k = (int)(t % krows); const int tap = (int)(t / krows);
+        float v = 0.f;
+        if (co < Cout && k < Cin) v = w[((size_t)co * Cin + k) * ntap + tap] * sc;
         img[i] = Elem<T>::from_f(v);
     }
 }
@@ -185,6 +214,39 @@ __global__ void mc_apply_kernel(const T* __restrict__ x, const float* __restrict
         const int c = (int)((i / inner) % C); const int n = (int)(i / ((size_t)HW * C));
         y[i] = Elem<T>::from_f(Elem<T>::to_f(x[i]) * code[(size_t)n * C + c]);
     }
+}
+
+// ---- compaction maps ------------------------------------------------------------------------------------------
+// one workgroup per sample: flags -> per-32-channel counts -> exclusive prefix -> positions / index list
+__global__ __launch_bounds__(256)
+void mc_cmap_kernel(const float* __restrict__ code, int C, int16_t* __restrict__ cmap, int stride) {
+    __shared__ int cnt32[65];
+    const int n = blockIdx.x, nd = (C + 31) / 32;
+    const float* row = code + (size_t)n * C;
+    int16_t* rec = cmap + (size_t)n * stride;
+    int16_t* cpos = rec; int16_t* cidx = rec + C;
+    int32_t* cpre = reinterpret_cast<int32_t*>(rec + 2 * C + 32);
+    for (int d = threadIdx.x; d < nd; d += blockDim.x) {
+        int k = 0;
+        for (int c = d * 32; c < d * 32 + 32 && c < C; ++c) k += (row[c] != 0.f);
+        cnt32[d + 1] = k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt32[0] = 0;
+        for (int d = 0; d < nd; ++d) cnt32[d + 1] += cnt32[d];
+    }
+    __syncthreads();
+    const int total = cnt32[nd];
+    for (int d = threadIdx.x; d <= nd; d += blockDim.x) cpre[d] = cnt32[d];
+    for (int d = threadIdx.x; d < nd; d += blockDim.x) {
+        int k = cnt32[d];
+        for (int c = d * 32; c < d * 32 + 32 && c < C; ++c) {
+            if (row[c] != 0.f) { cpos[c] = (int16_t)k; cidx[k] = (int16_t)c; ++k; }
+            else cpos[c] = -1;
+        }
+    }
+    for (int j = total + threadIdx.x; j < C + 32; j += blockDim.x) cidx[j] = (int16_t)C;     // padding -> the zero row
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------------
@@ -737,6 +799,23 @@ extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, con
         hipLaunchKernelGGL(prep_weight_batch_kernel<float>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base),
         hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
     MCGEN_LAUNCH_CHECK("prep_weight_batch"); return 0;
+}
+extern "C" int64_t mcgen_weight_image_k_elems(int Cout, int Cin, int ksize) {
+    return (int64_t)ksize * ksize * (round_up(Cin, 8) + 1) * round_up(Cout, 16);
+}
+extern "C" int mcgen_prep_weight_k(const float* w, void* image, int dtype, int Cout, int Cin, int ksize,
+                                   const float* sigma, float wscale, void* stream) {
+    MCGEN_CHECK(w && image && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "prep_weight_k: bad arguments");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_weight_k_kernel<float>, dim3(64), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, sigma, wscale),
+        hipLaunchKernelGGL(prep_weight_k_kernel<bf16_t>, dim3(64), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, sigma, wscale));
+    MCGEN_LAUNCH_CHECK("prep_weight_k"); return 0;
+}
+extern "C" int32_t mcgen_cmap_stride(int C) { return round_up(2 * C + 32 + 2 * ((C + 31) / 32 + 1), 8); }
+extern "C" int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream) {
+    MCGEN_CHECK(code && cmap && N > 0 && C > 0 && C % 8 == 0 && C <= 2048, "mc_cmap: bad arguments (C a multiple of 8, at most 2048)");
+    hipLaunchKernelGGL(mc_cmap_kernel, dim3(N), dim3(256), 0, STREAM(stream), code, C, cmap, mcgen_cmap_stride(C));
+    MCGEN_LAUNCH_CHECK("mc_cmap"); return 0;
 }
 extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
                                    const float* scale, int n_half, void* stream) {

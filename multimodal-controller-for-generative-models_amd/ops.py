@@ -143,6 +143,7 @@ class Seg:
     ups: bool = False
     relu: bool = False
     group_n: int = 0                # > 0: scale / shift are [N // group_n, C], one BatchNorm batch per group_n images
+    cmap: Optional[Tensor] = None   # int16 [N, cmap_stride(C)] compaction map of `code` (mc_cmap): mode-compacted K loop
 
     def fill(self, s: _lib.Seg):
         s.x = _p(self.x)
@@ -150,6 +151,11 @@ class Seg:
         s.C = self.x.shape[-1]
         s.ups, s.relu, s.ksize = int(self.ups), int(self.relu), self.ksize
         s.group_n = int(self.group_n)
+        s.cmap, s.cmap_stride = None, 0
+        if self.cmap is not None:
+            if self.cmap.dtype != torch.int16 or tuple(self.cmap.shape) != (self.x.shape[0], cmap_stride(s.C)):
+                raise _lib.McgenError(f'cmap must be int16 {(self.x.shape[0], cmap_stride(s.C))}, got {self.cmap.dtype} {tuple(self.cmap.shape)}')
+            s.cmap, s.cmap_stride = _p(self.cmap), self.cmap.shape[1]
         if self.group_n and self.scale is not None:
             g = self.x.shape[0] // self.group_n
             if self.x.shape[0] % self.group_n or tuple(self.scale.shape) != (g, s.C) or tuple(self.shift.shape) != (g, s.C):
@@ -206,6 +212,36 @@ def tile_images(n: int, h: int, w: int, cout: int, dtype: torch.dtype) -> int:
     return max(1, bm.value // (h * w))
 
 
+def cmap_stride(c: int) -> int:
+    return int(_lib.load().mcgen_cmap_stride(c))
+
+
+def mc_cmap(code: Tensor) -> Tensor:
+    """Per-sample compaction map of a code tensor [N, C] (mcgen_mc_cmap): int16 [N, cmap_stride(C)]."""
+    n, c = code.shape
+    out = torch.empty((n, cmap_stride(c)), dtype=torch.int16, device=code.device)
+    check(_lib.load().mcgen_mc_cmap(_f32(code), n, c, _p(out), _stream()), 'mc_cmap')
+    return out
+
+
+def weight_image_k_elems(cout: int, cin: int, ksize: int) -> int:
+    return int(_lib.load().mcgen_weight_image_k_elems(cout, cin, ksize))
+
+
+def prep_weight_k(w: Tensor, dtype: torch.dtype, sigma: Optional[Tensor] = None, wscale: float = 1.0,
+                  out: Optional[Tensor] = None) -> Tensor:
+    """Master weights [Cout, Cin, k, k] -> K-major image [tap][round_up(Cin, 8) + 1][pad16(Cout)] (last row zero)."""
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2] if w.dim() == 4 else 1
+    n = weight_image_k_elems(cout, cin, ks)
+    if out is None:
+        out = torch.empty(n, dtype=dtype, device=w.device)
+    assert out.numel() == n and out.dtype == dtype
+    check(_lib.load().mcgen_prep_weight_k(_f32(w.contiguous()), _p(out), _dt(dtype), cout, cin, ks, _f32(sigma), float(wscale), _stream()),
+          'prep_weight_k')
+    return out
+
+
 def weight_image_elems(cout: int, cin: int, ksize: int, transpose: bool = False) -> int:
     return int(_lib.load().mcgen_weight_image_elems(cout, cin, ksize, int(transpose)))
 
@@ -230,8 +266,9 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
                gscale: Optional[Tensor] = None, gshift: Optional[Tensor] = None,
                gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
                tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
-               out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None)."""
+               out: Optional[Tensor] = None, kmajor: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None).  `kmajor`: `wimg` is the K-major image
+    (prep_weight_k, segments concatenated) and every segment carries a compaction map: the mode-compacted kernel."""
     s0 = segs[0]
     n = s0.x.shape[0]
     h = s0.x.shape[1] * (2 if s0.ups else 1)
@@ -250,7 +287,10 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         s.fill(p.seg[i])
     if wimg.dtype != dtype:
         raise _lib.McgenError(f'weight image dtype {wimg.dtype} != activation dtype {dtype}')
-    need = sum(((s.x.shape[-1] + 31) // 32) * s.ksize * s.ksize for s in segs) * pad16(cout) * 32
+    if kmajor:
+        need = sum(s.ksize * s.ksize * (s.x.shape[-1] + 1) for s in segs) * pad16(cout)
+    else:
+        need = sum(((s.x.shape[-1] + 31) // 32) * s.ksize * s.ksize for s in segs) * pad16(cout) * 32
     if wimg.numel() != need:
         raise _lib.McgenError(f'weight image has {wimg.numel()} elements, the segments need {need}')
     y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=dtype, device=s0.x.device)
@@ -267,6 +307,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     p.res, p.ocode, p.gate_x = _p(res), _f32(ocode), _p(gate_x)
     p.gscale, p.gshift, p.gmean, p.grstd = _f32(gscale), _f32(gshift), _f32(gmean), _f32(grstd)
     p.tanh_out, p.stats_mode = int(tanh), stats_mode
+    p.w_layout = int(kmajor)
     stats = None
     lib = _lib.load()
     if stats_mode:
@@ -278,7 +319,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     def _name():
         bm, bn = C.c_int(), C.c_int()
         lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
-        base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}>'
+        base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{",mc" if kmajor else ""}>'
         if _os.environ.get('MCGEN_PROF_SHAPES'):
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')
@@ -595,13 +636,16 @@ class PrepBatch:
         self.dtype = dtype
         self.jobs = jobs
         arr = (_lib.Prep * len(jobs))()
-        for d, (w, img, transpose, row_perm, sidx, wscale) in zip(arr, jobs):
+        for d, job in zip(arr, jobs):
+            w, img, transpose, row_perm, sidx, wscale = job[:6]
+            kmajor = bool(job[6]) if len(job) > 6 else False          # K-major image (mode-compacted launches)
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
-            assert img.numel() == weight_image_elems(cout, cin, ks, transpose) and img.dtype == dtype
+            want = weight_image_k_elems(cout, cin, ks) if kmajor else weight_image_elems(cout, cin, ks, transpose)
+            assert img.numel() == want and img.dtype == dtype and not (kmajor and (transpose or row_perm != 1))
             d.w, d.image = _f32(w), _p(img)
             d.Cout, d.Cin, d.ksize, d.transpose, d.row_perm, d.sigma_idx = cout, cin, ks, int(transpose), row_perm, sidx
-            d.wscale = float(wscale)
+            d.wscale, d.layout = float(wscale), int(kmajor)
         self.key = tuple((w.data_ptr(), img.data_ptr()) for w, img, *_ in jobs)
         self.table = _struct_table(arr, jobs[0][0].device)
         self.n = len(jobs)

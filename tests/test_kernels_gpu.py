@@ -721,3 +721,129 @@ def test_grouped_batchnorm_pass_equals_separate_passes(dtype):
     sc1 = torch.ones(2, 16, device='cuda')
     with pytest.raises(_lib.McgenError):
         ops.conv_fused([ops.Seg(z, ksize=1, scale=sc1, shift=sc1, group_n=4)], ops.prep_weight((_rnd(g, 32, 16, 1, 1)).cuda(), dtype), 32)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# Mode-compacted convolutions (conv_fused.hip "mc" form): the K loop visits only the channels whose
+# MultimodalController code is non-zero (modules.py:58-76: controller_rate 0.5 zeroes half of them per sample).
+def test_cmap_and_kmajor_image_layout():
+    ops = _ops()
+    g = torch.Generator().manual_seed(901)
+    n, c = 7, 72
+    code = (torch.rand(n, c, generator=g) < 0.5).float() * (1 + torch.rand(n, c, generator=g))
+    code[2] = 0.0                                            # a sample with no active channel
+    code[3] = 1.0                                            # and one with all of them
+    cm = ops.mc_cmap(code.cuda()).cpu().numpy()
+    stride = ops.cmap_stride(c)
+    assert cm.shape == (n, stride) and stride % 8 == 0
+    nd = (c + 31) // 32
+    for i in range(n):
+        act = np.nonzero(code[i].numpy())[0]
+        cpos = np.full(c, -1); cpos[act] = np.arange(len(act))
+        assert np.array_equal(cm[i, :c], cpos)
+        cidx = cm[i, c:2 * c + 32]
+        assert np.array_equal(cidx[:len(act)], act) and np.all(cidx[len(act):] == c)
+        cpre = cm[i, 2 * c + 32:2 * c + 32 + 2 * (nd + 1)].copy().view(np.int32)
+        assert np.array_equal(cpre, [int((act < 32 * d).sum()) for d in range(nd)] + [len(act)])
+    w = _rnd(g, 20, 11, 3, 3)
+    sig = torch.tensor([1.7])
+    img = ops.prep_weight_k(w.cuda(), torch.float32, sigma=sig.cuda(), wscale=0.5).cpu().view(9, 17, 32)
+    ref = torch.zeros(9, 17, 32)
+    ref[:, :11, :20] = (w * 0.5 / 1.7).permute(2, 3, 1, 0).reshape(9, 11, 20)
+    np.testing.assert_allclose(img.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+    assert float(img[:, 16].abs().max()) == 0.0             # the zero row padded K slots point at
+
+
+def _mc_segments(ops, xs, scales, shifts, codes, upss, relus, ksizes, dtype):
+    segs_d, segs_c = [], []
+    for x, sc, sh, cd, up, rl, ks in zip(xs, scales, shifts, codes, upss, relus, ksizes):
+        xt = _nhwc(ops, x, dtype)
+        kw = dict(ksize=ks, scale=None if sc is None else sc.cuda(), shift=None if sh is None else sh.cuda(), code=cd.cuda(), ups=up, relu=rl)
+        segs_d.append(ops.Seg(xt, **kw))
+        segs_c.append(ops.Seg(xt, cmap=ops.mc_cmap(cd.cuda()), **kw))
+    return segs_d, segs_c
+
+
+def _assert_bf16_twin(a, b, what):
+    """Two bf16 results of the same fp32 sums taken in a different order: equal up to one bf16 ulp on a few elements."""
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = 2.0 ** -7 * b.abs() + 2e-3 * float(b.abs().max())
+    assert bool((err <= tol).all()), f'{what}: max err {float(err.max()):.3e}'
+    assert float((err > 0).float().mean()) < 0.2, f'{what}: {float((err > 0).float().mean()):.3f} of the elements differ'
+
+
+MC_CASES = [
+    # N, H(out), Cin, Cout, ups, tile
+    (128, 32, 256, 256, True, (256, 256)),      # G block 2 conv_a
+    (128, 16, 256, 256, True, (128, 256)),      # G block 1 conv_a in the generator update (N = 128)
+    (640, 16, 256, 256, True, (256, 256)),      # ... in the grouped pass of the discriminator updates (5 N images)
+    (256, 32, 128, 128, False, (128, 128)),     # D's 128-channel layers, paired pass
+    (32, 32, 200, 72, False, (128, 128)),       # ragged: 200 channels (6.25 chunks), 72 outputs (partial N tile)
+]
+
+
+@pytest.mark.parametrize('case', MC_CASES)
+def test_mode_compacted_conv_matches_dense_and_reference(case):
+    ops = _ops()
+    dtype = torch.bfloat16
+    n, h, ci, co, ups, tile = case
+    g = torch.Generator().manual_seed(911 + n + h + ci)
+    hs = h // 2 if ups else h
+    x = _rnd(g, n, ci, hs, hs)
+    scale, shift = _rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3
+    code = (torch.rand(n, ci, generator=g) < 0.5).float()
+    code[0] = 0.0; code[1] = 1.0                            # no active channel / all active
+    code[n // 2:] *= 1.25                                   # the paired pass scales the fake half's codes
+    code[2, : ci // 2] = 0.0; code[2, ci // 2:] = 1.0       # a block pattern: whole dense chunks without a slot
+    wt, b = _rnd(g, co, ci, 3, 3) * 0.03, _rnd(g, co)
+    segs_d, segs_c = _mc_segments(ops, [x], [scale], [shift], [code], [ups], [True], [3], dtype)
+    (yd, std), _ = _conv_logged(ops, segs_d, ops.prep_weight(wt.cuda(), dtype), co, bias=b.cuda(), stats_mode=1)
+    (yc, stc), tiles = _conv_logged(ops, segs_c, ops.prep_weight_k(wt.cuda(), dtype), co, bias=b.cuda(), stats_mode=1, kmajor=True)
+    assert tiles == [tile], tiles
+    _assert_bf16_twin(yc, yd, 'compacted vs dense')
+    np.testing.assert_allclose(stc.double().sum(0).cpu(), std.double().sum(0).cpu(), rtol=2e-4, atol=1e-2)
+    if n <= 256:
+        a = _q(ref_prologue(_q(x, dtype), scale, shift, True, code, ups), dtype)
+        ref = F.conv2d(a, _q(wt, dtype), b, padding=1)
+        _assert_close(ops.to_nchw(yc, co), ref, dtype, 'compacted vs fp32 reference')
+
+
+@pytest.mark.parametrize('n,h,t', [(128, 32, (256, 256)), (128, 16, (128, 256))])
+def test_mode_compacted_conv_b_two_segments(n, h, t):
+    """G.conv_b: conv3x3(BN/ReLU/MC2(h)) + conv1x1(MC1(Up(x))): two segments, each with its own compaction map."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(931 + h)
+    c, hs = 256, h // 2
+    h_in, x = _rnd(g, n, c, h, h), _rnd(g, n, c, hs, hs)
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code1 = (torch.rand(n, c, generator=g) < 0.5).float()
+    code2 = (torch.rand(n, c, generator=g) < 0.5).float()
+    code1[3] = 0.0
+    w2, ws, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c, c, 1, 1) * 0.08, _rnd(g, c)
+    segs_d, segs_c = _mc_segments(ops, [h_in, x], [scale, None], [shift, None], [code2, code1], [False, True], [True, False], [3, 1], dtype)
+    img_d = torch.cat([ops.prep_weight(w2.cuda(), dtype), ops.prep_weight(ws.cuda(), dtype)])
+    img_c = torch.cat([ops.prep_weight_k(w2.cuda(), dtype), ops.prep_weight_k(ws.cuda(), dtype)])
+    yd, _ = ops.conv_fused(segs_d, img_d, c, bias=b.cuda())
+    (yc, _), tiles = _conv_logged(ops, segs_c, img_c, c, bias=b.cuda(), kmajor=True)
+    assert tiles == [t], tiles
+    _assert_bf16_twin(yc, yd, 'compacted conv_b vs dense')
+    a2 = _q(ref_prologue(_q(h_in, dtype), scale, shift, True, code2, False), dtype)
+    a1 = _q(ref_prologue(_q(x, dtype), None, None, False, code1, True), dtype)
+    ref = F.conv2d(a2, _q(w2, dtype), b, padding=1) + F.conv2d(a1, _q(ws, dtype))
+    _assert_close(ops.to_nchw(yc, c), ref, dtype, 'compacted conv_b vs fp32 reference')
+
+
+def test_mode_compacted_conv_rejects_what_it_cannot_run():
+    from mcgen_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(941)
+    x = _rnd(g, 4, 64, 8, 8)
+    code = (torch.rand(4, 64, generator=g) < 0.5).float()
+    wk = ops.prep_weight_k((_rnd(g, 64, 64, 3, 3) * 0.1).cuda(), torch.bfloat16)
+    xt = _nhwc(ops, x, torch.bfloat16)
+    with pytest.raises(_lib.McgenError):                    # 8x8 maps: no 128-pixel tile inside one image
+        ops.conv_fused([ops.Seg(xt, code=code.cuda(), cmap=ops.mc_cmap(code.cuda()))], wk, 64, kmajor=True)
+    with pytest.raises(_lib.McgenError):                    # a K-major launch without a map
+        ops.conv_fused([ops.Seg(xt, code=code.cuda())], wk, 64, kmajor=True)
