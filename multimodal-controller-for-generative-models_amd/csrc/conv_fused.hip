@@ -824,7 +824,7 @@ static __device__ __forceinline__ s16x4 mc_tr16(const char* p) {
         (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool MC_PREFETCH>
 __global__ __launch_bounds__(64 * WM * WN)
 void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
     using T = bf16_t;
@@ -966,6 +966,17 @@ void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
         int consumed = 0;                                  // compacted slots the MFMA steps have used (multiple of 32)
         int filled = 0;
         int filled_next = (int)mc_sload(cpre + 2);       // cpre[1], fetched one chunk ahead of its use
+        // The window loads of the NEXT dense chunk are issued inside the current K step (behind its first weight DMA), so
+        // their round trip runs under the step's MFMAs; `have_raw` says the registers already hold chunk dq's window.
+        typename PatchStager<T, NT, NI, APITCH>::raw_t raw;
+        u32x4 cp4 = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        bool have_raw = false;
+        const int csub = stager.it_sub[0];
+        auto fetch = [&](int cq) {                         // window + compaction positions of dense chunk cq
+            stager.load(sg, cq * MCGEN_CK, raw);
+            cp4 = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (cq * MCGEN_CK + csub < Cs) cp4 = *reinterpret_cast<const u32x4*>(rec + cq * MCGEN_CK + csub);
+        };
 #pragma unroll 1
         for (int dq = 0; dq < nd && cnt > 0; ++dq) {
             const int c0 = dq * MCGEN_CK;
@@ -973,15 +984,14 @@ void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
             filled = filled_next;
             if (dq + 2 <= nd) filled_next = (int)mc_sload(cpre + 2 * (dq + 2));
             const bool last = (dq == nd - 1);
+            const bool next_live = !last && filled_next > filled;          // chunk dq + 1 has active channels
             if (filled > filled0) {
                 __builtin_amdgcn_s_barrier();              // everyone is past the window reads of the previous K step
                 // ---- stage dense chunk dq: loads, prologue, scatter to the compacted positions ---------------------
-                typename PatchStager<T, NT, NI, APITCH>::raw_t raw;
-                stager.load(sg, c0, raw);
-                const int c = c0 + stager.it_sub[0];
+                if (!have_raw) fetch(dq);
+                have_raw = false;
+                const int c = c0 + csub;
                 const bool cok = c < Cs;
-                u32x4 cp4 = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-                if (cok) cp4 = *reinterpret_cast<const u32x4*>(rec + c);             // cpos of this thread's 8 channels
                 float sc[8], sh[8], cd[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; cd[i] = 1.f; }
@@ -1001,7 +1011,7 @@ void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
                     float v[8];
                     PatchStager<T, NT, NI, APITCH>::unpack(raw[k], v);
                     const bool inside = stager.it_src[k] >= 0 && cok;
-                    char* px = ldsA + (stager.it_lds[k] - stager.it_sub[0] * 2);      // the window pixel's first slot
+                    char* px = ldsA + (stager.it_lds[k] - csub * 2);                  // the window pixel's first slot
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         float a = 0.f;
@@ -1024,6 +1034,7 @@ void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's window writes are in LDS
                     __builtin_amdgcn_s_barrier();
                     G_dma(gi + 1);                        // slot (gi+1)&1: its readers (group gi-1) passed the barrier
+                    if (MC_PREFETCH && gq == 0 && next_live && !have_raw) { fetch(dq + 1); have_raw = true; }
                     const char* slot = ldsB0 + (gi & 1) * SLOT;
 #pragma unroll
                     for (int t = 0; t < TPS; ++t) {
@@ -1255,10 +1266,18 @@ static int launch_mc(const mcgen_conv_t* p, hipStream_t st) {
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(mc): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
-    auto kern = conv_mc_kernel<BM, BN, WM, WN>;
-    static int raised = 0;
-    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised)) return rc;
-    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    // window loads of the next dense chunk prefetched across the K step (tuning builds can switch it off)
+    static const bool prefetch = env_long("MCGEN_MC_PREFETCH", 1) != 0;
+    static int raised = 0, raised0 = 0;
+    if (prefetch) {
+        auto kern = conv_mc_kernel<BM, BN, WM, WN, true>;
+        if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised)) return rc;
+        hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    } else {
+        auto kern = conv_mc_kernel<BM, BN, WM, WN, false>;
+        if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised0)) return rc;
+        hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    }
     MCGEN_LAUNCH_CHECK("conv_fused(mc)");
     return 0;
 }

@@ -88,6 +88,9 @@ class _BN:
 _PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
 _SN_FUSED = __import__('os').environ.get('MCGEN_SN_FUSED', '1') != '0'      # A/B switch: fused multi-round power iteration
 _BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # A/B switch: two gradient buckets per network
+# mode-compacted forward convolutions (bf16, maps >= 16x16, conv_a launches): opt-in -- measured x1.10 on those launches
+# (tools/bench_mc.py), about 0.5 % of the step after the map / K-major image launches are paid: see DESIGN.md section 4.6
+_MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -173,7 +176,15 @@ class GeneratorEngine:
                 jobs.append((wsc, cat[n2:], False, 1, -1, 1.0))
             jobs.append((head_conv.weight, buf('head', ops.weight_image_elems(head_conv.out_channels, head_conv.in_channels, 3), dt),
                          False, 1, -1, 1.0))
-            self._prep_fwd = ops.PrepBatch([(w.detach(), im, t, rp, si, sc) for w, im, t, rp, si, sc in jobs], dt)
+            if self._mc_enabled():
+                # K-major images of the blocks whose maps are large enough for a tile to lie inside one image (the
+                # mode-compacted kernel gathers the active channels' rows from them): conv_a, and conv_b ++ shortcut
+                for i, b in enumerate(res):
+                    if not self._mc_block(i):
+                        continue
+                    w1 = b.conv[4].module.weight
+                    jobs.append((w1, buf(f'b{i}.w1k', ops.weight_image_k_elems(w1.shape[0], w1.shape[1], 3), dt), False, 1, -1, 1.0, True))
+            self._prep_fwd = ops.PrepBatch([(j[0].detach(),) + tuple(j[1:]) for j in jobs], dt)
         self._prep_fwd.run()
         buf('lin_bias', lin.out_features, torch.float32).view(16, c0).copy_(lin.bias.detach().view(c0, 16).t())
         for i, b in enumerate(res):
@@ -201,6 +212,17 @@ class GeneratorEngine:
                 tbuf(f'b{i}.ws', b.shortcut[2].module.weight)
             self._prep_bwd = ops.PrepBatch(jobs, dt)
         self._prep_bwd.run()
+
+    # ---- mode-compacted convolutions ---------------------------------------------------------------
+    def _mc_enabled(self) -> bool:
+        return _MC and self.dtype == torch.bfloat16
+
+    def _mc_block(self, i: int) -> bool:
+        """Block i's convolutions run at side 8 * 2^i: from 16x16 up a 128- or 256-pixel tile lies inside one image, and
+        the channel counts must suit the kernel (multiples of 8, at least 64 outputs)."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        c1 = res[i].conv[4].module
+        return self._mc_enabled() and (8 << i) >= 16 and c1.out_channels >= 64 and c1.in_channels % 8 == 0 and c1.out_channels % 8 == 0
 
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:
@@ -250,9 +272,14 @@ class GeneratorEngine:
             bn1 = _bn_forward(b.conv[0].module, st, ng * s * s, train, fold, groups)
             fold = 1
             co = b.conv[4].module.out_channels
-            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True, group_n=gn)
-            h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1'], co, bias=b.conv[4].module.bias, stats_mode=st_mode)
+            # large maps: the K loop visits only each sample's active channels (mode-compacted kernel, K-major images)
+            mc = self._mc_block(i) and f'b{i}.w1k' in self.img
+            cm1 = ops.mc_cmap(code1) if mc else None
+            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True, group_n=gn, cmap=cm1)
+            h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1k' if mc else f'b{i}.w1'], co, bias=b.conv[4].module.bias,
+                                     stats_mode=st_mode, kmajor=mc)
             bn2 = _bn_forward(b.conv[5].module, st_h, ng * 4 * s * s, train, 1, groups)
+            # (conv_b ++ 1x1 shortcut stays dense: the shortcut's one-tap K steps cost more than compaction saves, x0.97)
             seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)
             seg_s = Seg(x, ksize=1, code=code1, ups=True)
             y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],

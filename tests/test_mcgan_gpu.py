@@ -433,3 +433,37 @@ def test_grouped_generator_passes_match_per_update_passes():
             elif k.startswith('discriminator.'):
                 assert float((sd[k] - v).abs().max()) <= 5e-4 * float(v.abs().max()) + 1e-5, k
     assert int(ref_sd['generator.blocks.0.conv.0.module.num_batches_tracked']) == 6
+
+
+def test_mode_compacted_generator_matches_dense():
+    """MCGEN_MC: the generator's conv_a launches on 16x16 / 32x32 maps through the mode-compacted kernel (K loop over
+    each sample's active channels only) against the dense path, same state / latents / batch, bf16 at N = 128: generated
+    batch to a bf16 rounding step, one whole train iteration to the bf16 loss bound."""
+    from mcgen_amd import gan_engine as GE, trainer as T
+    sd = gu.procedural_state(gu.mcgan_shapes([256] * 4, [128] * 4, 10), seed=1234, num_mode=10)
+    img, lab = gu.synthetic_batch(128, 10, seed=1)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(6, 128, 128, seed=2)]
+
+    def run(mc):
+        old = GE._MC
+        GE._MC = mc
+        try:
+            m = _build([256] * 4, [128] * 4, 10, 'CIFAR10', sd, torch.bfloat16)
+            m.train(True)
+            from mcgen_amd import ops
+            ops.TILE_LOG = []
+            with torch.no_grad():
+                gen = m.generate(lab, zs[0])
+            tiles = list(ops.TILE_LOG); ops.TILE_LOG = None
+            m.load_state_dict(sd)
+            losses = T.GANTrainer(m, 10).train_iteration(img, lab, zs)
+            return gen.float().cpu(), (float(losses[0]), float(losses[1])), tiles
+        finally:
+            GE._MC = old
+    gen_d, l_d, _ = run(False)
+    gen_c, l_c, tiles = run(True)
+    assert float((gen_c - gen_d).abs().max()) < 2e-2 and float((gen_c - gen_d).abs().mean()) < 1e-3
+    np.testing.assert_allclose(l_c, l_d, rtol=0, atol=2e-2)
+    d = gu.load_npz('mcgan_full_digest_b128.npz')
+    np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
