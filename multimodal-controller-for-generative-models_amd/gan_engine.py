@@ -86,8 +86,10 @@ class _BN:
 
 
 _PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
-_SN_FUSED = __import__('os').environ.get('MCGEN_SN_FUSED', '1') != '0'      # A/B switch: fused multi-round power iteration
-_BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # A/B switch: two gradient buckets per network
+# one-launch multi-round power iteration (mcgen_sn_power_iter_fused): opt-in -- one workgroup per layer streams W through a
+# single CU and measured 0.08 ms / iteration SLOWER than the four row-sliced kernels that fill the chip (tools/ab_bench.sh)
+_SN_FUSED = __import__('os').environ.get('MCGEN_SN_FUSED', '0') == '1'
+_BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # two gradient buckets per network (callers ask for them only when world > 1)
 # mode-compacted forward convolutions (bf16, maps >= 16x16, conv_a launches): opt-in -- measured x1.10 on those launches
 # (tools/bench_mc.py), about 0.5 % of the step after the map / K-major image launches are paid: see DESIGN.md section 4.6
 _MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
@@ -299,7 +301,7 @@ class GeneratorEngine:
     def backward(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
         """dimg: [N, C, H, W] fp32.  Writes (or adds) every generator parameter's gradient into
         `gflat`, a flat fp32 buffer laid out like ``flat_p``."""
-        for _ in self.backward_iter(ctx, dimg, gflat, accumulate):
+        for _ in self.backward_iter(ctx, dimg, gflat, accumulate, split=False):
             pass
 
     def bucket_cut(self) -> int:
@@ -308,8 +310,8 @@ class GeneratorEngine:
         lin, res, head_bn, head_mc, head_conv = self._layers()
         return max(1, len(res) // 2) if len(res) > 1 else 0
 
-    def backward_iter(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
-        """As `backward`, as a generator: yields (lo, hi) each time gflat[lo:hi] is final -- the head and the late
+    def backward_iter(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False, split: bool = True):
+        """As `backward`, as a generator (`split` False: one bucket, handed out at the end): yields (lo, hi) each time gflat[lo:hi] is final -- the head and the late
         blocks mid-pass, the early blocks and the Linear layer at the end."""
         if not ctx['train']:
             raise RuntimeError('generator backward needs a training-mode forward (batch statistics)')
@@ -365,9 +367,9 @@ class GeneratorEngine:
                                             gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)
                 dy = ops.bn_backward(part1, dz1, x, bn1.count, bn1.scale, bn1.mean, bn1.rstd,
                                      G(bnm1.weight), G(bnm1.bias), add=dx_sc, accumulate=acc)
-                if i == cut and cut > 0:
+                if i == cut and cut > 0 and _BUCKETS and split:
                     red.__exit__(None, None, None)           # head + blocks cut .. last are final
-                    if _BUCKETS:
+                    if _BUCKETS and split:
                         yield (off_cut, gflat.numel(), False)
                     red = ops.deferred_reduces()
                     red.__enter__()
@@ -380,7 +382,7 @@ class GeneratorEngine:
             red.__exit__(type(e), e, None)
             raise
         red.__exit__(None, None, None)
-        yield (0, off_cut if (cut > 0 and _BUCKETS) else gflat.numel(), True)
+        yield (0, off_cut if (cut > 0 and _BUCKETS and split) else gflat.numel(), True)
 
 
 # ============================================================================================= #
@@ -618,7 +620,7 @@ class DiscriminatorEngine:
     # ---- backward ----------------------------------------------------------------------------------
     def backward(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
         """Runs `backward_iter` to its end; returns d(input image) as NCHW fp32, or None."""
-        it = self.backward_iter(ctx, dlogit, gflat, accumulate, need_input_grad)
+        it = self.backward_iter(ctx, dlogit, gflat, accumulate, need_input_grad, split=False)
         while True:
             try:
                 next(it)
@@ -655,8 +657,9 @@ class DiscriminatorEngine:
             self._bk_key = key
         return self._bk
 
-    def backward_iter(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool):
-        """dlogit [N] fp32.  Parameter gradients (w.r.t. weight_orig and the biases) are written or
+    def backward_iter(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool,
+                      split: bool = True):
+        """dlogit [N] fp32.  (`split` False: one gradient bucket, handed out at the end.)  Parameter gradients (w.r.t. weight_orig and the biases) are written or
         added into `gflat` (flat, laid out like ``flat_p``; None skips them, e.g. in the generator
         step).  A generator: yields (lo, hi) each time gflat[lo:hi] is final -- the late bucket (tail + blocks
         bucket_cut() ..) mid-pass, the early bucket at the end -- and returns d(input image) as NCHW fp32, or None.
@@ -749,11 +752,11 @@ class DiscriminatorEngine:
                 else:
                     res = dy
                 dy, _ = ops.conv_fused([Seg(dc1)], I[f'{bi}.c1t'], c1m.cin, ocode=code1, gate_x=x, res=res)
-                if want_w and bi == cut:
+                if want_w and bi == cut and _BUCKETS and split:
                     # blocks cut .. last and the tail are done: reduce their slabs, fix them up, hand the bucket out
                     red.__exit__(None, None, None)
                     fix(bk['hi'], bk['i_cut'])
-                    if _BUCKETS:
+                    if _BUCKETS and split:
                         yield (bk['off_cut'], fp.numel(), False)
                     red = ops.deferred_reduces()
                     red.__enter__()
@@ -779,6 +782,8 @@ class DiscriminatorEngine:
             raise
         red.__exit__(None, None, None)
         if want_w:
+            if not (_BUCKETS and split):
+                fix(bk['hi'], bk['i_cut'])          # single bucket: the late layers were not fixed up mid-pass
             fix(bk['lo'], 0)
-            yield ((0, bk['off_cut'], True) if _BUCKETS else (0, fp.numel(), True))
+            yield ((0, bk['off_cut'], True) if (_BUCKETS and split) else (0, fp.numel(), True))
         return dimg

@@ -1,0 +1,51 @@
+"""Inception Score and Frechet Inception Distance from feature / probability tensors, on the device
+(reference: src/metrics/metrics.py:44-161).
+
+The reference pushes generated images through a feature network -- torchvision's pre-trained `inception_v3`
+(metrics.py:64-73,116-127; weights are downloaded, which this environment cannot do) or, for COIL100 / Omniglot, the
+small `models.classifier()` (metrics.py:49-62,89-113) -- then moves everything to NumPy / SciPy on the host:
+`np.cov`, `scipy.linalg.sqrtm` of a 2048 x 2048 product (seconds of single-thread LAPACK per evaluation), `F.kl_div`
+over the class probabilities.  This module is the part behind the network: the same statistics from tensors that stay in
+HBM, in float64.  tr sqrt(S1 S2) is taken as the sum of the square roots of the eigenvalues of S1^(1/2) S2 S1^(1/2)
+(symmetric positive semi-definite, so `eigh` applies) -- the quantity sqrtm's trace gives, without complex arithmetic.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def inception_score_from_probs(pred: torch.Tensor, splits: int = 1) -> float:
+    """metrics.py:75-82: pred [N, classes] softmax outputs -> mean over splits of exp(mean_n KL(p(y|x_n) || p(y)))."""
+    n = pred.shape[0]
+    pred = pred.to(torch.float64)
+    scores = []
+    for k in range(splits):
+        part = pred[k * (n // splits):(k + 1) * (n // splits)]
+        py = part.mean(0, keepdim=True)
+        # F.kl_div(log py, part, 'batchmean') = sum part * (log part - log py) / rows, with 0 log 0 = 0
+        kl = torch.where(part > 0, part * (part.clamp_min(1e-300).log() - py.log()), torch.zeros_like(part)).sum() / part.shape[0]
+        scores.append(kl.exp())
+    return float(torch.stack(scores).mean())
+
+
+def _cov(x: torch.Tensor):
+    x = x.to(torch.float64)
+    mu = x.mean(0)
+    xc = x - mu
+    return mu, xc.t() @ xc / (x.shape[0] - 1)                      # np.cov(rowvar=False): unbiased
+
+
+def _sqrt_psd(a: torch.Tensor):
+    w, v = torch.linalg.eigh((a + a.t()) * 0.5)
+    return (v * w.clamp_min(0).sqrt()) @ v.t()
+
+
+def fid_from_features(real: torch.Tensor, generated: torch.Tensor) -> float:
+    """metrics.py:139-161: |mu1 - mu2|^2 + tr S1 + tr S2 - 2 tr sqrt(S1 S2), features [N, D] each."""
+    mu1, s1 = _cov(real)
+    mu2, s2 = _cov(generated)
+    r1 = _sqrt_psd(s1)
+    m = r1 @ s2 @ r1
+    tr_covmean = torch.linalg.eigvalsh((m + m.t()) * 0.5).clamp_min(0).sqrt().sum()
+    diff = mu1 - mu2
+    return float(diff @ diff + torch.trace(s1) + torch.trace(s2) - 2 * tr_covmean)

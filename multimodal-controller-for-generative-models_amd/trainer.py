@@ -172,13 +172,13 @@ class GANTrainer:
             n = img.shape[0]
             lg = logits.view(-1)
             self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
-            yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False)
+            yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False, split=self.world > 1)
             return
         d_real, ctx_r = self.deng.forward(img, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
         self.loss_d, dreal, dfake = ops.hinge_d(d_real.view(-1), d_fake.view(-1))
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
-        yield from self.deng.backward_iter(ctx_f, dfake, self.grad_d, True, False)     # final once the second pass added
+        yield from self.deng.backward_iter(ctx_f, dfake, self.grad_d, True, False, split=self.world > 1)   # final once the second pass added
 
     def d_compute(self, img, ind, fake, ind2=None):
         for _ in self.d_compute_iter(img, ind, fake, ind2):
@@ -193,7 +193,7 @@ class GANTrainer:
         d_fake, dctx = self.deng.forward(fake, ind, True)
         self.loss_g, dfake = ops.hinge_g(d_fake.view(-1))
         dimg = self.deng.backward(dctx, dfake, None, False, True)
-        yield from self.geng.backward_iter(gctx, dimg, self.grad_g, False)
+        yield from self.geng.backward_iter(gctx, dimg, self.grad_g, False, split=self.world > 1)
 
     def g_compute(self, ind, z):
         for _ in self.g_compute_iter(ind, z):

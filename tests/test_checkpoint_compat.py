@@ -190,3 +190,27 @@ def test_driver_counterpart_runs_and_resumes(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'Resume from 2' in r.stdout and 'Train Epoch: 2' in r.stdout and 'Train Epoch: 1' not in r.stdout
     assert int(ck.load(path)['optimizer_dict']['discriminator']['state'][0]['step']) == 20
+
+
+def test_is_fid_statistics_match_the_reference_formulas():
+    """mcgen_amd.metrics against the NumPy / SciPy formulas of metrics.py:75-82 (IS) and :139-161 (FID)."""
+    import torch.nn.functional as F
+    from scipy import linalg
+    from mcgen_amd.metrics import fid_from_features, inception_score_from_probs
+    g = torch.Generator().manual_seed(5)
+    pred = torch.softmax(torch.randn(600, 40, generator=g) * 2, -1)
+    ref_scores = []
+    for k in range(3):
+        part = pred[k * 200:(k + 1) * 200]
+        py = part.mean(0)
+        ref_scores.append(F.kl_div(py.log().view(1, -1).expand_as(part), part, reduction='batchmean').exp())
+    assert abs(inception_score_from_probs(pred, 3) - float(np.mean(ref_scores))) < 1e-5
+    a = torch.randn(500, 48, generator=g) @ torch.randn(48, 48, generator=g)
+    b = torch.randn(400, 48, generator=g) @ torch.randn(48, 48, generator=g) + 0.3
+    mu1, mu2 = a.numpy().mean(0), b.numpy().mean(0)
+    s1, s2 = np.cov(a.numpy(), rowvar=False), np.cov(b.numpy(), rowvar=False)
+    covmean, _ = linalg.sqrtm(s1.dot(s2), disp=False)
+    ref = (mu1 - mu2).dot(mu1 - mu2) + np.trace(s1) + np.trace(s2) - 2 * np.trace(covmean.real)
+    got = fid_from_features(a, b)
+    assert abs(got - ref) < 1e-6 * abs(ref) + 1e-6, (got, ref)
+    assert abs(fid_from_features(a, a)) < 1e-6 * float(np.trace(s1))
