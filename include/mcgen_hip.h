@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 3: + mcgen_seg_t.cmap, mcgen_conv_t.w_layout (mode-compacted convolutions) */
+int mcgen_abi_version(void);      /* 4: + compacted activations between forward-only launches (ycmap, Cw, w_layout 2) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -58,6 +58,9 @@ typedef struct {
                            * image n is normalised with row n / group_n of scale / shift.  0: one batch.
                            * Convolution launches only (mcgen_wgrad requires 0); a tile never straddles groups. */
     int32_t cmap_stride;  /* int16 elements per sample record of cmap                 */
+    int32_t Cw;           /* w_layout 2 only: channels of the segment's WEIGHTS (rows of its K-major image, without the
+                           * zero row) when x holds compacted channels (C < Cw); 0: Cw = C                         */
+    int32_t reserved_;
 } mcgen_seg_t;
 
 /* Fused convolution  y = epilogue( sum_seg conv(prologue_seg(x_seg), W_seg) ).
@@ -97,8 +100,18 @@ typedef struct {
     float*  stats;         /* [m_tiles][2][Cy] partial sums, or NULL                       */
     int32_t stats_mode;
     int32_t w_layout;      /* 0: `w` is the [chunk][tap][cout][32] image of mcgen_prep_weight;
-                            * 1: the K-major image of mcgen_prep_weight_k (mode-compacted launches:
-                            *    every segment carries a cmap)                                     */
+                            * 1: the K-major image of mcgen_prep_weight_k, activations compacted while they are
+                            *    staged (every segment carries a cmap);
+                            * 2: K-major image, activations ALREADY compacted by the producing launch's ycmap
+                            *    (segment: C = compacted pitch, Cw = weight channels, cmap = row gather; a segment
+                            *    without a map is dense)                                           */
+    const int16_t* ycmap;  /* compacted OUTPUT: channel slot j of a pixel of image n receives true channel cidx_n[j] of the
+                            * map of the CONSUMER's code (zeros beyond its active count); y has pitch Cy (a multiple of 32
+                            * that holds every sample's active channels); stats keep covering all true channels, pitch
+                            * Cout_w.  Forward-only passes: needs pool = 0, no res / gate_x / ocode, tiles inside one image,
+                            * one channel tile.  NULL: dense output.                              */
+    int32_t ycmap_stride;
+    int32_t reserved_;
 } mcgen_conv_t;
 
 /* number of M tiles (rows of `stats`) the launch of `p` will use */
@@ -193,6 +206,13 @@ int mcgen_prep_weight_k(const float* w, void* image, int dtype, int Cout, int Ci
  *     cidx[C + 32]  the active channels in order, padded with C (the K-major image's zero row)
  *     cpre[C/32+1]  (int32 entries) number of active channels below each 32-channel boundary; the last = their count
  * modules.py:71-76: out = x * code -- a zero code entry removes the channel from every product that follows. */
+/* Per-image prologue rows for a launch that reads COMPACTED activations (w_layout 2): for image n and slot j with
+ * c = cidx_n[j]:  scale_out[n][j] = (scale ? scale[n / group_n][c] : 1) * code[n][c],  shift_out likewise (0 without
+ * scale); slots beyond the image's active count get 0.  relu(bn(x)) * code == relu(x * scale_out + shift_out) because
+ * MultimodalController codes are non-negative (modules.py:58-69).  Pass the rows as the segment's scale / shift with
+ * group_n = 1 and no code. */
+int mcgen_mc_affine(const float* scale, const float* shift, int group_n, const float* code, const int16_t* cmap,
+                    int N, int C, int Ccap, float* scale_out, float* shift_out, void* stream);
 int32_t mcgen_cmap_stride(int C);
 int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream);
 

@@ -13,7 +13,7 @@ F32, BF16 = 0, 1
 class Seg(C.Structure):
     _fields_ = [('x', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('code', C.c_void_p), ('cmap', C.c_void_p),
                 ('C', C.c_int32), ('ups', C.c_int32), ('relu', C.c_int32), ('ksize', C.c_int32),
-                ('group_n', C.c_int32), ('cmap_stride', C.c_int32)]
+                ('group_n', C.c_int32), ('cmap_stride', C.c_int32), ('Cw', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class Conv(C.Structure):
@@ -24,7 +24,8 @@ class Conv(C.Structure):
                 ('pool', C.c_int32), ('alpha', C.c_float),
                 ('res', C.c_void_p), ('ocode', C.c_void_p), ('gate_x', C.c_void_p),
                 ('gscale', C.c_void_p), ('gshift', C.c_void_p), ('gmean', C.c_void_p), ('grstd', C.c_void_p),
-                ('tanh_out', C.c_int32), ('stats', C.c_void_p), ('stats_mode', C.c_int32), ('w_layout', C.c_int32)]
+                ('tanh_out', C.c_int32), ('stats', C.c_void_p), ('stats_mode', C.c_int32), ('w_layout', C.c_int32),
+                ('ycmap', C.c_void_p), ('ycmap_stride', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class Wgrad(C.Structure):
@@ -111,6 +112,7 @@ SYMBOLS = {
     'mcgen_prep_weight_ex_batch': (_i, [_vp, _i, _i, _vp]),
     'mcgen_weight_image_k_elems': (_i64, [_i, _i, _i]),
     'mcgen_prep_weight_k': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp]),
+    'mcgen_mc_affine': (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mcgen_cmap_stride': (C.c_int32, [_i]),
     'mcgen_mc_cmap': (_i, [_vp, _i, _i, _vp, _vp]),
     'mcgen_prep_weight_batch': (_i, [_vp, _i, _vp, _i, _vp]),

@@ -54,7 +54,10 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const int ch = tid % CH, prow = tid / CH;
     const int co = cout0 + ch * 8;             // first channel of this thread's chunk
     const int Ho = p.pool ? (H >> 1) : H, Wo = p.pool ? (W >> 1) : W;
-    const bool chunk_live = co < p.Cy;
+    // compacted output (p.ycmap): y holds, per image, only the channels its consumer's MultimodalController keeps, in
+    // compacted order (pitch Cy); the statistics still cover every true channel (pitch Cout_w)
+    const int spitch = p.ycmap ? p.Cout_w : p.Cy;
+    const bool chunk_live = co < spitch;
     T* y = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* gx = reinterpret_cast<const T*>(p.gate_x);
@@ -162,7 +165,34 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
             }
-            E::store8(y + opix * p.Cy + co, v);
+            if (p.ycmap) {
+                float* e1 = epi + mo * EP + ch * 8;        // (pool == 0 here) hand the finished values back to the tile
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e1[i] = v[i];
+            } else {
+                E::store8(y + opix * p.Cy + co, v);
+            }
+        }
+        if (p.ycmap) {
+            // gather pass: output slot j of a pixel <- true channel cidx[j] of the tile's image (zeros beyond its count)
+            __syncthreads();
+            const int n = g.n0;
+            const int16_t* cidx = p.ycmap + (size_t)n * p.ycmap_stride + ((p.Cout + 7) & ~7);   // record: [cpos: C][cidx: C + 32]...
+            const int cgrp = p.Cy >> 3;
+            for (int u = tid; u < out_pp * cgrp; u += NT) {
+                const int mo = u / cgrp, jg = u - mo * cgrp;
+                const int mt = pass * out_pp + mo;
+                const int ro = mt >> lgWo, wo = mt & ((1 << lgWo) - 1);
+                const size_t opix = ((size_t)n * Ho + (g.h0 + ro)) * Wo + wo;
+                const u32x4 ci4 = *reinterpret_cast<const u32x4*>(cidx + jg * 8);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = (int)((i & 1) ? (ci4[i >> 1] >> 16) : (ci4[i >> 1] & 0xffffu)) - cout0;
+                    v[i] = (c >= 0 && c < BN && c + cout0 < p.Cout) ? epi[mo * EP + c] : 0.f;
+                }
+                if (n < N) E::store8(y + opix * p.Cy + jg * 8, v);
+            }
         }
     }
 
@@ -178,9 +208,9 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
         for (int c = tid; c < BN; c += NT) {
             float a = 0.f, b = 0.f;
             for (int r = 0; r < PROWS; ++r) { a += red[(r * BN + c) * 2]; b += red[(r * BN + c) * 2 + 1]; }
-            if (cout0 + c < p.Cy) {
-                p.stats[((size_t)tile_m * 2 + 0) * p.Cy + cout0 + c] = a;
-                p.stats[((size_t)tile_m * 2 + 1) * p.Cy + cout0 + c] = b;
+            if (cout0 + c < spitch) {
+                p.stats[((size_t)tile_m * 2 + 0) * spitch + cout0 + c] = a;
+                p.stats[((size_t)tile_m * 2 + 1) * spitch + cout0 + c] = b;
             }
         }
     }
@@ -307,6 +337,141 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "dma1" form: one tap per barrier, three single-tap slots ------------------------------------------------------
+// The weight ring holds three single taps (48 KB at 256 output channels instead of dma3's 96 KB), two taps ahead of
+// their use, one raw s_barrier per tap behind a counted vmcnt.  With a 128-pixel x 256-channel tile on FOUR waves
+// (one per SIMD, each 128 pixels x 64 channels: the same per-wave MFMA / fragment-read mix as the 256 x 256 tile) a
+// workgroup needs 68 KB of LDS, so TWO workgroups share a CU: one's window staging, barrier waits and epilogue run
+// under the other's MFMAs -- the overlap the one-workgroup-per-CU 256 x 256 tile cannot have.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 0)      // four-wave tiles: two workgroups (= two waves per SIMD) per CU
+void conv_dma1_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
+    constexpr int RB = 3, DIST = 2;                        // ring slots, prefetch distance (taps)
+    constexpr int NW = WM * WN;
+    constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
+    constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
+    static_assert(DIST == 2 && PPW <= 31, "counted vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    int total_steps = 0;
+    for (int s = 0; s < p.nseg; ++s)
+        total_steps += ((p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK) * p.seg[s].ksize * p.seg[s].ksize;
+
+    // DMA piece k of this wave: 1 KB = rows [16*ESZ/2 rows...]; lane -> (row, physical 16-byte unit)
+    constexpr int UPR = C::UPR;                            // 16-byte units per row (4 bf16 / 8 fp32)
+    constexpr int RPP = 64 / UPR;                          // rows per 1 KB piece
+    int d_src[PPW];                                        // per-lane source byte offset inside a weight block, -1 = zero rows
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int grp = pu / (ESZ / 2), within = pu % (ESZ / 2);
+        const int lgrp = grp ^ (3 * ((row >> 3) & 1));     // logical 8-channel group stored at this physical slot
+        d_src[k] = (piece < KB && cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + (lgrp * (ESZ / 2) + within) * 16 : -1;
+    }
+    auto B_dma = [&](int blk) {
+        if (blk >= total_steps) return;
+        const char* wb = wimg + (size_t)blk * wblock_bytes;
+        char* slot = ldsB0 + (blk % RB) * C::BBYTES;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = wave * PPW + k;
+            if (piece < KB) {
+                // rows beyond Cout_w read row 0 of the block (in bounds); their outputs are never stored
+                const char* src = wb + (d_src[k] >= 0 ? d_src[k] : (lane % UPR) * 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    int w_row_off[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int row = wn * (BN / WN) + fn * 16 + l15;
+        w_row_off[fn] = row * BROW + (lg ^ (3 * ((row >> 3) & 1))) * 8 * ESZ;
+    }
+
+    int blk = 0;
+    B_dma(0);
+    B_dma(1);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
+        const int halo = sg.ksize >> 1;
+        const int PR = g.TH + 2 * halo, PC = W + 2 * halo;
+        PatchStager<T, NT, C::NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int ti = m >> g.lgTHW, rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = ((ti * PR + r) * PC + c) * APITCH + lg * 8 * ESZ;
+        }
+        const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+        const int ntap = sg.ksize * sg.ksize;
+#pragma unroll 1
+        for (int q = 0; q < nchunk; ++q) {
+            // window of this chunk: everyone is past the previous chunk's reads (barrier), then publish
+            __builtin_amdgcn_s_barrier();
+            stager.stage(sg, q * MCGEN_CK, ldsA);
+#pragma unroll 1
+            for (int tap = 0; tap < ntap; ++tap) {
+                // this tap's weight tile has landed (this wave's pieces), then all waves' pieces + window writes
+                if (blk + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                B_dma(blk + DIST);                       // slot (blk+2)%3 == (blk-1)%3: its readers passed the barrier
+                const int kh = (sg.ksize == 3) ? tap / 3 : 0, kw = (sg.ksize == 3) ? tap % 3 : 0;
+                const int tapoff = (kh * PC + kw) * APITCH;
+                const char* ldsB = ldsB0 + (blk % RB) * C::BBYTES;
+                typename M::frag af[FM], wf[FN];
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    af[fm] = *reinterpret_cast<const typename M::frag*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + w_row_off[fn]);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) M::run(wf[fn], af[fm], acc[fn][fm]);
+                ++blk;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
+
 // ---- "dma3" form ------------------------------------------------------------------------------------------
 // The weight tiles move by LDS-DMA (global_load_lds, no VGPR round trip); the DMA writes LDS linearly (wave base +
 // lane*16), so the bank swizzle is applied to the SOURCE address.  THREE taps per barrier: a ring slot holds the weight tiles of a group of up to 3 taps (one kernel row of a 3x3 filter); the
@@ -327,7 +492,7 @@ void conv_fused_kernel(const mcgen_conv_t p, const int a_bytes) {
 #define MCGEN_BIG_WAVES 0
 #endif
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (MCGEN_BIG_WAVES && BM * BN >= 256 * 256) ? MCGEN_BIG_WAVES : 0)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BM * BN >= 256 * 128) ? 2 : ((MCGEN_BIG_WAVES && BM * BN >= 256 * 256) ? MCGEN_BIG_WAVES : 0))
 void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     using M = Mma<T>;
@@ -1072,6 +1237,198 @@ void conv_mc_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "gk" form: gathered-K convolution over COMPACTED activations ---------------------------------------------------
+// Forward-only passes (the grouped generator pass that feeds the discriminator updates, train_gan.py:145-146) never
+// read a masked activation again, so the producing convolution stores, per image, only the channels its consumer's
+// MultimodalController keeps (mcgen_conv_t.ycmap: compacted order, pitch Cy ~ 5/8 of the channels).  This kernel is
+// the consumer: the window is staged exactly as in the dma3 form -- contiguous channels, 16-byte LDS stores, the
+// BatchNorm affine and the code folded into per-image scale / shift rows (mcgen_mc_affine, group_n = 1) -- and only
+// the WEIGHTS are gathered: the K-major image's rows cidx[32 t + k] of the tile's image, as in the "mc" form.  A dense
+// segment (no map: the block input of the first compacted block) takes rows 32 t + k.  K steps per segment:
+// ceil(active channels / 32), about 5 of 8.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_gk_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using T = bf16_t;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, APITCH = C::APITCH;
+    constexpr int NW = WM * WN;
+    constexpr int ROWB = BN * 2, RPP = 1024 / ROWB, LPR = 64 / RPP, NPIECE = 32 / RPP;
+    constexpr int PPW = (NPIECE + NW - 1) / NW;
+    constexpr int TAPB = 32 * ROWB, TPS = 3, SLOT = TPS * TAPB;
+    constexpr int NI = C::NI;
+    static_assert(BN == 128 || BN == 256, "k-major tap tiles: 2 or 4 rows per DMA piece");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;
+    char* const ldsB0 = smem + a_bytes;
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);          // host guarantees TI == 1
+    const int n_img = g.n0 < N ? g.n0 : N - 1;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-segment bookkeeping (wave-uniform): active count, K steps, weight rows -----------------------------
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    auto seg_info = [&](int s, const int16_t*& cidx, int& cw, int& cnt) {
+        const mcgen_seg_t& sg = p.seg[s];
+        cw = sg.Cw > 0 ? sg.Cw : sg.C;
+        cidx = nullptr; cnt = sg.C;
+        if (sg.cmap) {
+            const int16_t* rec = sg.cmap + (size_t)n_img * sg.cmap_stride;
+            cidx = rec + cw;
+            cnt = (int)mc_sload(rec + 2 * cw + 32 + 2 * ((cw + 31) >> 5));
+            if (cnt > sg.C) cnt = sg.C;                    // (the host sized the compacted pitch to hold every sample)
+        }
+    };
+    const int16_t* cidx0; int cw0, cnt0;
+    seg_info(0, cidx0, cw0, cnt0);
+    const int nt0 = p.seg[0].ksize * p.seg[0].ksize, gpc0 = (nt0 == 9) ? 3 : 1, nks0 = (cnt0 + 31) >> 5;
+    const size_t tapstride0 = (size_t)(cw0 + 1) * p.Cout_w * 2, seg1_off = (size_t)nt0 * tapstride0;
+    const int16_t* cidx1 = nullptr; int cw1 = 8, cnt1 = 0, nt1 = 1, gpc1 = 1, nks1 = 0;
+    size_t tapstride1 = 0;
+    if (p.nseg > 1) {
+        seg_info(1, cidx1, cw1, cnt1);
+        nt1 = p.seg[1].ksize * p.seg[1].ksize; gpc1 = (nt1 == 9) ? 3 : 1; nks1 = (cnt1 + 31) >> 5;
+        tapstride1 = (size_t)(cw1 + 1) * p.Cout_w * 2;
+    }
+    const int G0 = nks0 * gpc0, GT = G0 + nks1 * gpc1;
+
+    // ---- weight DMA: LDS row rho of a tap tile holds k = krow(rho), so that the two transposing reads of lane group lg
+    // (rows 4 lg + q and 16 + 4 lg + q) deliver k = 8 lg + 0..3 and 8 lg + 4..7: the activations' natural channel order
+    const int rsub = lane / LPR, ci = lane % LPR;
+    auto G_dma = [&](int gi) {
+        if (gi >= GT) return;
+        const bool s1 = gi >= G0;
+        const int gl = s1 ? gi - G0 : gi;
+        const int gpc = s1 ? gpc1 : gpc0;
+        const int t = gl / gpc, gq = gl - t * gpc;
+        const int ntg = (gpc == 3) ? 3 : 1;
+        const int16_t* cidx = s1 ? cidx1 : cidx0;
+        const int cw = s1 ? cw1 : cw0;
+        const size_t tapstride = s1 ? tapstride1 : tapstride0;
+        const char* wseg = wimg + (s1 ? seg1_off : 0);
+        char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = wave * PPW + k;
+            if (piece < NPIECE) {
+                const int rho0 = RPP * piece;                                           // first LDS row of the piece
+                const int k0 = (rho0 < 16) ? 8 * (rho0 >> 2) + (rho0 & 3) : 8 * ((rho0 - 16) >> 2) + 4 + ((rho0 - 16) & 3);
+                int dense;
+                if (cidx) {
+                    const uint32_t d01 = mc_sload(cidx + 32 * t + k0);
+                    uint32_t sel = d01;
+                    if constexpr (RPP == 4) {
+                        const uint32_t d23 = mc_sload(cidx + 32 * t + k0 + 2);
+                        sel = (rsub & 2) ? d23 : d01;
+                    }
+                    dense = (int)((rsub & 1) ? (sel >> 16) : (sel & 0xffffu));
+                } else {
+                    dense = 32 * t + k0 + rsub;
+                    if (dense > cw) dense = cw;                                         // beyond the channels: the zero row
+                }
+                const int rho = rho0 + rsub;
+                int co = cout0 + 16 * ((ci >> 1) ^ (rho & 7)) + 8 * (ci & 1);
+                if (co > p.Cout_w - 8) co = p.Cout_w - 8;
+                const size_t roff = ((size_t)dense * p.Cout_w + co) * 2;
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt) {
+                    const int tap = gq * ntg + (tt < ntg ? tt : ntg - 1);
+                    const char* src = wseg + (size_t)tap * tapstride + roff;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(slot + tt * TAPB + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    int w_off[FN];
+    {
+        const int q = l15 >> 2, pq = l15 & 3, r0 = 4 * lg + q;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int c0 = wn * (BN / WN) + fn * 16;
+            w_off[fn] = r0 * ROWB + 32 * ((c0 >> 4) ^ (r0 & 7)) + 8 * pq;
+        }
+    }
+
+    int gi = 0;
+    G_dma(0);
+    for (int s = 0; s < p.nseg; ++s) {
+        const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
+        const int nks = s ? nks1 : nks0;
+        const int halo = sg.ksize >> 1;
+        const int PC = W + 2 * halo;
+        PatchStager<T, NT, NI, APITCH> stager;
+        stager.setup(sg, g, N, H, W, tid);
+        int a_base[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = wm * (BM / WM) + fm * 16 + l15;
+            const int rem = m & ((1 << g.lgTHW) - 1);
+            const int r = rem >> g.lgW, c = rem & (W - 1);
+            a_base[fm] = (r * PC + c) * APITCH + lg * 16;
+        }
+        const int ntap = sg.ksize * sg.ksize;
+        const int gpc = (ntap == 9) ? 3 : 1, ntg = (ntap == 9) ? 3 : 1;
+#pragma unroll 1
+        for (int q = 0; q < nks; ++q) {
+            __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
+            stager.stage(sg, q * MCGEN_CK, ldsA);
+#pragma unroll 1
+            for (int gq = 0; gq < gpc; ++gq) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                G_dma(gi + 1);
+                const char* slot = ldsB0 + (gi & 1) * SLOT;
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) {
+                    if (t < ntg) {
+                        const int tap = gq * ntg + t;
+                        const int kh = (ntap == 9) ? tap / 3 : 0, kw = (ntap == 9) ? tap % 3 : 0;
+                        const int tapoff = (kh * PC + kw) * APITCH;
+                        const char* ldsB = slot + t * TAPB;
+                        bf16x8 af[FM], wf[FN];
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm)
+                            af[fm] = *reinterpret_cast<const bf16x8*>(ldsA + a_base[fm] + tapoff);
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn) {
+                            union { bf16x8 v; s16x4 h[2]; } u;
+                            u.h[0] = mc_tr16(ldsB + w_off[fn]);
+                            u.h[1] = mc_tr16(ldsB + w_off[fn] + 16 * ROWB);
+                            wf[fn] = u.v;
+                        }
+#pragma unroll
+                        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                            for (int fm = 0; fm < FM; ++fm)
+                                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+                    }
+                }
+                ++gi;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct TilePick { int BM, BN, pipe; };
 
@@ -1108,12 +1465,9 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (dtype == MCGEN_F32) return (M <= 16384 || p->Cout_w <= 64) ? TilePick{64, 64, 0} : TilePick{128, 128, 0};
     const int HW = p->H * p->W;
 #ifdef MCGEN_TUNING
-    static int env_bm = 0, env_bn = 0, env_pipe = 0, env_read = 0;
-    if (!env_read) {
-        env_read = 1;
-        if (const char* e = getenv("MCGEN_CONV_CFG"))
-            if (sscanf(e, "%d,%d,%d", &env_bm, &env_bn, &env_pipe) != 3) env_bm = 0;
-    }
+    int env_bm = 0, env_bn = 0, env_pipe = 0;                 // tuning builds only: re-read per launch (tools/bench_conv.py)
+    if (const char* e = getenv("MCGEN_CONV_CFG"))
+        if (sscanf(e, "%d,%d,%d", &env_bm, &env_bn, &env_pipe) != 3) env_bm = 0;
     if (env_bm > 0 && ((env_bm >= 2 * p->W) || HW <= env_bm)) return {env_bm, env_bn, env_pipe};
 #endif
     // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring with three taps per
@@ -1209,6 +1563,28 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
+static int launch_dma1(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)((Mtot + BM - 1) / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
+    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    int lds = a_bytes + 3 * C::BBYTES;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_dma1_kernel<T, BM, BN, WM, WN>;
+    static int raised = 0;
+    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised)) return rc;
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(dma1)");
+    return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
 static int launch_cp(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     const long Mtot = (long)p->N * p->H * p->W;
@@ -1256,6 +1632,7 @@ static int launch_mc(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
     const long Mtot = (long)p->N * p->H * p->W;
     MCGEN_CHECK(Mtot % BM == 0 && p->H * p->W >= BM, "conv_fused(mc): tiles of %d pixels must lie inside one %dx%d image", BM, p->H, p->W);
+    MCGEN_CHECK(!p->ycmap || p->Cout_w <= BN, "conv_fused(mc): compacted output needs all channels in one tile");
     const int mt = (int)(Mtot / BM);
     const int nt = (p->Cout_w + BN - 1) / BN;
     const int PP = patch_pixels(p, BM);
@@ -1296,6 +1673,48 @@ static int dispatch_mc(const mcgen_conv_t* p, int dtype, hipStream_t st) {
     return launch_mc<128, 128, 2, 2>(p, st);
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_gk(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    MCGEN_CHECK(Mtot % BM == 0 && p->H * p->W >= BM, "conv_fused(gk): tiles of %d pixels must lie inside one %dx%d image", BM, p->H, p->W);
+    MCGEN_CHECK(!p->ycmap || p->Cout_w <= BN, "conv_fused(gk): compacted output needs all channels in one tile");
+    const int mt = (int)(Mtot / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = patch_pixels(p, BM);
+    MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused(gk): patch of %d pixels exceeds the staging plan", PP);
+    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    int lds = a_bytes + 2 * 3 * 32 * BN * 2;
+    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(gk): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    auto kern = conv_gk_kernel<BM, BN, WM, WN>;
+    static int raised = 0;
+    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised)) return rc;
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(gk)");
+    return 0;
+}
+
+static int dispatch_gk(const mcgen_conv_t* p, int dtype, hipStream_t st) {
+    MCGEN_CHECK(dtype == MCGEN_BF16, "conv_fused: K-major launches are bf16");
+    for (int s = 0; s < p->nseg; ++s) {
+        const mcgen_seg_t& g = p->seg[s];
+        const int cw = g.Cw > 0 ? g.Cw : g.C;
+        MCGEN_CHECK(cw % 8 == 0 && cw <= 2048 && g.C <= cw + 32, "conv_fused(gk): segment %d: bad channel counts C=%d Cw=%d", s, g.C, cw);
+        MCGEN_CHECK(g.cmap || g.C == cw, "conv_fused(gk): segment %d: compacted channels need the map that orders them", s);
+        MCGEN_CHECK(!g.cmap || g.cmap_stride >= 2 * cw + 32, "conv_fused(gk): segment %d: map stride too small", s);
+        MCGEN_CHECK(!g.cmap || g.code == nullptr, "conv_fused(gk): segment %d: the code of a compacted segment rides in its scale / shift rows", s);
+    }
+    MCGEN_CHECK(p->Cout_w % 8 == 0 && p->Cout_w >= 64, "conv_fused(gk): at least 64 output channels");
+    int bm = 0, bn = 0;
+    MCGEN_CHECK(mc_tile(p, &bm, &bn), "conv_fused(gk): no tile of a %dx%d map lies inside one image", p->H, p->W);
+    if (bm == 256 && bn == 256) return launch_gk<256, 256, 2, 4>(p, st);
+    if (bm == 128 && bn == 256) return launch_gk<128, 256, 2, 4>(p, st);
+    return launch_gk<128, 128, 2, 2>(p, st);
+}
+
 typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
 struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
 
@@ -1319,6 +1738,9 @@ static const CfgEntry* bf16_table(int* n) {
         {64, 64, 11, launch_dma<T, 64, 64, 4, 2>},    {256, 16, 5, launch_dma<T, 256, 16, 8, 1>},
         {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},     {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
 #ifdef MCGEN_TUNING
+        {128, 256, 4, launch_dma1<T, 128, 256, 1, 4>}, {128, 256, 14, launch_dma1<T, 128, 256, 2, 4>},
+        {256, 128, 15, launch_dma<T, 256, 128, 4, 1>}, {256, 128, 16, launch_dma<T, 256, 128, 2, 2>},
+        {64, 128, 4, launch_dma1<T, 64, 128, 1, 4>},   {128, 128, 4, launch_dma1<T, 128, 128, 1, 4>},
         {256, 128, 5, launch_dma<T, 256, 128, 4, 2>}, {64, 64, 5, launch_dma<T, 64, 64, 2, 2>},
         {128, 16, 5, launch_dma<T, 128, 16, 4, 1>},   {64, 16, 5, launch_dma<T, 64, 16, 4, 1>},
         {64, 64, 12, launch_cp<T, 64, 64, 2, 2>},     {32, 64, 12, launch_cp<T, 32, 64, 1, 2>},
@@ -1342,7 +1764,7 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->N > 0 && ilog2_exact(p->H) >= 0 && ilog2_exact(p->W) >= 0, "conv_fused: H and W must be powers of two (got %dx%d)", p->H, p->W);
     MCGEN_CHECK(p->W <= 64 && p->H * p->W >= 1, "conv_fused: W up to 64 supported");
     MCGEN_CHECK(p->Cout > 0 && p->Cout_w == round_up(p->Cout, 16), "conv_fused: Cout_w must be Cout rounded up to 16");
-    MCGEN_CHECK(p->Cy % 8 == 0 && p->Cy >= p->Cout, "conv_fused: Cy must be a multiple of 8 and >= Cout");
+    MCGEN_CHECK(p->Cy % 8 == 0 && p->Cy > 0, "conv_fused: Cy must be a positive multiple of 8");
     MCGEN_CHECK(p->w && p->y, "conv_fused: null weight image or output");
     for (int s = 0; s < p->nseg; ++s) {
         const mcgen_seg_t& g = p->seg[s];
@@ -1355,7 +1777,15 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->stats_mode >= 0 && p->stats_mode <= 2, "conv_fused: bad stats_mode");
     MCGEN_CHECK(p->stats_mode != 2 || (p->gate_x && p->gmean && p->grstd), "conv_fused: stats_mode 2 needs gate_x, gmean, grstd");
     MCGEN_CHECK(p->stats_mode == 0 || p->stats, "conv_fused: stats_mode set without a stats buffer");
-    MCGEN_CHECK(p->w_layout == 0 || p->w_layout == 1, "conv_fused: unknown weight layout %d", p->w_layout);
+    MCGEN_CHECK(p->w_layout >= 0 && p->w_layout <= 2, "conv_fused: unknown weight layout %d", p->w_layout);
+    if (p->ycmap) {
+        MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out, "conv_fused: a compacted output takes bias and statistics only");
+        MCGEN_CHECK(p->Cy % 32 == 0 && p->Cy <= round_up(p->Cout, 8) + 32 && p->ycmap_stride >= 2 * round_up(p->Cout, 8) + 32,
+                    "conv_fused: compacted output: bad pitch %d / map stride %d", p->Cy, p->ycmap_stride);
+        MCGEN_CHECK(p->Cout_w <= 256, "conv_fused: a compacted output needs all channels in one tile");
+    } else {
+        MCGEN_CHECK(p->Cy >= p->Cout, "conv_fused: Cy must be >= Cout");
+    }
     return 0;
 }
 
@@ -1363,7 +1793,7 @@ static int validate(const mcgen_conv_t* p) {
 
 extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
     if (!p) return 0;
-    if (p->w_layout == 1) {
+    if (p->w_layout != 0) {
         int bm = 0, bn = 0;
         if (!mc_tile(p, &bm, &bn)) return 0;
         return (int)(((long)p->N * p->H * p->W + bm - 1) / bm);
@@ -1375,7 +1805,7 @@ extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
 
 extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn) {
     if (!p || !bm || !bn) return mcgen_fail("conv_tile: null pointer");
-    if (p->w_layout == 1) {
+    if (p->w_layout != 0) {
         MCGEN_CHECK(mc_tile(p, bm, bn), "conv_tile: no K-major tile for a %dx%d map", p->H, p->W);
         return 0;
     }
@@ -1386,11 +1816,12 @@ extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* b
 
 extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) {
     if (int rc = validate(p)) return rc;
-    if (p->w_layout == 1) {
-        return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
-    }
-    for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs w_layout = 1");
+    if (p->w_layout == 1) return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
+    if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
+    for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
     const TilePick t = pick_tile(p, dtype);
+    if (p->ycmap) MCGEN_CHECK(t.BM <= p->H * p->W && p->Cout_w <= t.BN,
+                              "conv_fused: compacted output: the %dx%d tile must lie inside one image and hold all %d channels", t.BM, t.BN, p->Cout_w);
     // pooling / whole-row tiles need at least two rows per tile
     MCGEN_CHECK(t.BM >= 2 * p->W || p->H * p->W <= t.BM, "conv_fused: tile of %d pixels too small for W=%d", t.BM, p->W);
     for (int s = 0; s < p->nseg; ++s) {

@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 3; }
+extern "C" int mcgen_abi_version(void) { return 4; }
 
 namespace {
 
@@ -247,6 +247,24 @@ void mc_cmap_kernel(const float* __restrict__ code, int C, int16_t* __restrict__
         }
     }
     for (int j = total + threadIdx.x; j < C + 32; j += blockDim.x) cidx[j] = (int16_t)C;     // padding -> the zero row
+}
+
+__global__ void mc_affine_kernel(const float* __restrict__ scale, const float* __restrict__ shift, int group_n,
+                                 const float* __restrict__ code, const int16_t* __restrict__ cmap, int stride,
+                                 int N, int C, int Ccap, float* __restrict__ so, float* __restrict__ ho) {
+    const size_t total = (size_t)N * Ccap;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Ccap), n = (int)(i / Ccap);
+        const int c = cmap[(size_t)n * stride + C + j];                      // cidx: C for slots beyond the active count
+        float a = 0.f, b = 0.f;
+        if (c < C) {
+            const float cd = code[(size_t)n * C + c];
+            const size_t g = group_n > 0 ? (size_t)(n / group_n) * C : 0;
+            a = (scale ? scale[g + c] : 1.f) * cd;
+            b = (scale ? shift[g + c] : 0.f) * cd;
+        }
+        so[i] = a; ho[i] = b;
+    }
 }
 
 // ---- BatchNorm ------------------------------------------------------------------------------------
@@ -810,6 +828,15 @@ extern "C" int mcgen_prep_weight_k(const float* w, void* image, int dtype, int C
         hipLaunchKernelGGL(prep_weight_k_kernel<float>, dim3(64), dim3(256), 0, STREAM(stream), w, (float*)image, Cout, Cin, ksize, sigma, wscale),
         hipLaunchKernelGGL(prep_weight_k_kernel<bf16_t>, dim3(64), dim3(256), 0, STREAM(stream), w, (bf16_t*)image, Cout, Cin, ksize, sigma, wscale));
     MCGEN_LAUNCH_CHECK("prep_weight_k"); return 0;
+}
+extern "C" int mcgen_mc_affine(const float* scale, const float* shift, int group_n, const float* code, const int16_t* cmap,
+                               int N, int C, int Ccap, float* scale_out, float* shift_out, void* stream) {
+    MCGEN_CHECK(code && cmap && scale_out && shift_out && N > 0 && C > 0 && C % 8 == 0 && Ccap > 0 && Ccap <= C + 32 && Ccap % 8 == 0,
+                "mc_affine: bad arguments");
+    MCGEN_CHECK((scale == nullptr) == (shift == nullptr) && group_n >= 0, "mc_affine: scale and shift go together");
+    hipLaunchKernelGGL(mc_affine_kernel, dim3(grid_for((size_t)N * Ccap)), dim3(256), 0, STREAM(stream), scale, shift, group_n, code, cmap,
+                       mcgen_cmap_stride(C), N, C, Ccap, scale_out, shift_out);
+    MCGEN_LAUNCH_CHECK("mc_affine"); return 0;
 }
 extern "C" int32_t mcgen_cmap_stride(int C) { return round_up(2 * C + 32 + 2 * ((C + 31) / 32 + 1), 8); }
 extern "C" int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream) {

@@ -144,6 +144,7 @@ class Seg:
     relu: bool = False
     group_n: int = 0                # > 0: scale / shift are [N // group_n, C], one BatchNorm batch per group_n images
     cmap: Optional[Tensor] = None   # int16 [N, cmap_stride(C)] compaction map of `code` (mc_cmap): mode-compacted K loop
+    cw: int = 0                     # kmajor=2: channels of the segment's WEIGHTS when x holds compacted channels (else 0)
 
     def fill(self, s: _lib.Seg):
         s.x = _p(self.x)
@@ -151,10 +152,11 @@ class Seg:
         s.C = self.x.shape[-1]
         s.ups, s.relu, s.ksize = int(self.ups), int(self.relu), self.ksize
         s.group_n = int(self.group_n)
-        s.cmap, s.cmap_stride = None, 0
+        s.cmap, s.cmap_stride, s.Cw = None, 0, int(self.cw)
         if self.cmap is not None:
-            if self.cmap.dtype != torch.int16 or tuple(self.cmap.shape) != (self.x.shape[0], cmap_stride(s.C)):
-                raise _lib.McgenError(f'cmap must be int16 {(self.x.shape[0], cmap_stride(s.C))}, got {self.cmap.dtype} {tuple(self.cmap.shape)}')
+            cm = self.cw or s.C                                 # the map is over the weights' (true) channels
+            if self.cmap.dtype != torch.int16 or tuple(self.cmap.shape) != (self.x.shape[0], cmap_stride(cm)):
+                raise _lib.McgenError(f'cmap must be int16 {(self.x.shape[0], cmap_stride(cm))}, got {self.cmap.dtype} {tuple(self.cmap.shape)}')
             s.cmap, s.cmap_stride = _p(self.cmap), self.cmap.shape[1]
         if self.group_n and self.scale is not None:
             g = self.x.shape[0] // self.group_n
@@ -224,6 +226,17 @@ def mc_cmap(code: Tensor) -> Tensor:
     return out
 
 
+def mc_affine(code: Tensor, cmap: Tensor, ccap: int, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+              group_n: int = 0):
+    """Per-image prologue rows [N, ccap] of a launch that reads compacted activations (mcgen_mc_affine): the
+    BatchNorm affine (scale / shift: [C] or [N // group_n, C]) gathered through the map and multiplied by the code."""
+    n, c = code.shape
+    out = torch.empty((2, n, ccap), dtype=torch.float32, device=code.device)
+    check(_lib.load().mcgen_mc_affine(_f32(scale), _f32(shift), group_n, _f32(code), _p(cmap), n, c, ccap,
+                                      out[0].data_ptr(), out[1].data_ptr(), _stream()), 'mc_affine')
+    return out[0], out[1]
+
+
 def weight_image_k_elems(cout: int, cin: int, ksize: int) -> int:
     return int(_lib.load().mcgen_weight_image_k_elems(cout, cin, ksize))
 
@@ -266,9 +279,11 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
                gscale: Optional[Tensor] = None, gshift: Optional[Tensor] = None,
                gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
                tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
-               out: Optional[Tensor] = None, kmajor: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+               out: Optional[Tensor] = None, kmajor: int = 0, ycmap: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None).  `kmajor`: `wimg` is the K-major image
-    (prep_weight_k, segments concatenated) and every segment carries a compaction map: the mode-compacted kernel."""
+    (prep_weight_k, segments concatenated); 1: every segment carries a compaction map and is compacted while staged;
+    2: segments hold ALREADY compacted channels (Seg.cw, cmap) or are dense.  `ycmap` (+ `cy` = compacted pitch): the
+    output keeps, per image, only the channels of that map, compacted (forward-only passes)."""
     s0 = segs[0]
     n = s0.x.shape[0]
     h = s0.x.shape[1] * (2 if s0.ups else 1)
@@ -288,7 +303,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     if wimg.dtype != dtype:
         raise _lib.McgenError(f'weight image dtype {wimg.dtype} != activation dtype {dtype}')
     if kmajor:
-        need = sum(s.ksize * s.ksize * (s.x.shape[-1] + 1) for s in segs) * pad16(cout)
+        need = sum(s.ksize * s.ksize * ((s.cw or s.x.shape[-1]) + 1) for s in segs) * pad16(cout)
     else:
         need = sum(((s.x.shape[-1] + 31) // 32) * s.ksize * s.ksize for s in segs) * pad16(cout) * 32
     if wimg.numel() != need:
@@ -308,18 +323,23 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     p.gscale, p.gshift, p.gmean, p.grstd = _f32(gscale), _f32(gshift), _f32(gmean), _f32(grstd)
     p.tanh_out, p.stats_mode = int(tanh), stats_mode
     p.w_layout = int(kmajor)
+    p.ycmap, p.ycmap_stride = None, 0
+    if ycmap is not None:
+        if ycmap.dtype != torch.int16 or tuple(ycmap.shape) != (n, cmap_stride(pad8(cout))):
+            raise _lib.McgenError(f'ycmap must be int16 {(n, cmap_stride(pad8(cout)))}')
+        p.ycmap, p.ycmap_stride = _p(ycmap), ycmap.shape[1]
     stats = None
     lib = _lib.load()
     if stats_mode:
         tiles = lib.mcgen_conv_m_tiles(C.byref(p), _dt(dtype))
-        stats = torch.empty((tiles, 2, cy), dtype=torch.float32, device=y.device)
+        stats = torch.empty((tiles, 2, pad16(cout) if ycmap is not None else cy), dtype=torch.float32, device=y.device)
         p.stats = _p(stats)
     kflops = 2.0 * n * h * w * cout * sum(s.ksize * s.ksize * s.x.shape[-1] for s in segs)
 
     def _name():
         bm, bn = C.c_int(), C.c_int()
         lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
-        base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{",mc" if kmajor else ""}>'
+        base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{(",mc", ",gk")[kmajor - 1] if kmajor else ""}>'
         if _os.environ.get('MCGEN_PROF_SHAPES'):
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')

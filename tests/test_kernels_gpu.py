@@ -847,3 +847,70 @@ def test_mode_compacted_conv_rejects_what_it_cannot_run():
         ops.conv_fused([ops.Seg(xt, code=code.cuda(), cmap=ops.mc_cmap(code.cuda()))], wk, 64, kmajor=True)
     with pytest.raises(_lib.McgenError):                    # a K-major launch without a map
         ops.conv_fused([ops.Seg(xt, code=code.cuda())], wk, 64, kmajor=True)
+
+
+@pytest.mark.parametrize('n,h,t', [(128, 32, (256, 256)), (128, 16, (128, 256)), (640, 16, (256, 256))])
+def test_compacted_activation_chain_matches_dense(n, h, t):
+    """Forward-only chains keep activations compacted between launches: the producer stores, per image, only the
+    channels the consumer's MultimodalController keeps (ycmap), the consumer ('gk' form) stages them contiguously and
+    gathers the matching rows of its K-major weight image.  Against the dense chain conv -> BN -> ReLU -> MC -> conv
+    (+ an upsampled 1x1 shortcut segment that stays dense): the stored channels are bit-identical, the statistics are
+    the same sums, and the consumer's output is the dense launch's up to a bf16 rounding step."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(951 + n + h)
+    c = 256
+    x0 = _rnd(g, n, c, h, h)
+    xs = _rnd(g, n, c, h // 2, h // 2)                       # the block input of the shortcut segment
+    w1, b1 = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
+    w2, ws, b2 = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c, c, 1, 1) * 0.08, _rnd(g, c)
+    scale, shift = (_rnd(g, c) * 0.5 + 1).cuda(), (_rnd(g, c) * 0.3).cuda()
+    code2 = (torch.rand(n, c, generator=g) < 0.5).float()
+    code2[0] = 0.0
+    code2[1, :160] = 1.0; code2[1, 160:] = 0.0             # exactly fills the compacted pitch
+    code1 = (torch.rand(n, c, generator=g) < 0.5).float().cuda()
+    code2 = code2.cuda()
+    ccap = 160
+    assert int((code2 != 0).sum(1).max()) <= ccap
+    cm = ops.mc_cmap(code2)
+    x0t, xst = _nhwc(ops, x0, dtype), _nhwc(ops, xs, dtype)
+    img1 = ops.prep_weight(w1.cuda(), dtype)
+    h_d, st_d = ops.conv_fused([ops.Seg(x0t)], img1, c, bias=b1.cuda(), stats_mode=1)
+    h_c, st_c = ops.conv_fused([ops.Seg(x0t)], img1, c, bias=b1.cuda(), stats_mode=1, ycmap=cm, cy=ccap)
+    assert h_c.shape == (n, h, h, ccap)
+    assert torch.equal(st_c[..., :c], st_d[..., :c])
+    cidx = cm[:, c:c + ccap].long()                           # [n, ccap], value c beyond the active count
+    gathered = torch.gather(torch.nn.functional.pad(h_d, (0, 1)), 3, cidx.view(n, 1, 1, ccap).expand(n, h, h, ccap))
+    assert torch.equal(h_c, gathered)
+    # consumer: BN affine + code folded into per-image rows; second segment dense (its code applied in the prologue)
+    sc_rows, sh_rows = ops.mc_affine(code2, cm, ccap, scale, shift)
+    ref_rows = torch.gather(torch.nn.functional.pad(scale.view(1, c) * code2, (0, 1)), 1, cidx)
+    assert torch.equal(sc_rows, ref_rows)
+    img_d = torch.cat([ops.prep_weight(w2.cuda(), dtype), ops.prep_weight(ws.cuda(), dtype)])
+    img_k = torch.cat([ops.prep_weight_k(w2.cuda(), dtype), ops.prep_weight_k(ws.cuda(), dtype)])
+    segs_d = [ops.Seg(h_d, scale=scale, shift=shift, code=code2, relu=True), ops.Seg(xst, ksize=1, code=code1, ups=True)]
+    segs_c = [ops.Seg(h_c, scale=sc_rows, shift=sh_rows, relu=True, group_n=1, cmap=cm, cw=c), ops.Seg(xst, ksize=1, code=code1, ups=True)]
+    y_d, sd = ops.conv_fused(segs_d, img_d, c, bias=b2.cuda(), stats_mode=1)
+    (y_c, sc_), tiles = _conv_logged(ops, segs_c, img_k, c, bias=b2.cuda(), stats_mode=1, kmajor=2)
+    assert tiles == [t], tiles
+    _assert_bf16_twin(y_c, y_d, 'gathered-K consumer vs dense')
+    np.testing.assert_allclose(sc_.double().sum(0).cpu(), sd.double().sum(0).cpu(), rtol=2e-4, atol=1e-2)
+    # both segments compacted (the shortcut input stored compacted by the same consumer map, no BatchNorm: scale rows = code)
+    cm1 = ops.mc_cmap(code1)
+    cap1 = 160 if int((code1 != 0).sum(1).max()) <= 160 else 192
+    xs_c, _ = ops.conv_fused([ops.Seg(_nhwc(ops, _rnd(g, n, c, h // 2, h // 2), dtype))], img1, c, ycmap=cm1, cy=cap1)
+    s1, t1 = ops.mc_affine(code1, cm1, cap1)
+    x_dense = torch.zeros((n, h // 2, h // 2, c), dtype=dtype, device='cuda')
+    idx1 = cm1[:, c:c + cap1].long()
+    valid = idx1 < c
+    # scatter the compacted tensor back to dense channels for the reference launch
+    x_dense_p = torch.nn.functional.pad(x_dense, (0, 1))
+    x_dense_p.scatter_(3, idx1.view(n, 1, 1, cap1).expand(n, h // 2, h // 2, cap1), xs_c)
+    x_dense = x_dense_p[..., :c].contiguous()
+    segs_d2 = [ops.Seg(h_d, scale=scale, shift=shift, code=code2, relu=True), ops.Seg(x_dense, ksize=1, code=code1, ups=True)]
+    segs_c2 = [ops.Seg(h_c, scale=sc_rows, shift=sh_rows, relu=True, group_n=1, cmap=cm, cw=c),
+               ops.Seg(xs_c, ksize=1, scale=s1, shift=t1, ups=True, group_n=1, cmap=cm1, cw=c)]
+    y_d2, _ = ops.conv_fused(segs_d2, img_d, c, bias=b2.cuda())
+    y_c2, _ = ops.conv_fused(segs_c2, img_k, c, bias=b2.cuda(), kmajor=2)
+    _assert_bf16_twin(y_c2, y_d2, 'gathered-K consumer, both segments compacted')
+    assert bool(valid.any())
