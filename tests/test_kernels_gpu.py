@@ -898,15 +898,11 @@ def test_compacted_activation_chain_matches_dense(n, h, t):
     # both segments compacted (the shortcut input stored compacted by the same consumer map, no BatchNorm: scale rows = code)
     cm1 = ops.mc_cmap(code1)
     cap1 = 160 if int((code1 != 0).sum(1).max()) <= 160 else 192
-    xs_c, _ = ops.conv_fused([ops.Seg(_nhwc(ops, _rnd(g, n, c, h // 2, h // 2), dtype))], img1, c, ycmap=cm1, cy=cap1)
     s1, t1 = ops.mc_affine(code1, cm1, cap1)
-    x_dense = torch.zeros((n, h // 2, h // 2, c), dtype=dtype, device='cuda')
     idx1 = cm1[:, c:c + cap1].long()
     valid = idx1 < c
-    # scatter the compacted tensor back to dense channels for the reference launch
-    x_dense_p = torch.nn.functional.pad(x_dense, (0, 1))
-    x_dense_p.scatter_(3, idx1.view(n, 1, 1, cap1).expand(n, h // 2, h // 2, cap1), xs_c)
-    x_dense = x_dense_p[..., :c].contiguous()
+    x_dense = xst                                          # the dense block input; its compacted twin by a torch gather
+    xs_c = torch.gather(torch.nn.functional.pad(x_dense, (0, 1)), 3, idx1.view(n, 1, 1, cap1).expand(n, h // 2, h // 2, cap1)).contiguous()
     segs_d2 = [ops.Seg(h_d, scale=scale, shift=shift, code=code2, relu=True), ops.Seg(x_dense, ksize=1, code=code1, ups=True)]
     segs_c2 = [ops.Seg(h_c, scale=sc_rows, shift=sh_rows, relu=True, group_n=1, cmap=cm, cw=c),
                ops.Seg(xs_c, ksize=1, scale=s1, shift=t1, ups=True, group_n=1, cmap=cm1, cw=c)]
