@@ -42,6 +42,9 @@ struct ConvCfg {
     static_assert(BM % EPX == 0 && PPX % 16 == 0, "epilogue passes");
 };
 
+// compacted-output table behind the epilogue tile: int16 column per output slot, then fp32 bias per slot
+constexpr int YTAB_COLS = 320, YTAB_BYTES = YTAB_COLS * 2 + YTAB_COLS * 4;
+
 // Shared epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass, PPX pixels at a time.
 template <typename T, typename C, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
@@ -84,7 +87,23 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const int lgWo = p.pool ? g.lgW - 1 : g.lgW;
     const int lgTHWo = p.pool ? g.lgTHW - 2 : g.lgTHW;
     const int out_pp = p.pool ? (PPX >> 2) : PPX;          // output pixels per pass
-
+    // compacted output: tile column (or -1) and bias of every output slot of this tile's image, kept in LDS behind the
+    // accumulator tile (the launch reserves YTAB_BYTES for it); visible after the first barrier of pass 0
+    int16_t* ycol = reinterpret_cast<int16_t*>(epi + C::PPX * EP);
+    float* ybias = reinterpret_cast<float*>(ycol + YTAB_COLS);
+    const bool ylive = p.ycmap && g.n0 < N;
+    const int ycgrp = p.Cy >> 3;
+    const unsigned yinv = 65536u / (unsigned)ycgrp + 1u;          // u / ycgrp == (u * yinv) >> 16 for u < 4096
+    if (ylive) {
+        const int16_t* cidx = p.ycmap + (size_t)g.n0 * p.ycmap_stride + ((p.Cout + 7) & ~7);   // record: [cpos: C][cidx: C + 32]...
+        for (int j = tid; j < p.Cy; j += NT) {
+            const int ct = (int)(uint16_t)cidx[j];                 // true channel (the zero row's index beyond the image's count)
+            const int c = ct - cout0;
+            const bool ok = c >= 0 && c < BN && ct < p.Cout;
+            ycol[j] = (int16_t)(ok ? c : -1);
+            ybias[j] = (ok && p.bias) ? p.bias[ct] : 0.f;
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < C::EPX; ++pass) {
         if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
@@ -165,33 +184,26 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
             }
-            if (p.ycmap) {
-                float* e1 = epi + mo * EP + ch * 8;        // (pool == 0 here) hand the finished values back to the tile
-#pragma unroll
-                for (int i = 0; i < 8; ++i) e1[i] = v[i];
-            } else {
-                E::store8(y + opix * p.Cy + co, v);
-            }
+            if (!p.ycmap) E::store8(y + opix * p.Cy + co, v);          // (compacted output: the gather pass below stores)
         }
-        if (p.ycmap) {
-            // gather pass: output slot j of a pixel <- true channel cidx[j] of the tile's image (zeros beyond its count)
-            __syncthreads();
-            const int n = g.n0;
-            const int16_t* cidx = p.ycmap + (size_t)n * p.ycmap_stride + ((p.Cout + 7) & ~7);   // record: [cpos: C][cidx: C + 32]...
-            const int cgrp = p.Cy >> 3;
-            for (int u = tid; u < out_pp * cgrp; u += NT) {
-                const int mo = u / cgrp, jg = u - mo * cgrp;
+        if (ylive) {
+            // gather pass: output slot j of a pixel <- tile column ycol[j] (zeros beyond the image's count).  A compacted
+            // output carries bias only (validated), so the value is rebuilt from the raw accumulator tile: both loops of
+            // this pass only READ the tile -- no hand-back, no barrier between them.
+            for (int u = tid; u < out_pp * ycgrp; u += NT) {
+                const int mo = (int)(((unsigned)u * yinv) >> 16), jg = u - mo * ycgrp;
                 const int mt = pass * out_pp + mo;
                 const int ro = mt >> lgWo, wo = mt & ((1 << lgWo) - 1);
-                const size_t opix = ((size_t)n * Ho + (g.h0 + ro)) * Wo + wo;
-                const u32x4 ci4 = *reinterpret_cast<const u32x4*>(cidx + jg * 8);
+                const size_t opix = ((size_t)g.n0 * Ho + (g.h0 + ro)) * Wo + wo;
+                const u32x4 c4 = *reinterpret_cast<const u32x4*>(ycol + jg * 8);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ybias + jg * 8), b1 = *reinterpret_cast<const f32x4*>(ybias + jg * 8 + 4);
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int c = (int)((i & 1) ? (ci4[i >> 1] >> 16) : (ci4[i >> 1] & 0xffffu)) - cout0;
-                    v[i] = (c >= 0 && c < BN && c + cout0 < p.Cout) ? epi[mo * EP + c] : 0.f;
+                    const int c = (int)(int16_t)((i & 1) ? (c4[i >> 1] >> 16) : (c4[i >> 1] & 0xffffu));
+                    v[i] = c >= 0 ? fmaf(epi[mo * EP + c], p.alpha, i < 4 ? b0[i & 3] : b1[i & 3]) : 0.f;
                 }
-                if (n < N) E::store8(y + opix * p.Cy + jg * 8, v);
+                E::store8(y + opix * p.Cy + jg * 8, v);
             }
         }
     }
@@ -1513,7 +1525,7 @@ static int launch_cfg(const mcgen_conv_t* p, hipStream_t st) {
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
     int a_bytes = round_up(PP * C::APITCH, 32);
     int main_bytes = a_bytes + C::BBYTES;
-    int epi_bytes = C::PPX * C::EP * 4;
+    int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0);
     int red_bytes = C::PROWS * BN * 2 * 4;
     int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
@@ -1542,7 +1554,7 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
                          (a3 > a_bytes ? a3 : a_bytes) + 6 * C::BBYTES <= 96 * 1024;
     if (grouped && a3 > a_bytes) a_bytes = a3;
     int lds = a_bytes + 6 * C::BBYTES;
-    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
@@ -1572,7 +1584,7 @@ static int launch_dma1(const mcgen_conv_t* p, hipStream_t st) {
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused: patch of %d pixels exceeds the staging plan", PP);
     const int a_bytes = round_up(PP * C::APITCH, 1024);
     int lds = a_bytes + 3 * C::BBYTES;
-    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused: tile %dx%d needs %d bytes of LDS", BM, BN, lds);
@@ -1602,7 +1614,7 @@ static int launch_cp(const mcgen_conv_t* p, hipStream_t st) {
     }
     a_bytes = round_up(a_bytes, 1024);
     int lds = a_bytes + 2 * 9 * C::BBYTES;
-    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(cp): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
@@ -1639,12 +1651,12 @@ static int launch_mc(const mcgen_conv_t* p, hipStream_t st) {
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused(mc): patch of %d pixels exceeds the staging plan", PP);
     const int a_bytes = round_up(PP * C::APITCH, 16);
     int lds = 2 * a_bytes + 2 * 3 * 32 * BN * 2;
-    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(mc): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
     // window loads of the next dense chunk prefetched across the K step (tuning builds can switch it off)
-    static const bool prefetch = env_long("MCGEN_MC_PREFETCH", 1) != 0;
+    static const bool prefetch = env_long("MCGEN_MC_PREFETCH", 0) != 0;
     static int raised = 0, raised0 = 0;
     if (prefetch) {
         auto kern = conv_mc_kernel<BM, BN, WM, WN, true>;
@@ -1685,7 +1697,7 @@ static int launch_gk(const mcgen_conv_t* p, hipStream_t st) {
     MCGEN_CHECK(PP * 4 <= C::NI * C::NT, "conv_fused(gk): patch of %d pixels exceeds the staging plan", PP);
     const int a_bytes = round_up(PP * C::APITCH, 1024);
     int lds = a_bytes + 2 * 3 * 32 * BN * 2;
-    const int epi_bytes = C::PPX * C::EP * 4, red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(gk): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
@@ -1820,7 +1832,7 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
     const TilePick t = pick_tile(p, dtype);
-    if (p->ycmap) MCGEN_CHECK(t.BM <= p->H * p->W && p->Cout_w <= t.BN,
+    if (p->ycmap) MCGEN_CHECK(dtype == MCGEN_BF16 && t.BM <= p->H * p->W && p->Cout_w <= t.BN,
                               "conv_fused: compacted output: the %dx%d tile must lie inside one image and hold all %d channels", t.BM, t.BN, p->Cout_w);
     // pooling / whole-row tiles need at least two rows per tile
     MCGEN_CHECK(t.BM >= 2 * p->W || p->H * p->W <= t.BM, "conv_fused: tile of %d pixels too small for W=%d", t.BM, p->W);

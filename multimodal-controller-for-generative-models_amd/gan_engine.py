@@ -93,6 +93,9 @@ _BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # tw
 # mode-compacted forward convolutions (bf16, maps >= 16x16, conv_a launches): opt-in -- measured x1.10 on those launches
 # (tools/bench_mc.py), about 0.5 % of the step after the map / K-major image launches are paid: see DESIGN.md section 4.6
 _MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
+# compacted activations between the launches of the FORWARD-ONLY grouped generator pass (producer-side compacted store +
+# gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
+_GK = __import__('os').environ.get('MCGEN_GK', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -178,6 +181,20 @@ class GeneratorEngine:
                 jobs.append((wsc, cat[n2:], False, 1, -1, 1.0))
             jobs.append((head_conv.weight, buf('head', ops.weight_image_elems(head_conv.out_channels, head_conv.in_channels, 3), dt),
                          False, 1, -1, 1.0))
+            if self._gk_enabled():
+                # K-major images of the launches that read compacted activations in the grouped forward-only pass:
+                # conv_b ++ shortcut of every block from 16x16 up, conv_a of every block from 32x32 up
+                for i, b in enumerate(res):
+                    if not self._gk_block(i):
+                        continue
+                    w1, w2, wsc = b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight
+                    n2 = ops.weight_image_k_elems(w2.shape[0], w2.shape[1], 3)
+                    ns = ops.weight_image_k_elems(wsc.shape[0], wsc.shape[1], 1)
+                    catk = buf(f'b{i}.w2sk', n2 + ns, dt)
+                    jobs.append((w2, catk[:n2], False, 1, -1, 1.0, True))
+                    jobs.append((wsc, catk[n2:], False, 1, -1, 1.0, True))
+                    if i > 0 and self._gk_block(i - 1):
+                        jobs.append((w1, buf(f'b{i}.w1g', ops.weight_image_k_elems(w1.shape[0], w1.shape[1], 3), dt), False, 1, -1, 1.0, True))
             if self._mc_enabled():
                 # K-major images of the blocks whose maps are large enough for a tile to lie inside one image (the
                 # mode-compacted kernel gathers the active channels' rows from them): conv_a, and conv_b ++ shortcut
@@ -226,6 +243,32 @@ class GeneratorEngine:
         c1 = res[i].conv[4].module
         return self._mc_enabled() and (8 << i) >= 16 and c1.out_channels >= 64 and c1.in_channels % 8 == 0 and c1.out_channels % 8 == 0
 
+    # ---- compacted activations in the forward-only grouped pass -------------------------------------
+    def _gk_enabled(self) -> bool:
+        return _GK and self.dtype == torch.bfloat16
+
+    def _gk_block(self, i: int) -> bool:
+        """Block i (convolutions at side 8 * 2^i) can keep its inner activation h compacted: from 16x16 up a tile lies
+        inside one image, and one 256-channel tile holds every output channel."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        c1 = res[i].conv[4].module
+        return (self._gk_enabled() and (8 << i) >= 16 and 64 <= c1.out_channels <= 256 and c1.out_channels % 32 == 0
+                and c1.in_channels % 8 == 0)
+
+    def _cap(self, mc):
+        """Compacted channel pitch for activations masked by `mc`: the largest number of active channels any mode keeps,
+        rounded up to 32 (None when compaction would not pay, or a code is negative).  Read from the codebook on the
+        host once per codebook version (one-hot indicators: a sample's code is one codebook row, modules.py:73)."""
+        cb = mc.codebook
+        key = (cb.data_ptr(), tuple(cb.shape), cb._version)
+        cache = self.__dict__.setdefault('_cap_cache', {})
+        if cache.get(id(mc), (None,))[0] != key:
+            cnt = int((cb != 0).sum(1).max())
+            cap = (cnt + 31) // 32 * 32
+            ok = cap <= cb.shape[1] * 3 // 4 and float(cb.min()) >= 0.0
+            cache[id(mc)] = (key, cap if ok else None)
+        return cache[id(mc)][1]
+
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:
         """Can `groups` training-mode forwards of n_total / groups images each run as ONE pass?  Every launch's tile
@@ -268,26 +311,56 @@ class GeneratorEngine:
         ctx['zt'] = zt
         blocks_ctx = []
         codes = self._codes.run(indicator)
+        # Forward-only grouped pass: activations between the launches stay COMPACTED -- the producer stores, per image, only
+        # the channels the consumer's MultimodalController keeps (ycmap), the consumer gathers the matching weight rows.
+        gk = groups > 1 and self._gk_enabled()
+        x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
         for i, b in enumerate(res):
             s = x.shape[1]
             code1, code2 = codes[2 * i], codes[2 * i + 1]
             bn1 = _bn_forward(b.conv[0].module, st, ng * s * s, train, fold, groups)
             fold = 1
             co = b.conv[4].module.out_channels
-            # large maps: the K loop visits only each sample's active channels (mode-compacted kernel, K-major images)
-            mc = self._mc_block(i) and f'b{i}.w1k' in self.img
-            cm1 = ops.mc_cmap(code1) if mc else None
-            seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True, group_n=gn, cmap=cm1)
-            h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1k' if mc else f'b{i}.w1'], co, bias=b.conv[4].module.bias,
-                                     stats_mode=st_mode, kmajor=mc)
+            ci = b.conv[4].module.in_channels
+            cap_h = self._cap(b.mc_2) if (gk and self._gk_block(i)) else None            # h of this block, masked by mc_2
+            nxt = res[i + 1] if i + 1 < len(res) else None
+            cap_y = self._cap(nxt.mc_1) if (gk and nxt is not None and self._gk_block(i) and self._gk_block(i + 1)) else None
+            cm_h = ops.mc_cmap(code2) if cap_h else None
+            cm_y = ops.mc_cmap(codes[2 * (i + 1)]) if cap_y else None
+            # ---- conv_a: BN -> ReLU -> Up -> MC1 -> conv3x3 (mcgan.py:15-19)
+            if x_cm is not None:
+                sa, ta = ops.mc_affine(code1, x_cm[0], x_cm[1], bn1.scale, bn1.shift, group_n=gn)
+                seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1, cmap=x_cm[0], cw=ci)
+                h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1g'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
+                                         kmajor=2, ycmap=cm_h, cy=cap_h)
+            else:
+                # large maps: the K loop visits only each sample's active channels (mode-compacted kernel, K-major images)
+                mc = self._mc_block(i) and f'b{i}.w1k' in self.img
+                cm1 = ops.mc_cmap(code1) if mc else None
+                seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True, group_n=gn, cmap=cm1)
+                h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1k' if mc else f'b{i}.w1'], co, bias=b.conv[4].module.bias,
+                                         stats_mode=st_mode, kmajor=int(mc), ycmap=cm_h, cy=cap_h)
             bn2 = _bn_forward(b.conv[5].module, st_h, ng * 4 * s * s, train, 1, groups)
-            # (conv_b ++ 1x1 shortcut stays dense: the shortcut's one-tap K steps cost more than compaction saves, x0.97)
-            seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)
-            seg_s = Seg(x, ksize=1, code=code1, ups=True)
-            y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],
-                                   stats_mode=st_mode)
+            # ---- conv_b ++ shortcut: conv3x3(MC2(ReLU(BN(h)))) + conv1x1(MC1(Up(x))) (mcgan.py:20-30,42)
+            if cm_h is not None:
+                sb, tb = ops.mc_affine(code2, cm_h, cap_h, bn2.scale, bn2.shift, group_n=gn)
+                seg_b = Seg(h, scale=sb, shift=tb, relu=True, group_n=1, cmap=cm_h, cw=co)
+                if x_cm is not None:
+                    ss, ts = ops.mc_affine(code1, x_cm[0], x_cm[1])
+                    seg_s = Seg(x, ksize=1, scale=ss, shift=ts, ups=True, group_n=1, cmap=x_cm[0], cw=ci)
+                else:
+                    seg_s = Seg(x, ksize=1, code=code1, ups=True)
+                y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co, bias=self.img[f'b{i}.bias2s'],
+                                       stats_mode=st_mode, kmajor=2, ycmap=cm_y, cy=cap_y)
+            else:
+                # (conv_b ++ 1x1 shortcut stays dense in the mode-compacted form: one-tap K steps cost more than they save)
+                seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)
+                seg_s = Seg(x, ksize=1, code=code1, ups=True)
+                y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],
+                                       stats_mode=st_mode)
             blocks_ctx.append(dict(x=x, h=h, code1=code1, code2=code2, bn1=bn1, bn2=bn2))
             x = y
+            x_cm = (cm_y, cap_y) if cm_y is not None else None
         s = x.shape[1]
         bnh = _bn_forward(head_bn, st, ng * s * s, train, fold, groups)
         codeh = codes[-1]

@@ -51,6 +51,7 @@ def _f32(t: Optional[Tensor]) -> Optional[int]:
 # ---- per-launch profiling (bench.py roofline): HIP events on the launch stream -------------------------
 _PROF = None
 TILE_LOG = None        # tests set this to a list: every conv_fused launch appends the (BM, BN) tile the policy picked
+FORM_LOG = None        # tests set this to a list: every conv_fused launch appends its weight layout (0 dense, 1 mc, 2 gk)
 
 
 def _timed(name_fn, flops: float, launch, nbytes_fn=None):
@@ -348,6 +349,8 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         bm, bn = C.c_int(), C.c_int()
         check(lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn)), 'conv_tile')
         TILE_LOG.append((bm.value, bn.value))
+    if FORM_LOG is not None:
+        FORM_LOG.append(kmajor)
     _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'),
            lambda: _nbytes(wimg, y, res, gate_x, *[s.x for s in segs]))
     return y, stats
