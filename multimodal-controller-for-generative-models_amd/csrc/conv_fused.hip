@@ -17,6 +17,7 @@
 // fragment (exact fp32 FMA chains) -- same LDS images, same epilogue.
 #include "conv_tile.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -1441,6 +1442,331 @@ void conv_gk_kernel(const mcgen_conv_t p, const int a_bytes) {
     conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
 }
 
+// ---- "pp" form: the 3x3 main loop as a software pipeline ------------------------------------------------------------
+// The dma3 form serialises, per 32-channel chunk, one exposed global round trip (the window staging) and, per tap, an
+// LDS-read phase that all eight waves enter together after the group barrier: ablations of its loop (no MFMA / no
+// fragment reads / no window work / no epilogue) show the pieces ADD -- nothing runs under the matrix pipe.  Here, for a
+// 3x3 first segment whose tile lies inside one image:
+//   * two window buffers: the global loads of chunk q + 1 are issued in the first phases of chunk q, prologue + LDS
+//     stores follow ten phases later (BatchNorm affine x |code| per channel from an LDS table built once per tile);
+//   * a ring of R tap tiles fed by LDS-DMA R taps ahead, retired by COUNTED s_waitcnt vmcnt (never 0 in the loop);
+//   * a tap is two phases of 16 MFMAs (half of the wave's pixel fragments each), and every phase first issues the
+//     fragment reads of the NEXT phase into the other register set (activations: per phase; weights: per tap), so the
+//     wave's own LDS reads, window work and DMA issue sit in its MFMAs' shadow; ONE barrier per tap, after its first
+//     phase, publishes the next tap's weight tile (and, once per chunk, the next window).
+// Hazards: the counted wait for tap t + 1 and the barrier end phase (t, 0), its weight reads are issued in phase (t, 1);
+// slot t % R was last read in phase (t - 1, 1) and is re-filled from phase (t, 1) on (tap t + R); window buffer
+// (q + 1) & 1 is written in phases <= 16 of chunk q, behind the barrier of phase 16, and first read in phase 17.
+// Every wave issues the same VMEM sequence per phase (window loads are unconditional, clamped to a valid address; the
+// DMAs past the last tap re-load it into the free slot), so the vmcnt counts are compile-time constants (pp_vmcnt_*).
+// Further (1x1) segments run after the pipeline has drained, as in the dma3 form, on window buffer 0 and ring slots 0 / 1.
+template <int I, int E, typename F>
+static __device__ __forceinline__ void pp_static_for(F&& f) {
+    if constexpr (I < E) { f(std::integral_constant<int, I>{}); pp_static_for<I + 1, E>(f); }
+}
+constexpr int pp_mod(int a, int m) { return ((a % m) + m) % m; }
+// VMEM instructions a wave issues in chunk-local phase ph (negative: the previous chunk), in order: window load, DMA piece
+constexpr int pp_wl(int ph, int NIW) { return pp_mod(ph, 18) < NIW ? 1 : 0; }
+constexpr int pp_dma(int ph, int PPW) { return PPW == 2 ? 1 : (pp_mod(ph, 2) == 1 ? 1 : 0); }
+// wait at the END of even phase pc = (t, 0): this wave's pieces of tap t + 1 have landed.  Tap u's pieces are issued in
+// phases (u - R, 1) [piece 0] and (u - R + 1, 0) [piece 1, PPW == 2].
+constexpr int pp_vmcnt_b(int pc, int R, int NIW, int PPW) {
+    const int t = pc / 2;
+    const int plast = PPW == 2 ? 2 * (t + 2 - R) : 2 * (t + 1 - R) + 1;
+    int n = 0;
+    for (int ph = plast + 1; ph <= pc; ++ph) n += pp_wl(ph, NIW) + pp_dma(ph, PPW);
+    return n;
+}
+// wait at the START of phase pw, before that phase's own issues: window load j (issued in phase j, ahead of that phase's DMA)
+constexpr int pp_vmcnt_w(int j, int pw, int NIW, int PPW) {
+    int n = pp_dma(j, PPW);
+    for (int ph = j + 1; ph < pw; ++ph) n += pp_wl(ph, NIW) + pp_dma(ph, PPW);
+    return n;
+}
+template <int NCNT> static __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCNT) : "memory"); }
+static __device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+constexpr int PP_NIW = 3;            // window items per thread and chunk (host: 4 * window pixels <= PP_NIW * threads)
+
+// (LGW = log2 of the map width is a template parameter: every LDS address of the main loop is one per-lane base plus a
+// compile-time offset, i.e. the immediate field of the ds instruction -- no address VALU, no per-fragment registers.)
+template <int BM, int BN, int WM, int WN, int R, int LGW, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
+    using T = bf16_t;
+    using C = ConvCfg<T, BM, BN, WM, WN>;
+    using M = Mma<T>;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, APITCH = C::APITCH, BROW = C::BROW, BB = C::BBYTES;
+    constexpr int NW = WM * WN, KB = BB / 1024, PPW = KB / NW;
+    static_assert(KB % NW == 0 && (PPW == 1 || PPW == 2), "one or two 1 KB weight pieces per wave and tap");
+    static_assert(FM % 2 == 0, "two pixel halves per wave");
+    constexpr int NIW = PP_NIW, HF = FM / 2;
+    constexpr int PW0 = 10, PWS = 2;                       // window item j is stored in phase PW0 + PWS * j (<= 16)
+    static_assert(PW0 + PWS * (NIW - 1) <= 16 && 2 * R < 18, "window stores end before the chunk's last barrier");
+    constexpr int W = 1 << LGW, TH = BM / W, PC = W + 2, PR = TH + 2, PP = PR * PC;
+    static_assert(NIW == 3 && W >= 16 && PP * 4 <= NIW * NT && PP * 4 > (NIW - 1) * NT, "window items per thread");
+    constexpr int ITEM_STEP = (NT / 4) * APITCH;           // LDS distance between a thread's consecutive window items
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA0 = smem;
+    char* const ldsB0 = smem + 2 * a_bytes;
+    float* const aff = reinterpret_cast<float*>(ldsB0 + R * BB);   // [C0] scale * code, [C0] shift * code; then 16 B per thread: dump slots
+    float* epi = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = p.H, N = p.N;
+    const int tile_m = blockIdx.x;
+    const int cout0 = blockIdx.y * BN;
+    const Geo g = make_geo(BM, blockIdx.x, H, W);          // host guarantees TI == 1 and p.W == W
+    const int n_img = g.n0 < N ? g.n0 : N - 1;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const mcgen_seg_t sg0 = seg_for_tile(p.seg[0], g);
+    const int C0 = sg0.C, nchunk = C0 >> 5, T0 = nchunk * 9;
+    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+
+    // ---- per-channel prologue table: v -> max(v * sc + sh, relu ? 0 : -inf) with the code folded into sc, sh.  Under a ReLU
+    // that needs code >= 0 (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator,
+    // modules.py:73): a negative code poisons its channel with NaN instead of going wrong silently.
+    {
+        for (int c = tid; c < C0; c += NT) {
+            const float sc = sg0.scale ? sg0.scale[c] : 1.f, sh = sg0.scale ? sg0.shift[c] : 0.f;
+            float cd = sg0.code ? sg0.code[(size_t)n_img * C0 + c] : 1.f;
+            if (sg0.relu && cd < 0.f) cd = __builtin_nanf("");
+            aff[c] = sc * cd; aff[C0 + c] = sh * cd;
+        }
+    }
+
+    // ---- weight DMA: piece k of this wave, tap block blk -> ring slot ---------------------------------------------------
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    int d_src[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+        const int lgrp = pu ^ (3 * ((row >> 3) & 1));
+        d_src[k] = (cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + lgrp * 16 : (lane % UPR) * 16;
+    }
+    auto dma_piece = [&](int blk, int slot, int k) {
+        const char* src = wimg + (size_t)blk * wblock_bytes + d_src[k];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ldsB0 + slot * BB + (wave * PPW + k) * 1024), 16, 0, 0);
+    };
+    // weight fragment fn of this lane: row wn * (BN / WN) + 16 fn + l15 -- the swizzle term depends on l15 only
+    const int w_lane = (wn * (BN / WN) + l15) * BROW + (lg ^ (3 * ((l15 >> 3) & 1))) * 16;
+    // taps 0 .. R - 1 -> slots 0 .. R - 1, except the last piece of tap R - 1 (PPW == 2), which phase (0, 0) issues
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int k = 0; k < PPW; ++k)
+            if (!(PPW == 2 && t == R - 1 && k == 1)) dma_piece(t < T0 ? t : T0 - 1, t, k);
+
+    // ---- window items of this thread: item j = window unit tid + j * NT (unit = 8 channels of one window pixel) ----------
+    const T* xs0 = reinterpret_cast<const T*>(sg0.x);
+    const int sub = (tid & 3) * 8;
+    const int lds_item0 = (tid >> 2) * APITCH + (tid & 3) * 16;
+    int it_src[NIW];                                       // element offset of the source, -1: zero padding, -2: no such item
+    {
+        const int Hs = sg0.ups ? (H >> 1) : H, Ws = sg0.ups ? (W >> 1) : W;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int pp = (tid >> 2) + j * (NT / 4);
+            const int pr = pp / PC, pc = pp - pr * PC;
+            const int h = g.h0 + pr - 1, w = pc - 1;
+            it_src[j] = -1;
+            if (g.n0 < N && h >= 0 && h < H && w >= 0 && w < W) {
+                const int hs = sg0.ups ? (h >> 1) : h, ws = sg0.ups ? (w >> 1) : w;
+                it_src[j] = ((g.n0 * Hs + hs) * Ws + ws) * C0 + sub;
+            }
+            if (pp >= PP) it_src[j] = -2;
+        }
+    }
+    // (window loads and window stores are inline asm: hipcc drains vmcnt to 0 in front of a DS store it can see while LDS-DMA
+    // is in flight; the waits are the counted ones below)
+    auto wload = [&](int j, int c0, u32x4& r) {
+        const int off = it_src[j] >= 0 ? it_src[j] + c0 : 0;           // anything valid: zeroed / dropped below
+        const T* ptr = xs0 + off;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    };
+    // (straight-line on purpose: with branches around the stores hipcc spills ~50 registers into the main loop)
+    const float relu_lo = sg0.relu ? 0.f : -__builtin_inff();
+    const uint32_t lds_dump = (uint32_t)reinterpret_cast<uintptr_t>(reinterpret_cast<char*>(aff) + C0 * 8 + (C0 >> 1)) + tid * 16;
+    auto wwrite = [&](int j, const u32x4& r, char* abuf, int c0) {
+        union { bf16x8 h; u32x4 w; } o;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                               // four channels at a time: fewer live registers
+            const f32x4 a = *reinterpret_cast<const f32x4*>(aff + c0 + sub + 4 * hh);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(aff + C0 + c0 + sub + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float v0 = fmaxf(fmaf(__uint_as_float(r[2 * hh + i] << 16), a[2 * i], b[2 * i]), relu_lo);
+                const float v1 = fmaxf(fmaf(__uint_as_float(r[2 * hh + i] & 0xffff0000u), a[2 * i + 1], b[2 * i + 1]), relu_lo);
+                o.h[4 * hh + 2 * i] = (bf16_t)v0; o.h[4 * hh + 2 * i + 1] = (bf16_t)v1;
+            }
+        }
+        if (it_src[j] < 0) o.w = u32x4{0u, 0u, 0u, 0u};               // the convolution's zero padding
+        uint32_t la = (uint32_t)reinterpret_cast<uintptr_t>(abuf + lds_item0 + j * ITEM_STEP);
+        if (j == NIW - 1 && it_src[j] == -2) la = lds_dump;            // no such item: the store goes to this thread's dump slot
+        asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(o.w) : "memory");
+    };
+    // activation fragment fm of this lane: tile pixel wm * (BM / WM) + 16 fm + l15 (16 | W: the fm part is a constant)
+    const int a_lane = (((wm * (BM / WM)) >> LGW) * PC + l15) * APITCH + lg * 16;
+    auto a_off = [](int fm) constexpr { return (((fm * 16) >> LGW) * PC + ((fm * 16) & (W - 1))) * APITCH; };
+
+    // window of chunk 0 (needs the table)
+    __syncthreads();
+    {
+        u32x4 raw0[NIW];
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) wload(j, 0, raw0[j]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) wwrite(j, raw0[j], ldsA0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+
+    // ---- main loop ------------------------------------------------------------------------------------------------
+    // registers: activations af[phase parity] (the next phase's half is read while this one multiplies); weights wf, one
+    // set: in a tap's second phase the MFMAs run weight fragment by weight fragment and each fragment is re-read for
+    // the next tap as soon as its four MFMAs are issued.  Phase 0's fragments are read here.
+    typename M::frag af[2][HF], wf[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB0 + w_lane + fn * 16 * BROW);
+#pragma unroll
+    for (int i = 0; i < HF; ++i) af[0][i] = *reinterpret_cast<const typename M::frag*>(ldsA0 + a_lane + a_off(i));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int slot_c = 0, tcur = 0;                              // ring slot / index of the tap being computed
+    u32x4 raw[NIW];
+#pragma unroll 1
+    for (int q = 0; q < nchunk; ++q) {
+        const char* acur = ldsA0 + ((q & 1) ? a_bytes : 0) + a_lane;
+        const char* anxr = ldsA0 + ((q & 1) ? 0 : a_bytes) + a_lane;
+        char* anext = ldsA0 + ((q & 1) ? 0 : a_bytes);
+        const int cn = (q + 1 < nchunk ? q + 1 : q) * MCGEN_CK;       // last chunk: re-stages itself into the idle buffer
+        pp_static_for<0, 18>([&](auto PH) {
+            constexpr int ph = decltype(PH)::value, k = ph >> 1, h = ph & 1;
+            constexpr int np = (ph + 1) % 18, nk = np >> 1, nh = np & 1;
+            constexpr int ntapoff = ((nk / 3) * PC + (nk % 3)) * APITCH;
+            constexpr int cs = ph & 1, ns = cs ^ 1;                      // activation sets: this phase / the next
+            // ---- activation fragments of the next phase
+            {
+                const char* asrc = (ph == 17) ? anxr : acur;
+#pragma unroll
+                for (int i = 0; i < HF; ++i) af[ns][i] = *reinterpret_cast<const typename M::frag*>(asrc + a_off(nh * HF + i) + ntapoff);
+            }
+            // ---- window of the next chunk: stores of the loads issued in phases 0 .. 2
+            if constexpr (ph >= PW0 && (ph - PW0) % PWS == 0 && (ph - PW0) / PWS < NIW) {
+                constexpr int j = (ph - PW0) / PWS;
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[j]) : "n"(pp_vmcnt_w(j, ph, NIW, PPW)) : "memory");
+                wwrite(j, raw[j], anext, cn);
+            }
+            if constexpr (ph < NIW) wload(ph, cn, raw[ph]);
+            // ---- weight DMA R taps ahead: piece 0 in the tap's second phase (its slot's reads are behind the barrier), piece 1 next
+            if constexpr (h == 1) {
+                const int blk = tcur + R < T0 ? tcur + R : T0 - 1;
+                dma_piece(blk, slot_c, 0);
+            } else if constexpr (PPW == 2) {
+                const int blk = tcur + R - 1 < T0 ? tcur + R - 1 : T0 - 1;
+                const int sp = slot_c == 0 ? R - 1 : slot_c - 1;
+                dma_piece(blk, sp, 1);
+            }
+            // ---- this phase's MFMAs
+            if constexpr (h == 0) {
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                    for (int i = 0; i < HF; ++i) M::run(wf[fn], af[cs][i], acc[fn][i]);
+            } else {
+                const int sn = (slot_c + 1 == R) ? 0 : slot_c + 1;
+                const char* ldsB = ldsB0 + sn * BB + w_lane;
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+#pragma unroll
+                    for (int i = 0; i < HF; ++i) M::run(wf[fn], af[cs][i], acc[fn][HF + i]);
+                    wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + fn * 16 * BROW);   // the next tap's
+                }
+            }
+            if constexpr (h == 0) {
+                // every LDS read of this wave so far is complete (the slot re-filled next, the window buffer stored next) ...
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pp_wait_vm<pp_vmcnt_b(ph, R, NIW, PPW)>();           // ... tap + 1 has landed (this wave's pieces) ...
+                pp_barrier();                                          // ... everyone's; window stores of this chunk so far too
+            } else {
+                slot_c = (slot_c + 1 == R) ? 0 : slot_c + 1;
+                ++tcur;
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- further (1x1) segments: synchronous, window buffer 0, ring slots 0 / 1 ---------------------------------------
+    if (p.nseg > 1) {
+        int blk = T0, tg = 0;
+        int nrest = 0;
+        for (int s = 1; s < p.nseg; ++s) nrest += (p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK;
+        pp_barrier();                                          // every wave is past its last ring / window read
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) dma_piece(blk, 0, k);
+        for (int s = 1; s < p.nseg; ++s) {
+            const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
+            PatchStager<T, NT, C::NI, APITCH> stager;
+            stager.setup(sg, g, N, H, W, tid);
+            const int b_lane = (wm * (BM / WM) + l15) * APITCH + lg * 16;
+            const int nch = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+#pragma unroll 1
+            for (int q = 0; q < nch; ++q) {
+                __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
+                stager.stage(sg, q * MCGEN_CK, ldsA0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (tg + 1 < nrest) {
+#pragma unroll
+                    for (int k = 0; k < PPW; ++k) dma_piece(blk + 1, (tg + 1) & 1, k);
+                }
+                const char* ldsB = ldsB0 + (tg & 1) * BB + w_lane;
+                typename M::frag xf[FM], yf[FN];
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const typename M::frag*>(ldsA0 + b_lane + fm * 16 * APITCH);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) yf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + fn * 16 * BROW);
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) M::run(yf[fn], xf[fm], acc[fn][fm]);
+                ++tg; ++blk;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (ABL == 2) {
+        if (p.N < 0) conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else {
+        conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+    }
+}
+
+#ifndef MCGEN_KERNELS_ONLY      // (tools/micro builds include this file for one kernel's ISA)
 // ---- host side ----------------------------------------------------------------------------------
 struct TilePick { int BM, BN, pipe; };
 
@@ -1727,6 +2053,51 @@ static int dispatch_gk(const mcgen_conv_t* p, int dtype, hipStream_t st) {
     return launch_gk<128, 128, 2, 2>(p, st);
 }
 
+// "pp" form (conv_pp_kernel): 3x3 first segment with whole 32-channel chunks, further segments 1x1, tile inside one image,
+// window small enough for PP_NIW items per thread, two windows + ring + table within the CU's LDS.
+template <int BM, int BN, int WM, int WN, int R>
+static bool pp_fits(const mcgen_conv_t* p) {
+    using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
+    if (p->w_layout != 0 || p->H * p->W < BM || (p->W != 16 && p->W != 32)) return false;
+    if (p->seg[0].ksize != 3 || p->seg[0].C % MCGEN_CK != 0 || p->seg[0].C < 2 * MCGEN_CK || p->seg[0].cmap) return false;
+    for (int s = 1; s < p->nseg; ++s) if (p->seg[s].ksize != 1 || p->seg[s].cmap) return false;
+    const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
+    if (PP * 4 > PP_NIW * C::NT) return false;
+    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + p->seg[0].C / 2 + C::NT * 16;
+    return lds <= 160 * 1024;
+}
+template <int BM, int BN, int WM, int WN, int R>
+static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
+    using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
+    const long Mtot = (long)p->N * p->H * p->W;
+    const int mt = (int)(Mtot / BM);
+    const int nt = (p->Cout_w + BN - 1) / BN;
+    const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
+    const int a_bytes = round_up(PP * C::APITCH, 1024);
+    int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + p->seg[0].C / 2 + C::NT * 16;
+    const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
+    if (epi_bytes > lds) lds = epi_bytes;
+    if (red_bytes > lds) lds = red_bytes;
+    MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(pp): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
+    void (*kern)(const mcgen_conv_t, const int) = p->W == 32 ? conv_pp_kernel<BM, BN, WM, WN, R, 5> : conv_pp_kernel<BM, BN, WM, WN, R, 4>;
+#ifdef MCGEN_TUNING
+    static const long abl = env_long("MCGEN_PP_ABL", 0);
+    if (abl == 2 && p->W == 32) kern = conv_pp_kernel<BM, BN, WM, WN, R, 5, 2>;
+#endif
+    // (LDS limit per kernel symbol; tuning builds switch symbols, so they set it on every launch)
+#ifdef MCGEN_TUNING
+    int raised_now = 0;
+    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised_now)) return rc;
+#else
+    static int raised[2] = {0, 0};
+    if (int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, &raised[p->W == 32])) return rc;
+#endif
+    hipLaunchKernelGGL(kern, dim3(mt, nt), dim3(C::NT), lds, st, *p, a_bytes);
+    MCGEN_LAUNCH_CHECK("conv_fused(pp)");
+    return 0;
+}
+
 typedef int (*launch_fn)(const mcgen_conv_t*, hipStream_t);
 struct CfgEntry { int BM, BN, pipe; launch_fn fn; };
 
@@ -1764,6 +2135,10 @@ static const CfgEntry* bf16_table(int* n) {
 }
 
 static int dispatch(const mcgen_conv_t* p, int dtype, const TilePick& t, hipStream_t st) {
+    // the big tile's 3x3 launches go through the two-group pipeline (tuning builds: MCGEN_PP=0 switches it off)
+    static const long pp_mode = env_long("MCGEN_PP", 1);
+    if (dtype == MCGEN_BF16 && pp_mode && t.BM == 256 && t.BN == 256 && t.pipe == 5 && pp_fits<256, 256, 2, 4, 5>(p))
+        return launch_pp<256, 256, 2, 4, 5>(p, st);
     int n = 0;
     const CfgEntry* tab = dtype == MCGEN_BF16 ? bf16_table(&n) : f32_table(&n);
     for (int i = 0; i < n; ++i)
@@ -1845,3 +2220,4 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (dtype != MCGEN_F32 && dtype != MCGEN_BF16) return mcgen_fail("conv_fused: unknown dtype %d", dtype);
     return dispatch(p, dtype, t, st);
 }
+#endif  // MCGEN_KERNELS_ONLY

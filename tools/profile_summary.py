@@ -22,6 +22,9 @@ def bench_name(k: str):
     m = re.search(r'conv_\w+?_kernelI(DF16b|f)Li(\d+)ELi(\d+)E', k)
     if m:
         return f'conv_fused<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)},{m.group(3)}>'
+    m = re.search(r'conv_(gk|mc)_kernelILi(\d+)ELi(\d+)E', k)          # K-major forms: bf16 only, no dtype parameter
+    if m:
+        return f'conv_fused<bf16,{m.group(2)},{m.group(3)},{m.group(1)}>'
     if 'wgrad_reduce' in k:
         return None
     m = re.search(r'wgrad_ring_kernel(?:ILi|<)(\d+)', k)        # bf16-only LDS-DMA ring form
