@@ -1493,7 +1493,11 @@ constexpr int PP_NIW = 3;            // window items per thread and chunk (host:
 
 // (LGW = log2 of the map width is a template parameter: every LDS address of the main loop is one per-lane base plus a
 // compile-time offset, i.e. the immediate field of the ds instruction -- no address VALU, no per-fragment registers.)
-template <int BM, int BN, int WM, int WN, int R, int LGW, int ABL = 0>
+// GK: the K-major / gathered-K weight form of conv_gk_kernel (compacted activations): the window side is the same (its
+// channels are the image's compacted ones, the affine rows are per image), a tap tile is 32 k-rows of BN channels whose
+// rows are the image's cidx entries (read through the scalar cache one chunk ahead), fragments come from transposing reads,
+// and the number of chunks is the IMAGE's: ceil(active channels / 32).
+template <int BM, int BN, int WM, int WN, int R, int LGW, bool GK = false, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN)
 void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     using T = bf16_t;
@@ -1509,6 +1513,9 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     constexpr int W = 1 << LGW, TH = BM / W, PC = W + 2, PR = TH + 2, PP = PR * PC;
     static_assert(NIW == 3 && W >= 16 && PP * 4 <= NIW * NT && PP * 4 > (NIW - 1) * NT, "window items per thread");
     constexpr int ITEM_STEP = (NT / 4) * APITCH;           // LDS distance between a thread's consecutive window items
+    // K-major tap tile: 32 rows of ROWB bytes, RPPK rows per 1 KB DMA piece, LPR lanes per row
+    constexpr int ROWB = BN * 2, RPPK = 1024 / ROWB, LPR = 64 / RPPK;
+    static_assert(!GK || ((BN == 128 || BN == 256) && 32 * ROWB == BB), "k-major tap tiles: 2 or 4 rows per DMA piece");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsA0 = smem;
@@ -1534,10 +1541,96 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const mcgen_seg_t sg0 = seg_for_tile(p.seg[0], g);
-    const int C0 = sg0.C, nchunk = C0 >> 5, T0 = nchunk * 9;
+    const int C0 = sg0.C;
     const char* wimg = reinterpret_cast<const char*>(p.w);
     const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
+    // gathered-K bookkeeping of a segment (wave-uniform): weight rows of the image, its active count
+    auto seg_info = [&](int si, const int16_t*& cidx, int& cw, int& cnt) {
+        const mcgen_seg_t& sg = p.seg[si];
+        cw = sg.Cw > 0 ? sg.Cw : sg.C;
+        cidx = nullptr; cnt = sg.C;
+        if (sg.cmap) {
+            const int16_t* rec = sg.cmap + (size_t)n_img * sg.cmap_stride;
+            cidx = rec + cw;
+            cnt = (int)mc_sload(rec + 2 * cw + 32 + 2 * ((cw + 31) >> 5));
+            if (cnt > sg.C) cnt = sg.C;                    // (the host sized the compacted pitch to hold every sample)
+        }
+    };
+    const int16_t* cidx0 = nullptr; int cw0 = C0, cnt0 = C0;
+    if constexpr (GK) seg_info(0, cidx0, cw0, cnt0);
+    const int nchunk = GK ? ((cnt0 + 31) >> 5) : (C0 >> 5), T0 = nchunk * 9;
+    const size_t tapstride0 = (size_t)(cw0 + 1) * p.Cout_w * 2;          // (GK) bytes per tap of segment 0's image
 
+    // ---- weight DMA: piece k of this wave -> ring slot -----------------------------------------------------------------
+    // dense form: tap block blk of the [chunk][tap][cout][32] image.  GK: tap `tap` of the k-major image, row = the lane's
+    // dense channel of the chunk (ksel), LDS row rho holds k(rho) so that the transposing reads deliver natural k order.
+    constexpr int UPR = C::UPR, RPP = 64 / UPR;
+    int d_src[PPW];                                        // dense: byte offset inside a tap block; GK: byte offset of the lane's channels inside a row
+    int k0_[PPW];                                          // GK: first k of the piece's rows
+    const int rsub = lane / LPR, ci = lane % LPR;          // GK: row inside the piece, 16-byte unit inside the row
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int piece = wave * PPW + k;
+        if constexpr (!GK) {
+            const int row = piece * RPP + lane / UPR, pu = lane % UPR;
+            const int lgrp = pu ^ (3 * ((row >> 3) & 1));
+            d_src[k] = (cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + lgrp * 16 : (lane % UPR) * 16;
+            k0_[k] = 0;
+        } else {
+            const int rho0 = RPPK * piece, rho = rho0 + rsub;
+            k0_[k] = (rho0 < 16) ? 8 * (rho0 >> 2) + (rho0 & 3) : 8 * ((rho0 - 16) >> 2) + 4 + ((rho0 - 16) & 3);
+            int co = cout0 + 16 * ((ci >> 1) ^ (rho & 7)) + 8 * (ci & 1);
+            if (co > p.Cout_w - 8) co = p.Cout_w - 8;
+            d_src[k] = co * 2;
+        }
+    }
+    // (GK) the lane's weight row for chunk t, piece k: cidx[32 t + k0 + rsub] (scalar-cache dwords, selected per lane) or,
+    // for a dense segment, 32 t + k0 + rsub clamped to the zero row
+    auto ksel_map = [&](const int16_t* cidx, int t, int k) -> int {       // (branch-free: the main loop calls it)
+        const uint32_t d01 = mc_sload(cidx + 32 * t + k0_[k]);
+        uint32_t sel = d01;
+        if constexpr (RPPK == 4) {
+            const uint32_t d23 = mc_sload(cidx + 32 * t + k0_[k] + 2);
+            sel = (rsub & 2) ? d23 : d01;
+        }
+        return (int)((rsub & 1) ? (sel >> 16) : (sel & 0xffffu));
+    };
+    auto ksel = [&](const int16_t* cidx, int cw, int t, int k) -> int {
+        if (cidx) return ksel_map(cidx, t, k);
+        const int d = 32 * t + k0_[k] + rsub;
+        return d > cw ? cw : d;
+    };
+    int krow_c[PPW], krow_n[PPW];                          // (GK) byte offset of the lane's row + channels inside a tap: the chunk being DMA'd / the next one
+    auto dma_piece = [&](int blk, int slot, int k) {       // dense form
+        const char* src = wimg + (size_t)blk * wblock_bytes + d_src[k];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ldsB0 + slot * BB + (wave * PPW + k) * 1024), 16, 0, 0);
+    };
+    auto dma_piece_gk = [&](const char* wseg, size_t tapstride, int krow, int tap, int slot, int k) {
+        const char* src = wseg + (size_t)tap * tapstride + krow;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ldsB0 + slot * BB + (wave * PPW + k) * 1024), 16, 0, 0);
+    };
+    // weight fragment fn of this lane.  dense: row wn * (BN / WN) + 16 fn + l15 (the swizzle term depends on l15 only: one
+    // base + constants).  GK: two transposing reads at rows 4 lg + q and 16 + 4 lg + q, 32-byte slot XOR-swizzled by the row
+    const int w_lane = (wn * (BN / WN) + l15) * BROW + (lg ^ (3 * ((l15 >> 3) & 1))) * 16;
+    // GK: row r0 = 4 lg + q4, 32-byte slot (c0 >> 4) ^ (r0 & 7) with c0 >> 4 = 4 wn + fn: the fn part is (fn ^ q4) -- one base
+    // register plus an XOR per read instead of a register per fragment
+    const int q4 = l15 >> 2;
+    const int w_gk = (4 * lg + q4) * ROWB + 32 * ((4 * wn) ^ (4 * (lg & 1))) + 8 * (l15 & 3);
+    auto wfrag = [&](const char* slotp, int fn) -> typename M::frag {
+        if constexpr (GK) {
+            union { bf16x8 v; s16x4 h[2]; } u;
+            const int o = w_gk + 32 * (fn ^ q4);
+            u.h[0] = mc_tr16(slotp + o);
+            u.h[1] = mc_tr16(slotp + o + 16 * ROWB);
+            return u.v;
+        } else {
+            return *reinterpret_cast<const typename M::frag*>(slotp + w_lane + fn * 16 * BROW);
+        }
+    };
+
+    if (nchunk > 0) {       // (GK: an image without active channels contributes nothing from this segment)
     // ---- per-channel prologue table: v -> max(v * sc + sh, relu ? 0 : -inf) with the code folded into sc, sh.  Under a ReLU
     // that needs code >= 0 (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator,
     // modules.py:73): a negative code poisons its channel with NaN instead of going wrong silently.
@@ -1549,30 +1642,19 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
             aff[c] = sc * cd; aff[C0 + c] = sh * cd;
         }
     }
-
-    // ---- weight DMA: piece k of this wave, tap block blk -> ring slot ---------------------------------------------------
-    constexpr int UPR = C::UPR, RPP = 64 / UPR;
-    int d_src[PPW];
-#pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-        const int piece = wave * PPW + k;
-        const int row = piece * RPP + lane / UPR, pu = lane % UPR;
-        const int lgrp = pu ^ (3 * ((row >> 3) & 1));
-        d_src[k] = (cout0 + row < p.Cout_w) ? (cout0 + row) * BROW + lgrp * 16 : (lane % UPR) * 16;
-    }
-    auto dma_piece = [&](int blk, int slot, int k) {
-        const char* src = wimg + (size_t)blk * wblock_bytes + d_src[k];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(ldsB0 + slot * BB + (wave * PPW + k) * 1024), 16, 0, 0);
-    };
-    // weight fragment fn of this lane: row wn * (BN / WN) + 16 fn + l15 -- the swizzle term depends on l15 only
-    const int w_lane = (wn * (BN / WN) + l15) * BROW + (lg ^ (3 * ((l15 >> 3) & 1))) * 16;
     // taps 0 .. R - 1 -> slots 0 .. R - 1, except the last piece of tap R - 1 (PPW == 2), which phase (0, 0) issues
+    if constexpr (GK) {
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) krow_c[k] = ksel_map(cidx0, 0, k) * p.Cout_w * 2 + d_src[k];      // (host: segment 0 of a pp launch has a map)
+    }
 #pragma unroll
     for (int t = 0; t < R; ++t)
 #pragma unroll
         for (int k = 0; k < PPW; ++k)
-            if (!(PPW == 2 && t == R - 1 && k == 1)) dma_piece(t < T0 ? t : T0 - 1, t, k);
+            if (!(PPW == 2 && t == R - 1 && k == 1)) {
+                if constexpr (GK) dma_piece_gk(wimg, tapstride0, krow_c[k], t, t, k);      // (R <= 9: all in chunk 0)
+                else dma_piece(t < T0 ? t : T0 - 1, t, k);
+            }
 
     // ---- window items of this thread: item j = window unit tid + j * NT (unit = 8 channels of one window pixel) ----------
     const T* xs0 = reinterpret_cast<const T*>(sg0.x);
@@ -1646,7 +1728,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     // the next tap as soon as its four MFMAs are issued.  Phase 0's fragments are read here.
     typename M::frag af[2][HF], wf[FN];
 #pragma unroll
-    for (int fn = 0; fn < FN; ++fn) wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB0 + w_lane + fn * 16 * BROW);
+    for (int fn = 0; fn < FN; ++fn) wf[fn] = wfrag(ldsB0, fn);
 #pragma unroll
     for (int i = 0; i < HF; ++i) af[0][i] = *reinterpret_cast<const typename M::frag*>(ldsA0 + a_lane + a_off(i));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1657,7 +1739,8 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         const char* acur = ldsA0 + ((q & 1) ? a_bytes : 0) + a_lane;
         const char* anxr = ldsA0 + ((q & 1) ? 0 : a_bytes) + a_lane;
         char* anext = ldsA0 + ((q & 1) ? 0 : a_bytes);
-        const int cn = (q + 1 < nchunk ? q + 1 : q) * MCGEN_CK;       // last chunk: re-stages itself into the idle buffer
+        const bool more = q + 1 < nchunk;
+        const int cn = (more ? q + 1 : q) * MCGEN_CK;                 // last chunk: re-stages itself into the idle buffer
         pp_static_for<0, 18>([&](auto PH) {
             constexpr int ph = decltype(PH)::value, k = ph >> 1, h = ph & 1;
             constexpr int np = (ph + 1) % 18, nk = np >> 1, nh = np & 1;
@@ -1669,6 +1752,11 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 #pragma unroll
                 for (int i = 0; i < HF; ++i) af[ns][i] = *reinterpret_cast<const typename M::frag*>(asrc + a_off(nh * HF + i) + ntapoff);
             }
+            // ---- (GK) weight rows of the next chunk, ahead of the first DMA that needs them (phase 2 R - 1 ... of this chunk)
+            if constexpr (GK && ph == 1) {
+#pragma unroll
+                for (int kk = 0; kk < PPW; ++kk) krow_n[kk] = ksel_map(cidx0, more ? q + 1 : q, kk) * p.Cout_w * 2 + d_src[kk];
+            }
             // ---- window of the next chunk: stores of the loads issued in phases 0 .. 2
             if constexpr (ph >= PW0 && (ph - PW0) % PWS == 0 && (ph - PW0) / PWS < NIW) {
                 constexpr int j = (ph - PW0) / PWS;
@@ -1677,13 +1765,17 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
             }
             if constexpr (ph < NIW) wload(ph, cn, raw[ph]);
             // ---- weight DMA R taps ahead: piece 0 in the tap's second phase (its slot's reads are behind the barrier), piece 1 next
-            if constexpr (h == 1) {
-                const int blk = tcur + R < T0 ? tcur + R : T0 - 1;
-                dma_piece(blk, slot_c, 0);
-            } else if constexpr (PPW == 2) {
-                const int blk = tcur + R - 1 < T0 ? tcur + R - 1 : T0 - 1;
-                const int sp = slot_c == 0 ? R - 1 : slot_c - 1;
-                dma_piece(blk, sp, 1);
+            if constexpr (h == 1 || PPW == 2) {
+                constexpr int lt = h == 1 ? k + R : k + R - 1;             // chunk-local index of the tap to load
+                constexpr int pk = h == 1 ? 0 : 1;                         // which of the wave's pieces
+                const int slot = h == 1 ? slot_c : (slot_c == 0 ? R - 1 : slot_c - 1);
+                if constexpr (GK) {
+                    if constexpr (lt < 9) dma_piece_gk(wimg, tapstride0, krow_c[pk], lt, slot, pk);
+                    else dma_piece_gk(wimg, tapstride0, krow_n[pk], more ? lt - 9 : 8, slot, pk);   // past the end: the last tap again
+                } else {
+                    const int blk = tcur - k + lt < T0 ? tcur - k + lt : T0 - 1;
+                    dma_piece(blk, slot, pk);
+                }
             }
             // ---- this phase's MFMAs
             if constexpr (h == 0) {
@@ -1693,12 +1785,12 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                     for (int i = 0; i < HF; ++i) M::run(wf[fn], af[cs][i], acc[fn][i]);
             } else {
                 const int sn = (slot_c + 1 == R) ? 0 : slot_c + 1;
-                const char* ldsB = ldsB0 + sn * BB + w_lane;
+                const char* ldsB = ldsB0 + sn * BB;
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn) {
 #pragma unroll
                     for (int i = 0; i < HF; ++i) M::run(wf[fn], af[cs][i], acc[fn][HF + i]);
-                    wf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + fn * 16 * BROW);   // the next tap's
+                    wf[fn] = wfrag(ldsB, fn);                                   // the next tap's
                 }
             }
             if constexpr (h == 0) {
@@ -1711,23 +1803,39 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                 ++tcur;
             }
         });
+        if constexpr (GK) {
+#pragma unroll
+            for (int kk = 0; kk < PPW; ++kk) krow_c[kk] = krow_n[kk];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }       // nchunk > 0
 
     // ---- further (1x1) segments: synchronous, window buffer 0, ring slots 0 / 1 ---------------------------------------
     if (p.nseg > 1) {
         int blk = T0, tg = 0;
         int nrest = 0;
-        for (int s = 1; s < p.nseg; ++s) nrest += (p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK;
-        pp_barrier();                                          // every wave is past its last ring / window read
+        // (GK: one further segment; its chunks are the image's active ones)
+        const int16_t* cidx1 = nullptr; int cw1 = 8, cnt1 = 0;
+        if constexpr (GK) { seg_info(1, cidx1, cw1, cnt1); nrest = (cnt1 + 31) >> 5; }
+        else for (int s = 1; s < p.nseg; ++s) nrest += (p.seg[s].C + MCGEN_CK - 1) / MCGEN_CK;
+        const char* wseg1 = wimg + 9 * tapstride0;
+        const size_t tapstride1 = (size_t)(cw1 + 1) * p.Cout_w * 2;
+        auto tail_dma = [&](int t, int slot) {
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) dma_piece(blk, 0, k);
+            for (int k = 0; k < PPW; ++k) {
+                if constexpr (GK) dma_piece_gk(wseg1, tapstride1, ksel(cidx1, cw1, t, k) * p.Cout_w * 2 + d_src[k], 0, slot, k);
+                else dma_piece(T0 + t, slot, k);
+            }
+        };
+        pp_barrier();                                          // every wave is past its last ring / window read
+        if (nrest > 0) tail_dma(0, 0);
         for (int s = 1; s < p.nseg; ++s) {
             const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
             PatchStager<T, NT, C::NI, APITCH> stager;
             stager.setup(sg, g, N, H, W, tid);
             const int b_lane = (wm * (BM / WM) + l15) * APITCH + lg * 16;
-            const int nch = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+            const int nch = GK ? nrest : (sg.C + MCGEN_CK - 1) / MCGEN_CK;
 #pragma unroll 1
             for (int q = 0; q < nch; ++q) {
                 __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
@@ -1735,16 +1843,13 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (tg + 1 < nrest) {
-#pragma unroll
-                    for (int k = 0; k < PPW; ++k) dma_piece(blk + 1, (tg + 1) & 1, k);
-                }
-                const char* ldsB = ldsB0 + (tg & 1) * BB + w_lane;
+                if (tg + 1 < nrest) tail_dma(tg + 1, (tg + 1) & 1);
+                const char* ldsB = ldsB0 + (tg & 1) * BB;
                 typename M::frag xf[FM], yf[FN];
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const typename M::frag*>(ldsA0 + b_lane + fm * 16 * APITCH);
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn) yf[fn] = *reinterpret_cast<const typename M::frag*>(ldsB + fn * 16 * BROW);
+                for (int fn = 0; fn < FN; ++fn) yf[fn] = wfrag(ldsB, fn);
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
@@ -1771,7 +1876,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 struct TilePick { int BM, BN, pipe; };
 
 // pipe codes: 0 = simple register-staged form (fp32 parity build), 5 = dma3 (4 or 8 waves as the table says),
-// 11 = dma3 on the 64x64 tile with 8 waves (4 x 2), 12 = chunk-pipelined "cp" form.
+// 11 = dma3 on the 64x64 tile with 8 waves (4 x 2), 12 = chunk-pipelined "cp" form, 20 = software-pipelined "pp" form.
 // Tuning builds (-DMCGEN_TUNING) read the overrides below ONCE per process; the shipped library has no
 // environment-dependent dispatch.
 #ifdef MCGEN_TUNING
@@ -1782,6 +1887,8 @@ static long env_long(const char*, long dflt) { return dflt; }
 
 // Output tile: widest channel tile the layer fills, then the largest pixel tile that still gives
 // every CU a workgroup (256 CUs); fp32 (parity build) is limited by LDS to the two small tiles.
+template <int BM, int BN, int WM, int WN, int R> static bool pp_fits(const mcgen_conv_t* p);
+
 static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     const long M = (long)p->N * p->H * p->W;
     if (p->Cout_w <= 16) {
@@ -1811,7 +1918,10 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     // measured on MI355X (tools/bench_conv.py, profiles/): the LDS-DMA weight ring with three taps per
     // barrier ("dma3" form) wins on every shape; big tiles only where there are enough pixels to fill 256 CUs
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
-    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, 5};
+    // pipe 20: the software-pipelined form of the 3x3 main loop ("pp"), where its window / ring / item plan fits (pp_fits)
+    static const long pp_mode = env_long("MCGEN_PP", 7);       // tuning builds: bit 0 = the 256x256 tile, bit 1 = 256x128 (bit 2: gathered K)
+    if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, ((pp_mode & 1) && pp_fits<256, 256, 2, 4, 5>(p)) ? 20 : 5};
+    if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, 2, 4, 5>(p)) return {256, 128, 20};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, 5};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
@@ -2011,6 +2121,9 @@ static int dispatch_mc(const mcgen_conv_t* p, int dtype, hipStream_t st) {
     return launch_mc<128, 128, 2, 2>(p, st);
 }
 
+template <int BM, int BN, int WM, int WN, int R, bool GK> static bool pp_fits_(const mcgen_conv_t* p);
+template <typename T, int BM, int BN, int WM, int WN, int R, bool GK> static int launch_pp(const mcgen_conv_t* p, hipStream_t st);
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gk(const mcgen_conv_t* p, hipStream_t st) {
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
@@ -2048,6 +2161,9 @@ static int dispatch_gk(const mcgen_conv_t* p, int dtype, hipStream_t st) {
     MCGEN_CHECK(p->Cout_w % 8 == 0 && p->Cout_w >= 64, "conv_fused(gk): at least 64 output channels");
     int bm = 0, bn = 0;
     MCGEN_CHECK(mc_tile(p, &bm, &bn), "conv_fused(gk): no tile of a %dx%d map lies inside one image", p->H, p->W);
+    // the big tile's 3x3 launches with a mapped first segment: the software-pipelined form (tuning builds: MCGEN_PP bit 2 off)
+    static const long pp_mode = env_long("MCGEN_PP", 7);
+    if (bm == 256 && bn == 256 && (pp_mode & 4) && pp_fits_<256, 256, 2, 4, 5, true>(p)) return launch_pp<bf16_t, 256, 256, 2, 4, 5, true>(p, st);
     if (bm == 256 && bn == 256) return launch_gk<256, 256, 2, 4>(p, st);
     if (bm == 128 && bn == 256) return launch_gk<128, 256, 2, 4>(p, st);
     return launch_gk<128, 128, 2, 2>(p, st);
@@ -2055,12 +2171,13 @@ static int dispatch_gk(const mcgen_conv_t* p, int dtype, hipStream_t st) {
 
 // "pp" form (conv_pp_kernel): 3x3 first segment with whole 32-channel chunks, further segments 1x1, tile inside one image,
 // window small enough for PP_NIW items per thread, two windows + ring + table within the CU's LDS.
-template <int BM, int BN, int WM, int WN, int R>
-static bool pp_fits(const mcgen_conv_t* p) {
+template <int BM, int BN, int WM, int WN, int R, bool GK>
+static bool pp_fits_(const mcgen_conv_t* p) {
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
-    if (p->w_layout != 0 || p->H * p->W < BM || (p->W != 16 && p->W != 32)) return false;
-    if (p->seg[0].ksize != 3 || p->seg[0].C % MCGEN_CK != 0 || p->seg[0].C < 2 * MCGEN_CK || p->seg[0].cmap) return false;
-    for (int s = 1; s < p->nseg; ++s) if (p->seg[s].ksize != 1 || p->seg[s].cmap) return false;
+    if (p->w_layout != (GK ? 2 : 0) || p->H * p->W < BM || (p->W != 16 && p->W != 32)) return false;
+    if (p->seg[0].ksize != 3 || p->seg[0].C % MCGEN_CK != 0 || p->seg[0].C < 2 * MCGEN_CK) return false;
+    if ((p->seg[0].cmap != nullptr) != GK) return false;               // gathered K: the first segment's rows come from its map
+    for (int s = 1; s < p->nseg; ++s) if (p->seg[s].ksize != 1 || (!GK && p->seg[s].cmap)) return false;
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
     if (PP * 4 > PP_NIW * C::NT) return false;
     const int a_bytes = round_up(PP * C::APITCH, 1024);
@@ -2068,7 +2185,10 @@ static bool pp_fits(const mcgen_conv_t* p) {
     return lds <= 160 * 1024;
 }
 template <int BM, int BN, int WM, int WN, int R>
+static bool pp_fits(const mcgen_conv_t* p) { return pp_fits_<BM, BN, WM, WN, R, false>(p); }
+template <typename T, int BM, int BN, int WM, int WN, int R, bool GK>
 static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
+    static_assert(sizeof(T) == 2, "the pp form is bf16");
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
     const long Mtot = (long)p->N * p->H * p->W;
     const int mt = (int)(Mtot / BM);
@@ -2080,10 +2200,10 @@ static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(pp): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
-    void (*kern)(const mcgen_conv_t, const int) = p->W == 32 ? conv_pp_kernel<BM, BN, WM, WN, R, 5> : conv_pp_kernel<BM, BN, WM, WN, R, 4>;
+    void (*kern)(const mcgen_conv_t, const int) = p->W == 32 ? conv_pp_kernel<BM, BN, WM, WN, R, 5, GK> : conv_pp_kernel<BM, BN, WM, WN, R, 4, GK>;
 #ifdef MCGEN_TUNING
     static const long abl = env_long("MCGEN_PP_ABL", 0);
-    if (abl == 2 && p->W == 32) kern = conv_pp_kernel<BM, BN, WM, WN, R, 5, 2>;
+    if (abl == 2 && p->W == 32) kern = conv_pp_kernel<BM, BN, WM, WN, R, 5, GK, 2>;
 #endif
     // (LDS limit per kernel symbol; tuning builds switch symbols, so they set it on every launch)
 #ifdef MCGEN_TUNING
@@ -2120,6 +2240,7 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 128, 5, launch_dma<T, 128, 128, 2, 2>}, {64, 128, 5, launch_dma<T, 64, 128, 2, 2>},
         {64, 64, 11, launch_dma<T, 64, 64, 4, 2>},    {256, 16, 5, launch_dma<T, 256, 16, 8, 1>},
         {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},     {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
+        {256, 256, 20, launch_pp<T, 256, 256, 2, 4, 5, false>}, {256, 128, 20, launch_pp<T, 256, 128, 2, 4, 5, false>},
 #ifdef MCGEN_TUNING
         {128, 256, 4, launch_dma1<T, 128, 256, 1, 4>}, {128, 256, 14, launch_dma1<T, 128, 256, 2, 4>},
         {256, 128, 15, launch_dma<T, 256, 128, 4, 1>}, {256, 128, 16, launch_dma<T, 256, 128, 2, 2>},
@@ -2135,10 +2256,6 @@ static const CfgEntry* bf16_table(int* n) {
 }
 
 static int dispatch(const mcgen_conv_t* p, int dtype, const TilePick& t, hipStream_t st) {
-    // the big tile's 3x3 launches go through the two-group pipeline (tuning builds: MCGEN_PP=0 switches it off)
-    static const long pp_mode = env_long("MCGEN_PP", 1);
-    if (dtype == MCGEN_BF16 && pp_mode && t.BM == 256 && t.BN == 256 && t.pipe == 5 && pp_fits<256, 256, 2, 4, 5>(p))
-        return launch_pp<256, 256, 2, 4, 5>(p, st);
     int n = 0;
     const CfgEntry* tab = dtype == MCGEN_BF16 ? bf16_table(&n) : f32_table(&n);
     for (int i = 0; i < n; ++i)

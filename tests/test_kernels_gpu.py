@@ -570,11 +570,27 @@ def test_big_dgrad_gate_bnstats(dtype, pool):
     np.testing.assert_allclose(s[1, :c], (dz * xhat).double().sum((0, 2, 3)), rtol=tol['rtol'], atol=tol['atol'] * 3)
 
 
+def test_big_conv_image_input_dma3_tile():
+    """D's first convolution (3 image channels padded to 8, conv3x3 -> 128 at 32x32, N = 256): too few input channels for
+    the pipelined form, so the dma3 form's 128 x 128 tile -- the instantiation every other 128-channel launch of the
+    bench has left."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(977)
+    n, h, c = 256, 32, 128
+    x = _rnd(g, n, 3, h, h)
+    wt, b = _rnd(g, c, 3, 3, 3) * 0.2, _rnd(g, c)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, padding=1) + b.view(1, -1, 1, 1)
+    (y, _), tiles = _conv_logged(ops, [ops.Seg(_nhwc(ops, x, dtype))], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda())
+    assert tiles == [(128, 128)], tiles
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'image-input conv')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('n,h,t16', [(128, 32, (128, 128)), (256, 32, (128, 128)), (256, 16, (128, 128)), (128, 16, (64, 128))])
+@pytest.mark.parametrize('n,h,t16', [(128, 32, (256, 128)), (256, 32, (256, 128)), (256, 16, (256, 128)), (128, 16, (64, 128))])
 def test_big_conv_pool_residual(n, h, t16, dtype):
     """D's 128-channel layers at the bench's batch (128 images, 256 for the paired real + fake pass):
-    ReLU -> MC -> conv3x3 -> AvgPool2 + residual."""
+    ReLU -> MC -> conv3x3 -> AvgPool2 + residual.  bf16 from 65536 pixels up: the software-pipelined 256 x 128 tile."""
     ops = _ops()
     if dtype == torch.float32 and n > 128:
         pytest.skip('fp32: same tile as the N=128 case')
