@@ -351,6 +351,11 @@ def bench_mcpixelcnn(a, dev, dtype, world, rank, group):
     finish(world)
 
 
+def _mask_compaction(dtype: str) -> bool:
+    from mcgen_amd import gan_engine as GE, trainer as T
+    return bool(GE._GK and T._GROUP_G and dtype == 'bf16')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -473,6 +478,10 @@ def main():
                        'graph_replay': graphed, 'workload_key': a.workload, 'batch_per_gpu': a.batch},
             'd_steps_per_s': 5 * a.steps * world / dt / world, 'g_steps_per_s': a.steps / dt,     # per replica
             'model_flops_per_image': FLOP_PER_IMAGE[a.workload],
+            # the forward-only 5 N generator pass skips the channels each sample's MultimodalController masks (compacted
+            # activations, gathered-K launches): the step's FLOP figures above stay the DENSE 2*MAC count; the per-kernel
+            # figures of roofline.by_kernel count what the launch actually multiplies
+            'mask_compaction': bool(_mask_compaction(a.dtype)),
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses, 'sustained_ms_per_step': sustained, 'sustain_steps': a.sustain_steps,
             'roofline': attach_traffic(roofline, a.workload, a.batch, a.dtype), 'cpu_baseline': cpu,

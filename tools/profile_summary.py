@@ -22,6 +22,11 @@ def bench_name(k: str):
     m = re.search(r'conv_\w+?_kernelI(DF16b|f)Li(\d+)ELi(\d+)E', k)
     if m:
         return f'conv_fused<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)},{m.group(3)}>'
+    m = re.search(r'conv_pp_kernel(?:ILi|<)(\d+)(?:ELi|, )(\d+)', k)    # software-pipelined form: bf16 only; <BM, BN, WM, WN, R, LGW, GK, ..>
+    if m:
+        gk = bool(re.search(r'conv_pp_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb1', k) or
+                  re.search(r'conv_pp_kernel<\d+, \d+, \d+, \d+, \d+, \d+, true', k))
+        return f'conv_fused<bf16,{m.group(1)},{m.group(2)}{",gk" if gk else ""}>'
     m = re.search(r'conv_(gk|mc)_kernelILi(\d+)ELi(\d+)E', k)          # K-major forms: bf16 only, no dtype parameter
     if m:
         return f'conv_fused<bf16,{m.group(2)},{m.group(3)},{m.group(1)}>'
