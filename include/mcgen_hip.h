@@ -285,6 +285,12 @@ int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_s
 int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
                       const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate,
                       float* workspace /* 32 * nlayers floats */, void* stream);
+/* The same for the two halves of a paired discriminator pass (each half with the u, v, sigma of its own forward,
+ * train_gan.py:144-150) in ONE dot launch and ONE apply launch: dst (+)= fix(g_src0; uv0, sigma0) + fix(g_src1; uv1, sigma1).
+ * workspace: 2 * 32 * nlayers floats; dst must not alias a source. */
+int mcgen_sn_grad_fix_pair(const float* g_src0, const float* g_src1, float* g_dst, const float* w_base,
+                           const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                           const float* sigma0, const float* sigma1, int accumulate, float* workspace, void* stream);
 
 /* Discriminator tail (mcgan.py:158-165): logit[n] = b + sum_c (w[c]/sigma) * sum_hw relu(x)*code */
 int mcgen_dtail_fwd(const void* x, int dtype, const float* code, const float* w, const float* b,

@@ -130,6 +130,7 @@ SYMBOLS = {
     'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     'mcgen_sn_power_iter_fused': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i, _i, _vp]),
     'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    'mcgen_sn_grad_fix_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_dtail_pair_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

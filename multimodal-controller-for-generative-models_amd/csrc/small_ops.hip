@@ -578,6 +578,57 @@ __global__ void sn_grad_apply_kernel(const float* __restrict__ gsrc, float* gdst
     }
 }
 
+// Two halves of a paired pass (DiscriminatorEngine.forward_pair: the same weights, each half with the u, v, sigma of its own
+// forward) in one launch each: blockIdx.z = half in the dot pass; the apply pass adds both halves' terms and writes once.
+__global__ void sn_grad_dot2_kernel(const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ wb,
+                                    const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ partial, int nlayers) {
+    __shared__ float red[32];
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    if (L.rows == 0) return;
+    const float* G = (blockIdx.z ? g1 : g0) + L.w_off; const float* W = wb + L.w_off;
+    const size_t n = (size_t)L.rows * L.cols;
+    const size_t per = (n + SNF_CHUNKS - 1) / SNF_CHUNKS;
+    const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+    float d = 0.f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) d = fmaf(G[i], W[i], d);
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) partial[((size_t)blockIdx.z * nlayers + blockIdx.x) * SNF_CHUNKS + blockIdx.y] = d;
+}
+__global__ void sn_grad_apply2_kernel(const float* __restrict__ g0, const float* __restrict__ g1, float* gdst,
+                                      const float* __restrict__ uv0, const float* __restrict__ uv1,
+                                      const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma0,
+                                      const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
+                                      int accumulate) {
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* A = g0 + L.w_off; const float* B = g1 + L.w_off; float* D = gdst + L.w_off;
+    if (L.rows == 0) {
+        const int per = (L.cols + SNF_CHUNKS - 1) / SNF_CHUNKS;
+        const int i0 = blockIdx.y * per, i1 = (i0 + per < L.cols) ? i0 + per : L.cols;
+        // (same order of additions as two single-half calls: dst (+)= first, then += second)
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) D[i] = (accumulate ? D[i] + A[i] : A[i]) + B[i];
+        return;
+    }
+    const float* ua = uv0 + L.u_off; const float* va = uv0 + L.v_off;
+    const float* ub = uv1 + L.u_off; const float* vb = uv1 + L.v_off;
+    const float sa = sigma0[blockIdx.x], sb = sigma1[blockIdx.x];
+    float da = 0.f, db = 0.f;
+    for (int k = 0; k < SNF_CHUNKS; ++k) {
+        da += partial[(size_t)blockIdx.x * SNF_CHUNKS + k];
+        db += partial[((size_t)nlayers + blockIdx.x) * SNF_CHUNKS + k];
+    }
+    da /= sa; db /= sb;
+    const float ia = 1.f / sa, ib = 1.f / sb;
+    const size_t n = (size_t)L.rows * L.cols;
+    const size_t per = (n + SNF_CHUNKS - 1) / SNF_CHUNKS;
+    const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const int r = (int)(i / L.cols), c = (int)(i - (size_t)r * L.cols);
+        const float oa = (A[i] - da * ua[r] * va[c]) * ia;
+        const float ob = (B[i] - db * ub[r] * vb[c]) * ib;
+        D[i] = (accumulate ? D[i] + oa : oa) + ob;
+    }
+}
+
 // ---- discriminator tail -------------------------------------------------------------------------------
 // one workgroup per sample; thread c handles channel c
 template <typename T>
@@ -947,6 +998,19 @@ extern "C" int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, co
                        do_iter, sigma, uv_snap, (long)uv_total, max_rows, max_cols);
     MCGEN_LAUNCH_CHECK("sn_power_iter_fused"); return 0;
 }
+extern "C" int mcgen_sn_grad_fix_pair(const float* g_src0, const float* g_src1, float* g_dst, const float* w_base,
+                                      const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                      const float* sigma0, const float* sigma1, int accumulate, float* workspace, void* stream) {
+    MCGEN_CHECK(g_src0 && g_src1 && g_dst && w_base && uv0 && uv1 && layers_dev && sigma0 && sigma1 && workspace && nlayers > 0,
+                "sn_grad_fix_pair: bad arguments (workspace must hold 2 * 32 * nlayers floats)");
+    MCGEN_CHECK(g_src0 != g_dst && g_src1 != g_dst, "sn_grad_fix_pair: the destination must not alias a source");
+    hipLaunchKernelGGL(sn_grad_dot2_kernel, dim3(nlayers, SNF_CHUNKS, 2), dim3(256), 0, STREAM(stream), g_src0, g_src1, w_base, layers_dev,
+                       workspace, nlayers);
+    hipLaunchKernelGGL(sn_grad_apply2_kernel, dim3(nlayers, SNF_CHUNKS), dim3(256), 0, STREAM(stream), g_src0, g_src1, g_dst, uv0, uv1,
+                       layers_dev, sigma0, sigma1, workspace, nlayers, accumulate);
+    MCGEN_LAUNCH_CHECK("sn_grad_fix_pair"); return 0;
+}
+
 extern "C" int mcgen_sn_grad_fix(const float* g_src, float* g_dst, const float* w_base, const float* uv_base,
                                  const mcgen_sn_layer_t* layers_dev, int nlayers, const float* sigma, int accumulate,
                                  float* workspace, void* stream) {

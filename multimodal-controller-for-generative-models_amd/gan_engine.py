@@ -776,9 +776,11 @@ class DiscriminatorEngine:
             table, nl = tab
             if nl == 0:
                 return
-            ops.sn_grad_fix(passes[0][1], gflat, fp, uv, table, nl, sigma[sg_off:], accumulate=accumulate)
             if pair is not None:
-                ops.sn_grad_fix(passes[1][1], gflat, fp, pair['uv2'], table, nl, pair['sigma2'][sg_off:], accumulate=True)
+                ops.sn_grad_fix_pair(passes[0][1], passes[1][1], gflat, fp, uv, pair['uv2'], table, nl, sigma[sg_off:],
+                                     pair['sigma2'][sg_off:], accumulate=accumulate)
+            else:
+                ops.sn_grad_fix(passes[0][1], gflat, fp, uv, table, nl, sigma[sg_off:], accumulate=accumulate)
 
         bk = self._bucket_tables() if want_w else None
         cut = self.bucket_cut()

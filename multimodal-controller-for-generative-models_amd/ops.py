@@ -639,6 +639,15 @@ def sn_grad_fix(g_src: Tensor, g_dst: Tensor, w_base: Tensor, uv_base: Tensor, l
                                         _f32(sigma), int(accumulate), _f32(ws), _stream()), 'sn_grad_fix')
 
 
+def sn_grad_fix_pair(g_src0: Tensor, g_src1: Tensor, g_dst: Tensor, w_base: Tensor, uv0: Tensor, uv1: Tensor,
+                     layers_dev: Tensor, nlayers: int, sigma0: Tensor, sigma1: Tensor, accumulate: bool = False):
+    """Both halves of a paired discriminator pass in one dot + one apply launch (mcgen_sn_grad_fix_pair)."""
+    ws = torch.empty(2 * 32 * nlayers, dtype=torch.float32, device=g_dst.device)
+    check(_lib.load().mcgen_sn_grad_fix_pair(_f32(g_src0), _f32(g_src1), _f32(g_dst), _f32(w_base), _f32(uv0), _f32(uv1),
+                                             _p(layers_dev), nlayers, _f32(sigma0), _f32(sigma1), int(accumulate), _f32(ws),
+                                             _stream()), 'sn_grad_fix_pair')
+
+
 def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),
          eps: float = 1e-8, weight_decay: float = 0.0):
     assert step.dtype == torch.int64

@@ -393,6 +393,20 @@ def test_spectral_norm_kernels():
         k = m.weight_orig.numel()
         np.testing.assert_allclose(G[off:off + k].cpu(), m.weight_orig.grad.reshape(-1), rtol=2e-4, atol=2e-5)
         off += k
+    # the paired form (both halves of a discriminator update in one dot + one apply launch) == two single-half calls (to an
+    # fp32 rounding step: the compiler contracts the sum differently)
+    Ga, Gb = torch.randn_like(G), torch.randn_like(G)
+    UV2, sigma2 = UV * 1.01, sigma * 0.97
+    d1, d2 = torch.randn_like(G), None
+    d2 = d1.clone()
+    ops.sn_grad_fix(Ga, d1, W, UV, ld, len(sn), sigma, accumulate=True)
+    ops.sn_grad_fix(Gb, d1, W, UV2, ld, len(sn), sigma2, accumulate=True)
+    ops.sn_grad_fix_pair(Ga, Gb, d2, W, UV, UV2, ld, len(sn), sigma, sigma2, accumulate=True)
+    np.testing.assert_allclose(d2.cpu(), d1.cpu(), rtol=2e-6, atol=2e-6)
+    ops.sn_grad_fix(Ga, d1, W, UV, ld, len(sn), sigma)
+    ops.sn_grad_fix(Gb, d1, W, UV2, ld, len(sn), sigma2, accumulate=True)
+    ops.sn_grad_fix_pair(Ga, Gb, d2, W, UV, UV2, ld, len(sn), sigma, sigma2)
+    np.testing.assert_allclose(d2.cpu(), d1.cpu(), rtol=2e-6, atol=2e-6)
     # the fused form: two rounds in one launch == two launches of the four-kernel form, snapshots included
     UVa, UVb = UV.clone(), UV.clone()
     sa1, sa2 = torch.zeros_like(sigma), torch.zeros_like(sigma)
