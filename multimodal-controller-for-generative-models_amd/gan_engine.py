@@ -315,6 +315,7 @@ class GeneratorEngine:
         # the channels the consumer's MultimodalController keeps (ycmap), the consumer gathers the matching weight rows.
         gk = groups > 1 and self._gk_enabled()
         x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
+        caps_h = [self._cap(b.mc_2) if (gk and self._gk_block(i)) else None for i, b in enumerate(res)]
         for i, b in enumerate(res):
             s = x.shape[1]
             code1, code2 = codes[2 * i], codes[2 * i + 1]
@@ -322,9 +323,10 @@ class GeneratorEngine:
             fold = 1
             co = b.conv[4].module.out_channels
             ci = b.conv[4].module.in_channels
-            cap_h = self._cap(b.mc_2) if (gk and self._gk_block(i)) else None            # h of this block, masked by mc_2
+            cap_h = caps_h[i]                                                            # h of this block, masked by mc_2
             nxt = res[i + 1] if i + 1 < len(res) else None
-            cap_y = self._cap(nxt.mc_1) if (gk and nxt is not None and self._gk_block(i) and self._gk_block(i + 1)) else None
+            # the block's output x stays compacted only if the NEXT block reads it compacted in both of its launches
+            cap_y = self._cap(nxt.mc_1) if (nxt is not None and cap_h is not None and caps_h[i + 1] is not None) else None
             cm_h = ops.mc_cmap(code2) if cap_h else None
             cm_y = ops.mc_cmap(codes[2 * (i + 1)]) if cap_y else None
             # ---- conv_a: BN -> ReLU -> Up -> MC1 -> conv3x3 (mcgan.py:15-19)

@@ -469,15 +469,22 @@ def test_mode_compacted_generator_matches_dense():
     np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
 
 
-def test_compacted_grouped_pass_matches_dense():
+@pytest.mark.parametrize('cfg_name', ['cifar10', 'coil100'])
+def test_compacted_grouped_pass_matches_dense(cfg_name):
     """MCGEN_GK: in the forward-only 5 N generator pass the activations h_1, x_2 and h_2 stay compacted between launches
     (producer stores only the channels the consumer's MultimodalController keeps, the consumer gathers the matching
     weight rows -- the masked channels contribute exact zeros in the dense path, modules.py:73).  Against the dense
     grouped pass on the same state / latents, bf16 at N = 5 x 128, full width: same images to a bf16 rounding step,
-    same BatchNorm running statistics, one train iteration inside the bf16 loss bound of the B = 128 digest."""
+    same BatchNorm running statistics, one train iteration inside the bf16 loss bound of the B = 128 digest.
+    COIL100 widths (G [512,256,128,64]: channel counts change from block to block and only some masks are worth
+    compacting): the chain must fall back block by block -- same checks against the dense pass."""
     from mcgen_amd import gan_engine as GE, trainer as T, ops
-    sd = gu.procedural_state(gu.mcgan_shapes([256] * 4, [128] * 4, 10), seed=1234, num_mode=10)
-    img, lab = gu.synthetic_batch(128, 10, seed=1)
+    if cfg_name == 'cifar10':
+        gh, dh, modes, data, kw = [256] * 4, [128] * 4, 10, 'CIFAR10', {}
+    else:
+        gh, dh, modes, data, kw = [512, 256, 128, 64], [64, 128, 256, 512], 100, 'COIL100', {'cifar_layout': False}
+    sd = gu.procedural_state(gu.mcgan_shapes(gh, dh, modes, **kw), seed=1234, num_mode=modes)
+    img, lab = gu.synthetic_batch(128, modes, seed=1)
     img, lab = img.cuda(), lab.cuda()
     zs = [z.cuda() for z in gu.latent_batches(6, 128, 128, seed=2)]
 
@@ -485,27 +492,30 @@ def test_compacted_grouped_pass_matches_dense():
         old = GE._GK
         GE._GK = gk
         try:
-            m = _build([256] * 4, [128] * 4, 10, 'CIFAR10', sd, torch.bfloat16)
+            m = _build(gh, dh, modes, data, sd, torch.bfloat16)
             m.train(True)
-            tr = T.GANTrainer(m, 10)
+            tr = T.GANTrainer(m, modes)
             assert tr.fake_groups(128) == 5
             ops.FORM_LOG = []
-            ind = torch.nn.functional.one_hot(lab, 10).float()
+            ind = torch.nn.functional.one_hot(lab, modes).float()
             fakes = tr.g_fakes(ind.repeat(5, 1), torch.cat(zs[:5]), 5)
             tiles = list(ops.FORM_LOG); ops.FORM_LOG = None
             bn = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()
                   if 'generator' in k and 'running' in k}
             m.load_state_dict(sd)
-            losses = T.GANTrainer(m, 10).train_iteration(img, lab, zs)
+            losses = T.GANTrainer(m, modes).train_iteration(img, lab, zs)
             return fakes.float().cpu(), bn, (float(losses[0]), float(losses[1])), tiles
         finally:
             GE._GK = old
     f_d, bn_d, l_d, t_d = run(False)
     f_c, bn_c, l_c, t_c = run(True)
-    assert t_c.count(2) == 3 and t_d.count(2) == 0, (t_c, t_d)      # conv_b1 ++ sc, conv_a2, conv_b2 ++ sc read compacted input
+    assert t_d.count(2) == 0 and t_c.count(2) >= 1, (t_c, t_d)
+    if cfg_name == 'cifar10':
+        assert t_c.count(2) == 3, t_c                # conv_b1 ++ sc, conv_a2, conv_b2 ++ sc read compacted input
     assert float((f_c - f_d).abs().max()) < 3e-2 and float((f_c - f_d).abs().mean()) < 1e-3
     for k, v in bn_d.items():
         assert float((bn_c[k] - v).abs().max()) <= 2e-3 * (1 + float(v.abs().max())), k
     np.testing.assert_allclose(l_c, l_d, rtol=0, atol=2e-2)
-    d = gu.load_npz('mcgan_full_digest_b128.npz')
-    np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
+    if cfg_name == 'cifar10':
+        d = gu.load_npz('mcgan_full_digest_b128.npz')
+        np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
