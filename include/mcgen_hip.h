@@ -219,6 +219,10 @@ int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream);
 /* layout / dtype conversion at the module boundary (the reference works on NCHW fp32) */
 int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+/* y[N, Ho, Wo, C] = 2x2 sums of x[N, 2 Ho, 2 Wo, C] (NHWC, C a multiple of 8): the adjoint of the nearest x2 upsample.
+ * The generator's shortcut conv1x1(Up(x)) (mcgan.py:26-30,42) commutes with the upsample, so its weight gradient and
+ * input gradient are taken at x's resolution from the pooled output gradient -- a quarter of the FLOPs. */
+int mcgen_pool2_sum(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream);
 
 /* code[N, C] = indicator[N, M] @ codebook[M, C]      MultimodalController.forward, modules.py:73 */
 int mcgen_mc_code(const float* indicator, const float* codebook, float* code, int N, int M, int C, void* stream);

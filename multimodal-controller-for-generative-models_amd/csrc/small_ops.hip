@@ -41,6 +41,26 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
     }
 }
 
+// 2x2 sum pooling of an NHWC tensor (the adjoint of the nearest x2 upsample): thread = 8 channels of one output pixel
+template <typename T>
+__global__ void pool2_sum_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int Ho, int Wo, int C) {
+    const int cg = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * cg;
+    const int W = 2 * Wo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg); size_t t = i / cg;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho); const int n = (int)(t / Ho);
+        const T* p = x + (((size_t)n * 2 * Ho + 2 * ho) * W + 2 * wo) * C + g * 8;
+        float a[8], b[8], c[8], d[8], o[8];
+        Elem<T>::load8(p, a); Elem<T>::load8(p + C, b);
+        Elem<T>::load8(p + (size_t)W * C, c); Elem<T>::load8(p + (size_t)W * C + C, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (a[k] + b[k]) + (c[k] + d[k]);
+        Elem<T>::store8(y + (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8, o);
+    }
+}
+
 // ---- weight image ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ img, int Cout, int Cin, int KS,
@@ -795,6 +815,15 @@ extern "C" int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N,
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)src, dst, N, C, H * W, Cp),
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)src, dst, N, C, H * W, Cp));
     MCGEN_LAUNCH_CHECK("nhwc_to_nchw"); return 0;
+}
+
+extern "C" int mcgen_pool2_sum(const void* x, void* y, int dtype, int N, int Ho, int Wo, int C, void* stream) {
+    MCGEN_CHECK(x && y && N > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "pool2_sum: bad arguments (C a multiple of 8)");
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(pool2_sum_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, (float*)y, N, Ho, Wo, C),
+        hipLaunchKernelGGL(pool2_sum_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, (bf16_t*)y, N, Ho, Wo, C));
+    MCGEN_LAUNCH_CHECK("pool2_sum"); return 0;
 }
 
 extern "C" int64_t mcgen_weight_image_elems(int Cout, int Cin, int ksize, int transpose) {

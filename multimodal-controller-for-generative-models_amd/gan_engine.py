@@ -96,6 +96,7 @@ _MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
 # compacted activations between the launches of the FORWARD-ONLY grouped generator pass (producer-side compacted store +
 # gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
 _GK = __import__('os').environ.get('MCGEN_GK', '1') != '0'
+_LOWRES_SC_BWD = __import__('os').environ.get('MCGEN_LOWRES_SC_BWD', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -426,7 +427,14 @@ class GeneratorEngine:
                 seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True)
                 seg_s = Seg(x, ksize=1, code=code1, ups=True)
                 ops.wgrad(seg_b, dy, co, co, G(conv2.weight), accumulate=acc, bias_grad=G(conv2.bias), bias_grad2=G(convs.bias))
-                ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
+                # the shortcut conv1x1(Up(x)) commutes with the upsample: in bf16 its weight gradient and input gradient are
+                # taken at x's resolution from the 2x2-pooled dy (a quarter of the FLOPs; fp32 keeps the literal form)
+                lowres = _LOWRES_SC_BWD and dt == torch.bfloat16 and dy.shape[1] >= 16
+                dy_lo = ops.pool2_sum(dy) if lowres else None
+                if lowres:
+                    ops.wgrad(Seg(x, ksize=1, code=code1), dy_lo, co, ci, G(convs.weight), accumulate=acc)
+                else:
+                    ops.wgrad(seg_s, dy, co, ci, G(convs.weight), accumulate=acc)
                 w2t = self.img_t[f'b{i}.w2']
                 dz2, part2 = ops.conv_fused([Seg(dy)], w2t, co, ocode=code2, gate_x=h, gscale=bn2.scale, gshift=bn2.shift,
                                             gmean=bn2.mean, grstd=bn2.rstd, stats_mode=2)
@@ -436,7 +444,10 @@ class GeneratorEngine:
                 seg_a = Seg(x, scale=bn1.scale, shift=bn1.shift, code=code1, ups=True, relu=True)
                 ops.wgrad(seg_a, dh, co, ci, G(conv1.weight), accumulate=acc, bias_grad=G(conv1.bias))
                 wst = self.img_t[f'b{i}.ws']
-                dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
+                if lowres:
+                    dx_sc, _ = ops.conv_fused([Seg(dy_lo, ksize=1)], wst, ci, ocode=code1)
+                else:
+                    dx_sc, _ = ops.conv_fused([Seg(dy, ksize=1)], wst, ci, pool=True, alpha=1.0, ocode=code1)
                 w1t = self.img_t[f'b{i}.w1']
                 dz1, part1 = ops.conv_fused([Seg(dh)], w1t, ci, pool=True, alpha=1.0, ocode=code1, gate_x=x,
                                             gscale=bn1.scale, gshift=bn1.shift, gmean=bn1.mean, grstd=bn1.rstd, stats_mode=2)

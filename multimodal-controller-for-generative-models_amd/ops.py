@@ -184,6 +184,14 @@ def to_nchw(x: Tensor, c: int) -> Tensor:
     return y
 
 
+def pool2_sum(x: Tensor) -> Tensor:
+    """2x2 sums of an NHWC tensor (adjoint of the nearest x2 upsample)."""
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    check(_lib.load().mcgen_pool2_sum(_p(x), _p(y), _dt(x.dtype), n, h // 2, w // 2, c, _stream()), 'pool2_sum')
+    return y
+
+
 def mc_code(indicator: Tensor, codebook: Tensor, cp: Optional[int] = None) -> Tensor:
     """code = indicator @ codebook  (modules.py:73), zero-padded to `cp` columns."""
     n, m = indicator.shape

@@ -584,6 +584,41 @@ def test_big_dgrad_gate_bnstats(dtype, pool):
     np.testing.assert_allclose(s[1, :c], (dz * xhat).double().sum((0, 2, 3)), rtol=tol['rtol'], atol=tol['atol'] * 3)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pool2_sum_and_shortcut_gradients_at_low_resolution(dtype):
+    """mcgen_pool2_sum (adjoint of the nearest x2 upsample) and what the generator's backward uses it for: the weight
+    gradient and the input gradient of the shortcut conv1x1(Up(x)) (mcgan.py:26-30,42) taken at x's resolution from
+    the pooled dy equal the literal full-resolution forms."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(611)
+    n, h, c = (32, 32, 256) if dtype == torch.bfloat16 else (4, 16, 32)
+    dy, xlo = _rnd(g, n, c, h, h), _rnd(g, n, c, h // 2, h // 2)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    ws = _rnd(g, c, c, 1, 1) * 0.05
+    dyt, xt = _nhwc(ops, dy, dtype), _nhwc(ops, xlo, dtype)
+    lo = ops.pool2_sum(dyt)
+    ref_lo = F.avg_pool2d(_q(dy, dtype), 2) * 4
+    _assert_close(ops.to_nchw(lo, c), _q(ref_lo, dtype) if dtype == torch.bfloat16 else ref_lo, dtype, 'pool2_sum')
+    # weight gradient: sum_px dy (x) Up(x * code)  ==  sum_q pool(dy) (x) (x * code)
+    g_full, g_low = torch.zeros(c, c, 1, 1, device='cuda'), torch.zeros(c, c, 1, 1, device='cuda')
+    ops.wgrad(ops.Seg(xt, ksize=1, code=code.cuda(), ups=True), dyt, c, c, g_full)
+    ops.wgrad(ops.Seg(xt, ksize=1, code=code.cuda()), lo, c, c, g_low)
+    a = (_q(xlo, dtype) * code.view(n, c, 1, 1))
+    a = _q(a, dtype) if dtype == torch.bfloat16 else a
+    ref_w = torch.einsum('nohw,nihw->oi', _q(ref_lo, dtype) if dtype == torch.bfloat16 else ref_lo, a)
+    tol = dict(rtol=3e-2, atol=0.5) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(g_low.view(c, c).cpu(), ref_w, **tol)
+    # (bf16: the pooled dy is rounded once more -- an error of ~ sqrt(pixels) * 2^-9 * |dy| |x| on sums of magnitude ~200)
+    np.testing.assert_allclose(g_low.cpu(), g_full.cpu(), rtol=tol['rtol'], atol=4 * tol['atol'])
+    # input gradient: pool(conv1x1^T(dy)) * code  ==  conv1x1^T(pool(dy)) * code
+    wt = ops.prep_weight(ws.cuda(), dtype, transpose=True)
+    d_full, _ = ops.conv_fused([ops.Seg(dyt, ksize=1)], wt, c, pool=True, alpha=1.0, ocode=code.cuda())
+    d_low, _ = ops.conv_fused([ops.Seg(lo, ksize=1)], wt, c, ocode=code.cuda())
+    ref_d = F.conv2d(_q(ref_lo, dtype) if dtype == torch.bfloat16 else ref_lo, _q(ws, dtype).permute(1, 0, 2, 3)) * code.view(n, c, 1, 1)
+    _assert_close(ops.to_nchw(d_low, c), ref_d, dtype, 'shortcut dgrad from pooled dy')
+    _assert_close(ops.to_nchw(d_full, c), ref_d, dtype, 'shortcut dgrad, literal form')
+
+
 def test_big_conv_image_input_dma3_tile():
     """D's first convolution (3 image channels padded to 8, conv3x3 -> 128 at 32x32, N = 256): too few input channels for
     the pipelined form, so the dma3 form's 128 x 128 tile -- the instantiation every other 128-channel launch of the
