@@ -1631,17 +1631,8 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     };
 
     if (nchunk > 0) {       // (GK: an image without active channels contributes nothing from this segment)
-    // ---- per-channel prologue table: v -> max(v * sc + sh, relu ? 0 : -inf) with the code folded into sc, sh.  Under a ReLU
-    // that needs code >= 0 (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator,
-    // modules.py:73): a negative code poisons its channel with NaN instead of going wrong silently.
-    {
-        for (int c = tid; c < C0; c += NT) {
-            const float sc = sg0.scale ? sg0.scale[c] : 1.f, sh = sg0.scale ? sg0.shift[c] : 0.f;
-            float cd = sg0.code ? sg0.code[(size_t)n_img * C0 + c] : 1.f;
-            if (sg0.relu && cd < 0.f) cd = __builtin_nanf("");
-            aff[c] = sc * cd; aff[C0 + c] = sh * cd;
-        }
-    }
+    // (prologue order: weight DMAs, then the table's global loads, then the window loads of chunk 0 -- ONE exposed round trip
+    // for all three; the table is written to LDS and the window transformed once everything has landed)
     // taps 0 .. R - 1 -> slots 0 .. R - 1, except the last piece of tap R - 1 (PPW == 2), which phase (0, 0) issues
     if constexpr (GK) {
 #pragma unroll
@@ -1655,6 +1646,16 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                 if constexpr (GK) dma_piece_gk(wimg, tapstride0, krow_c[k], t, t, k);      // (R <= 9: all in chunk 0)
                 else dma_piece(t < T0 ? t : T0 - 1, t, k);
             }
+
+    // ---- per-channel prologue table: v -> max(v * sc + sh, relu ? 0 : -inf) with the code folded into sc, sh.  Under a ReLU
+    // that needs code >= 0 (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator,
+    // modules.py:73): a negative code poisons its channel with NaN instead of going wrong silently.  One channel per
+    // thread (host: C0 <= threads); the values wait in registers until the window loads are issued.
+    float t_sc = 1.f, t_sh = 0.f, t_cd = 1.f;
+    if (tid < C0) {
+        if (sg0.scale) { t_sc = sg0.scale[tid]; t_sh = sg0.shift[tid]; }
+        if (sg0.code) t_cd = sg0.code[(size_t)n_img * C0 + tid];
+    }
 
     // ---- window items of this thread: item j = window unit tid + j * NT (unit = 8 channels of one window pixel) ----------
     const T* xs0 = reinterpret_cast<const T*>(sg0.x);
@@ -1708,12 +1709,16 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     const int a_lane = (((wm * (BM / WM)) >> LGW) * PC + l15) * APITCH + lg * 16;
     auto a_off = [](int fm) constexpr { return (((fm * 16) >> LGW) * PC + ((fm * 16) & (W - 1))) * APITCH; };
 
-    // window of chunk 0 (needs the table)
-    __syncthreads();
+    // window of chunk 0: loads first, then the table (its values and the window arrive together), then the prologue
     {
         u32x4 raw0[NIW];
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wload(j, 0, raw0[j]);
+        if (tid < C0) {
+            if (sg0.relu && t_cd < 0.f) t_cd = __builtin_nanf("");
+            aff[tid] = t_sc * t_cd; aff[C0 + tid] = t_sh * t_cd;
+        }
+        __syncthreads();
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wwrite(j, raw0[j], ldsA0, 0);
@@ -2175,7 +2180,7 @@ template <int BM, int BN, int WM, int WN, int R, bool GK>
 static bool pp_fits_(const mcgen_conv_t* p) {
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
     if (p->w_layout != (GK ? 2 : 0) || p->H * p->W < BM || (p->W != 16 && p->W != 32)) return false;
-    if (p->seg[0].ksize != 3 || p->seg[0].C % MCGEN_CK != 0 || p->seg[0].C < 2 * MCGEN_CK) return false;
+    if (p->seg[0].ksize != 3 || p->seg[0].C % MCGEN_CK != 0 || p->seg[0].C < 2 * MCGEN_CK || p->seg[0].C > C::NT) return false;
     if ((p->seg[0].cmap != nullptr) != GK) return false;               // gathered K: the first segment's rows come from its map
     for (int s = 1; s < p->nseg; ++s) if (p->seg[s].ksize != 1 || (!GK && p->seg[s].cmap)) return false;
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
