@@ -627,36 +627,42 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
                                                  (__attribute__((address_space(3))) void*)(ldsC0 + ((i % WG_NR) * 4 + wave) * 128), 16, 0, 0);
             }
         };
-        auto prologue = [&](int i) {                                   // R[i % 3] -> A[i & 1]
+        // R[i % 3] -> A[i & 1]: v -> max(v * sc' + sh', relu ? 0 : -inf) with the tile's code row folded into the affine
+        // (sc' = sc * code, sh' = sh * code; the tile lies inside one image).  Under a ReLU the fold needs code >= 0
+        // (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator, modules.py:73): a negative
+        // code poisons its channel with NaN instead of going wrong silently.  Out-of-image rows are zeroed on the packed words.
+        const float relu_lo = sg.relu ? 0.f : -__builtin_inff();
+        auto prologue = [&](int i) {
             const int pix0 = tile_of(i) * WG_BM;
             const int h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
-            float cd[8];
+            float scc[8], shc[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cd[e] = 1.f;
-            if (sg.code) load8f(reinterpret_cast<const float*>(ldsC0 + ((i % WG_NR) * 4 + wave) * 128) + sub, cd);
+            for (int e = 0; e < 8; ++e) { scc[e] = sc[e]; shc[e] = sh[e]; }
+            if (sg.code) {
+                float cd[8];
+                load8f(reinterpret_cast<const float*>(ldsC0 + ((i % WG_NR) * 4 + wave) * 128) + sub, cd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float c = (sg.relu && cd[e] < 0.f) ? __builtin_nanf("") : cd[e];
+                    scc[e] *= c; shc[e] *= c;
+                }
+            }
             const char* rs = ldsR0 + (i % WG_NR) * RSLOT + rtid * 16;
             char* ldsA = ldsA0 + (i & 1) * a_bytes;
 #pragma unroll
             for (int k = 0; k < NIX; ++k) {
                 if (x_lds[k] < 0) continue;
-                float v[8];
-                E::load8(reinterpret_cast<const T*>(rs + k * (WG_NT * 16)), v);
-                if (sg.scale) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(rs + k * (WG_NT * 16));
+                union { bf16x8 h; u32x4 w; } o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-                }
-                if (sg.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (sg.code) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= cd[e];
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = fmaxf(fmaf(__uint_as_float(r[e] << 16), scc[2 * e], shc[2 * e]), relu_lo);
+                    const float v1 = fmaxf(fmaf(__uint_as_float(r[e] & 0xffff0000u), scc[2 * e + 1], shc[2 * e + 1]), relu_lo);
+                    o.h[2 * e] = (bf16_t)v0; o.h[2 * e + 1] = (bf16_t)v1;
                 }
                 const bool ok = (unsigned)(h0 + x_dh[k]) < (unsigned)H;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
-                E::store8(reinterpret_cast<T*>(ldsA + x_lds[k]), v);
+                if (!ok) o.w = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(ldsA + x_lds[k]) = o.w;
             }
         };
         auto landed = [&]() {                                          // all but the two youngest tiles' DMAs are done
