@@ -44,10 +44,11 @@ typedef struct {
     const void*  x;       /* [N, H>>ups, W>>ups, C]                                   */
     const float* scale;   /* [C] ([N/group_n][C] when group_n > 0) or NULL            */
     const float* shift;   /* same shape as scale (read only when scale != NULL)       */
-    const float* code;    /* [N, C] = indicator @ codebook, or NULL.  With relu = 1 the code must be >= 0 (it is a product
-                           * of a 0/1 codebook and a non-negative indicator, modules.py:58-76): the pipelined bf16 forms
-                           * (conv "pp", ring weight gradient) fold it into the BatchNorm affine in front of the ReLU and
-                           * turn a negative entry into NaN for its channel rather than computing something else     */
+    const float* code;    /* [N, C] = indicator @ codebook, or NULL.  MultimodalController codes are >= 0 (a 0/1 codebook
+                           * times a non-negative indicator, modules.py:58-76).  With relu = 1 the software-pipelined bf16
+                           * convolution folds the code into the affine in front of the ReLU: a tile whose code row has a
+                           * NEGATIVE entry returns NaN (fails loudly) instead of code * relu(.); every other form and
+                           * the weight-gradient kernels compute code * relu(.) for any sign                           */
     const int16_t* cmap;  /* per-sample compaction map built by mcgen_mc_cmap from `code` (see there), or NULL:
                            * the K loop then visits only the channels whose code is non-zero -- with
                            * controller_rate 0.5 half of them (modules.py:58-76); bf16 launches on K-major

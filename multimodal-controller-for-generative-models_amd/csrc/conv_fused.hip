@@ -1630,6 +1630,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         }
     };
 
+    bool neg_tile = false;  // (workgroup-uniform) the tile's code row has a negative entry in front of a ReLU: outputs become NaN
     if (nchunk > 0) {       // (GK: an image without active channels contributes nothing from this segment)
     // (prologue order: weight DMAs, then the table's global loads, then the window loads of chunk 0 -- ONE exposed round trip
     // for all three; the table is written to LDS and the window transformed once everything has landed)
@@ -1647,10 +1648,12 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                 else dma_piece(t < T0 ? t : T0 - 1, t, k);
             }
 
-    // ---- per-channel prologue table: v -> max(v * sc + sh, relu ? 0 : -inf) with the code folded into sc, sh.  Under a ReLU
-    // that needs code >= 0 (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator,
-    // modules.py:73): a negative code poisons its channel with NaN instead of going wrong silently.  One channel per
-    // thread (host: C0 <= threads); the values wait in registers until the window loads are issued.
+    // ---- per-channel prologue table: v -> max(v * sc' + sh', relu ? 0 : -inf) with the code folded into the affine in front of
+    // the ReLU: sc' = scale * code, sh' = shift * code.  That is code * relu(.) only for code >= 0 -- always the case for
+    // MultimodalController codes (a 0/1 codebook times a non-negative indicator, modules.py:58-76).  The C ABI takes any
+    // float, so a tile whose code row holds a negative entry in front of a ReLU is made to FAIL LOUDLY: its outputs are NaN
+    // (neg_tile, applied through the epilogue's alpha) -- a branch for the general form inside the main loop costs every
+    // launch 30 spilled registers, a sign multiply per element 1.5 % of the step.  One channel per thread
     float t_sc = 1.f, t_sh = 0.f, t_cd = 1.f;
     if (tid < C0) {
         if (sg0.scale) { t_sc = sg0.scale[tid]; t_sh = sg0.shift[tid]; }
@@ -1686,7 +1689,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     };
     // (straight-line on purpose: with branches around the stores hipcc spills ~50 registers into the main loop)
     const float relu_lo = sg0.relu ? 0.f : -__builtin_inff();
-    const uint32_t lds_dump = (uint32_t)reinterpret_cast<uintptr_t>(reinterpret_cast<char*>(aff) + C0 * 8 + (C0 >> 1)) + tid * 16;
+    const uint32_t lds_dump = (uint32_t)reinterpret_cast<uintptr_t>(reinterpret_cast<char*>(aff) + C0 * 8) + tid * 16;
     auto wwrite = [&](int j, const u32x4& r, char* abuf, int c0) {
         union { bf16x8 h; u32x4 w; } o;
 #pragma unroll
@@ -1714,11 +1717,8 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         u32x4 raw0[NIW];
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wload(j, 0, raw0[j]);
-        if (tid < C0) {
-            if (sg0.relu && t_cd < 0.f) t_cd = __builtin_nanf("");
-            aff[tid] = t_sc * t_cd; aff[C0 + tid] = t_sh * t_cd;
-        }
-        __syncthreads();
+        if (tid < C0) { aff[tid] = t_sc * t_cd; aff[C0 + tid] = t_sh * t_cd; }
+        neg_tile = __syncthreads_or((tid < C0 && sg0.relu && t_cd < 0.f) ? 1 : 0) != 0;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wwrite(j, raw0[j], ldsA0, 0);
@@ -1872,7 +1872,13 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 #pragma unroll
             for (int j = 0; j < FM; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else {
-        conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+        if (neg_tile) {
+            mcgen_conv_t pn = p;
+            pn.alpha = __builtin_nanf("");
+            conv_epilogue<T, C, BM, BN, WM, WN>(pn, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+        } else {
+            conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0);
+        }
     }
 }
 
@@ -2186,7 +2192,7 @@ static bool pp_fits_(const mcgen_conv_t* p) {
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
     if (PP * 4 > PP_NIW * C::NT) return false;
     const int a_bytes = round_up(PP * C::APITCH, 1024);
-    const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + p->seg[0].C / 2 + C::NT * 16;
+    const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + C::NT * 16;
     return lds <= 160 * 1024;
 }
 template <int BM, int BN, int WM, int WN, int R>
@@ -2200,7 +2206,7 @@ static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
     const int nt = (p->Cout_w + BN - 1) / BN;
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
     const int a_bytes = round_up(PP * C::APITCH, 1024);
-    int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + p->seg[0].C / 2 + C::NT * 16;
+    int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + C::NT * 16;
     const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;

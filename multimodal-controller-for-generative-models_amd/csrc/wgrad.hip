@@ -628,27 +628,40 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
             }
         };
         // R[i % 3] -> A[i & 1]: v -> max(v * sc' + sh', relu ? 0 : -inf) with the tile's code row folded into the affine
-        // (sc' = sc * code, sh' = sh * code; the tile lies inside one image).  Under a ReLU the fold needs code >= 0
-        // (MultimodalController codes are products of a 0/1 codebook and a non-negative indicator, modules.py:73): a negative
-        // code poisons its channel with NaN instead of going wrong silently.  Out-of-image rows are zeroed on the packed words.
+        // (sc' = sc * code, sh' = sh * code; the tile lies inside one image) -- the SIMD's vector issue port is this kernel's
+        // limit, and the fold takes the per-element code multiply out of the item loop.  In front of a ReLU the fold needs
+        // code >= 0 (always true for MultimodalController codes, modules.py:73); a wave that sees a negative entry takes the
+        // literal form for that tile.  Out-of-image rows are zeroed on the packed words.
         const float relu_lo = sg.relu ? 0.f : -__builtin_inff();
         auto prologue = [&](int i) {
             const int pix0 = tile_of(i) * WG_BM;
             const int h0 = (pix0 & ((1 << lgHW) - 1)) >> LGW;
-            float scc[8], shc[8];
+            float scc[8], shc[8], cd[8];
+            bool neg = false;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { scc[e] = sc[e]; shc[e] = sh[e]; }
+            for (int e = 0; e < 8; ++e) { scc[e] = sc[e]; shc[e] = sh[e]; cd[e] = 1.f; }
             if (sg.code) {
-                float cd[8];
                 load8f(reinterpret_cast<const float*>(ldsC0 + ((i % WG_NR) * 4 + wave) * 128) + sub, cd);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float c = (sg.relu && cd[e] < 0.f) ? __builtin_nanf("") : cd[e];
-                    scc[e] *= c; shc[e] *= c;
-                }
+                for (int e = 0; e < 8; ++e) neg = neg || (cd[e] < 0.f);
             }
             const char* rs = ldsR0 + (i % WG_NR) * RSLOT + rtid * 16;
             char* ldsA = ldsA0 + (i & 1) * a_bytes;
+            if (__builtin_expect(sg.relu && __any(neg), 0)) {          // wave-uniform; never taken for MultimodalController codes
+#pragma unroll 1
+                for (int k = 0; k < NIX; ++k) {
+                    if (x_lds[k] < 0) continue;
+                    float v[8];
+                    E::load8(reinterpret_cast<const T*>(rs + k * (WG_NT * 16)), v);
+                    const bool ok = (unsigned)(h0 + x_dh[k]) < (unsigned)H;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ok ? fmaxf(fmaf(v[e], sc[e], sh[e]), relu_lo) * cd[e] : 0.f;
+                    E::store8(reinterpret_cast<T*>(ldsA + x_lds[k]), v);
+                }
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { scc[e] *= cd[e]; shc[e] *= cd[e]; }
 #pragma unroll
             for (int k = 0; k < NIX; ++k) {
                 if (x_lds[k] < 0) continue;

@@ -619,6 +619,40 @@ def test_pool2_sum_and_shortcut_gradients_at_low_resolution(dtype):
     _assert_close(ops.to_nchw(d_full, c), ref_d, dtype, 'shortcut dgrad, literal form')
 
 
+def test_pipelined_forms_with_a_negative_code_under_relu():
+    """The software-pipelined bf16 convolution and the ring weight-gradient kernel fold the MultimodalController code into
+    the affine in front of the ReLU, which equals code * relu(.) only for code >= 0.  MC codes are never negative
+    (modules.py:58-76), but the C ABI takes any float: the convolution must FAIL LOUDLY (NaN for the tiles of the image that
+    carries the entry, every other image exact), the weight gradient takes its literal form for such a tile and stays exact."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(29)
+    n, h, c = 64, 32, 256
+    x = _rnd(g, n, c, h, h)
+    wt, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    code[3, 17], code[5, 200] = -1.0, -0.5
+    xt = _nhwc(ops, x, dtype)
+    (y, _), tiles = _conv_logged(ops, [ops.Seg(xt, code=code.cuda(), relu=True)], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda())
+    assert tiles == [(256, 256)], tiles
+    out = ops.to_nchw(y, c).cpu()
+    a = _q(ref_prologue(_q(x, dtype), None, None, True, code, False), dtype)
+    ref = F.conv2d(a, _q(wt, dtype), None, padding=1) + b.view(1, -1, 1, 1)
+    keep = [i for i in range(n) if i not in (3, 5)]
+    assert torch.isnan(out[3]).all() and torch.isnan(out[5]).all() and torch.isfinite(out[keep]).all()
+    _assert_close(out[keep], ref[keep], dtype, 'pp form, images without a negative code')
+    # without the ReLU the fold is exact for any sign
+    y2, _ = ops.conv_fused([ops.Seg(xt, code=code.cuda())], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda())
+    a2 = _q(_q(x, dtype) * code.view(n, c, 1, 1), dtype)
+    _assert_close(ops.to_nchw(y2, c), F.conv2d(a2, _q(wt, dtype), None, padding=1) + b.view(1, -1, 1, 1), dtype, 'pp form, no ReLU')
+    # ring weight gradient on the same operands: exact
+    dy = _rnd(g, n, c, h, h)
+    gw = torch.zeros(c, c, 3, 3, device='cuda')
+    ops.wgrad(ops.Seg(xt, code=code.cuda(), relu=True), _nhwc(ops, dy, dtype), c, c, gw)
+    ref_w = torch.nn.grad.conv2d_weight(a, (c, c, 3, 3), _q(dy, dtype), padding=1)
+    np.testing.assert_allclose(gw.cpu(), ref_w, rtol=3e-2, atol=0.6)
+
+
 def test_big_conv_image_input_dma3_tile():
     """D's first convolution (3 image channels padded to 8, conv3x3 -> 128 at 32x32, N = 256): too few input channels for
     the pipelined form, so the dma3 form's 128 x 128 tile -- the instantiation every other 128-channel launch of the
