@@ -264,11 +264,22 @@ class GeneratorEngine:
         key = (cb.data_ptr(), tuple(cb.shape), cb._version)
         cache = self.__dict__.setdefault('_cap_cache', {})
         if cache.get(id(mc), (None,))[0] != key:
+            if cb.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise McgenError('compacted generator pass: a codebook changed since the last eager pass; call '
+                                 'GeneratorEngine.warm_caps() before capturing (the compacted pitch is read on the host)')
             cnt = int((cb != 0).sum(1).max())
             cap = (cnt + 31) // 32 * 32
             ok = cap <= cb.shape[1] * 3 // 4 and float(cb.min()) >= 0.0
             cache[id(mc)] = (key, cap if ok else None)
         return cache[id(mc)][1]
+
+    def warm_caps(self):
+        """Read the compacted pitches of the current codebooks (a host synchronisation): graph capture calls this after it
+        has restored the model state, so that the captured pass finds them cached."""
+        if self._gk_enabled():
+            lin, res, head_bn, head_mc, head_conv = self._layers()
+            for b in res:
+                self._cap(b.mc_1); self._cap(b.mc_2)
 
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:

@@ -273,6 +273,7 @@ class GraphedGANTrainer(GANTrainer):
         self.geng.flat_p.ensure()
         self.deng._ensure_flat()
         self.geng.refresh_images(force=True)
+        self.geng.warm_caps()                       # (load_state_dict bumped the codebooks' versions)
 
     def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 1):
         n = img.shape[0]

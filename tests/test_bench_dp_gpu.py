@@ -27,3 +27,18 @@ def test_bench_two_ranks_one_card(workload):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
     assert out['config']['global_batch'] == 32 and out['value'] > 0
+
+
+@pytest.mark.parametrize('workload', ['cifar10', 'coil100'])
+def test_bench_default_path_replays_graphs(workload):
+    """The single-GPU bench command at its real batch: the HIP-graph capture must succeed (an eager fall-back would still
+    print a line -- `config.graph_replay` says which path was timed) and the line carries the contract's keys."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline', '--sustain-steps', '0']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert out['config']['graph_replay'] is True, r.stderr[-3000:]
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['mask_compaction'] is True
+    rf = out['roofline']
+    assert rf['unit'] in ('TFLOP/s', 'GB/s') and 0 < rf['frac'] < 1 and rf['bound'] in ('mfma', 'hbm')

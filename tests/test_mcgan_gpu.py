@@ -519,3 +519,28 @@ def test_compacted_grouped_pass_matches_dense(cfg_name):
     if cfg_name == 'cifar10':
         d = gu.load_npz('mcgan_full_digest_b128.npz')
         np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
+
+
+def test_graphed_trainer_full_width_bf16_matches_eager():
+    """The path bench.py times, at its real size: GraphedGANTrainer at full width, bf16, B = 128 (grouped 5 N generator pass
+    with compacted activations, pipelined tiles) captures into HIP graphs -- the compacted pitches are read on the host
+    BEFORE the capture -- and its replayed iteration equals the eager trainer's on the same state, batch and latents."""
+    from mcgen_amd import trainer as T
+    sd = gu.procedural_state(gu.mcgan_shapes([256] * 4, [128] * 4, 10), seed=1234, num_mode=10)
+    img, lab = gu.synthetic_batch(128, 10, seed=1)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(6, 128, 128, seed=2)]
+    m1 = _build([256] * 4, [128] * 4, 10, 'CIFAR10', sd, torch.bfloat16)
+    l_e = T.GANTrainer(m1, 10).train_iteration(img, lab, zs)
+    m2 = _build([256] * 4, [128] * 4, 10, 'CIFAR10', sd, torch.bfloat16)
+    tr = T.GraphedGANTrainer(m2, 10)
+    tr.capture(img, lab)
+    assert tr._graphs is not None
+    l_g = tr.train_iteration(img, lab, zs)
+    np.testing.assert_allclose([float(l_g[0]), float(l_g[1])], [float(l_e[0]), float(l_e[1])], rtol=0, atol=2e-3)
+    a, b = m1.state_dict(), m2.state_dict()
+    for k in a:
+        if a[k].dtype.is_floating_point:
+            assert float((a[k].float() - b[k].float()).abs().max()) <= 2e-3 * (1 + float(a[k].float().abs().max())), k
+    d = gu.load_npz('mcgan_full_digest_b128.npz')
+    np.testing.assert_allclose([float(l_g[0]), float(l_g[1])], d['losses'][0], rtol=0, atol=5e-2)
