@@ -155,6 +155,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise McgenError(f'{LIB_PATH} is missing: run __graft_entry__.build() '
                              f'(or csrc/build.sh); there is no CPU fallback')
+        # PyTorch-ROCm ships its own libamdhip64; the process must have ONE HIP runtime, and it has to be the one torch's
+        # streams and allocations live in: import torch first, so that this library's libamdhip64 dependency resolves to
+        # the copy already loaded (loaded the other way round, every launch fails with "no ROCm-capable device").
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -214,3 +214,14 @@ def test_process_control_fills_vqvae_and_rederives_classes():
     process_control()
     assert cfg['classes_size'] == 12
     _cfg_for('CIFAR10')
+
+
+def test_library_loader_imports_torch_first():
+    """_lib.load() in a fresh interpreter that has not imported torch: afterwards torch IS loaded (one HIP runtime per
+    process, torch's; loading libmcgen_hip.so first made every later launch fail on the GPU box)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import mcgen_amd._lib as L; assert 'torch' not in sys.modules; "
+            "L.load(); assert 'torch' in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
