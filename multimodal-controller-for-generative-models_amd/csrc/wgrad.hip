@@ -502,8 +502,8 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 //    of a tile past the end is clamped).  The prologue is then an LDS -> LDS pass over the thread's own units, and
 //    everything tile-independent is a per-thread constant (LDS offset, element offset from the tile's first pixel, row
 //    offset): per tile an item costs a row-range test and an address add.
-//  * consumers: EIGHT consumer waves, two per SIMD (a lone wave issues bare v_mfma_f32_16x16x32_bf16 at 55 % of the
-//    nominal peak on this part, two waves at 82 %: tools/micro/mfma_peak.hip), each 32 output channels x 16 input
+//  * consumers: EIGHT consumer waves, two per SIMD (measured: 628 -> 641 TFLOP/s against four consumer waves; the
+//    SIMD's vector issue port, shared with its producer wave, is the kernel's limit), each 32 output channels x 16 input
 //    channels over HALF of the tile's pixels; the halves are added once, through LDS, after the last tile.  Tried on
 //    the way and neutral: all 64 output channels per wave (fewer LDS reads per MFMA), reading fragments 2-6 taps ahead
 //    of their MFMAs (sched_group_barrier) -- LDS is ~20 % busy, it was never the limit.
@@ -536,8 +536,7 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     char* const ldsC0 = ldsD0 + WG_ND * WG_DSLOT;                      // [WG_NR][4 waves][32 floats] code rows (per producer wave)
 
     const int tid = threadIdx.x;
-    // waves 0-7 consume (two per SIMD: a lone wave issues bare MFMAs at 55 % of peak on this part, two at 82 %,
-    // tools/micro/mfma_peak.hip), waves 8-11 produce
+    // waves 0-7 consume (two per SIMD), waves 8-11 produce
     const bool producer = __builtin_amdgcn_readfirstlane(tid >> 9) != 0;
     const int rtid = tid & 255;
     const int lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6), wave = cw & 3;
