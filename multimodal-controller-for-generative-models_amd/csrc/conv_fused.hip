@@ -1489,7 +1489,7 @@ static __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
-constexpr int PP_NIW = 3;            // window items per thread and chunk (host: 4 * window pixels <= PP_NIW * threads)
+constexpr int PP_NIW_MAX = 3;        // at most three window items per thread and chunk (registers)
 
 // (LGW = log2 of the map width is a template parameter: every LDS address of the main loop is one per-lane base plus a
 // compile-time offset, i.e. the immediate field of the ds instruction -- no address VALU, no per-fragment registers.)
@@ -1507,11 +1507,12 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     constexpr int NW = WM * WN, KB = BB / 1024, PPW = KB / NW;
     static_assert(KB % NW == 0 && (PPW == 1 || PPW == 2), "one or two 1 KB weight pieces per wave and tap");
     static_assert(FM % 2 == 0, "two pixel halves per wave");
-    constexpr int NIW = PP_NIW, HF = FM / 2;
+    constexpr int HF = FM / 2;
     constexpr int PW0 = 10, PWS = 2;                       // window item j is stored in phase PW0 + PWS * j (<= 16)
-    static_assert(PW0 + PWS * (NIW - 1) <= 16 && 2 * R < 18, "window stores end before the chunk's last barrier");
     constexpr int W = 1 << LGW, TH = BM / W, PC = W + 2, PR = TH + 2, PP = PR * PC;
-    static_assert(NIW == 3 && W >= 16 && PP * 4 <= NIW * NT && PP * 4 > (NIW - 1) * NT, "window items per thread");
+    constexpr int NIW = (PP * 4 + NT - 1) / NT;            // window items per thread and chunk
+    static_assert((NIW == 2 || NIW == 3) && NIW <= PP_NIW_MAX && W >= 16 && TH >= 1, "window items per thread");
+    static_assert(PW0 + PWS * (NIW - 1) <= 16 && 2 * R < 18, "window stores end before the chunk's last barrier");
     constexpr int ITEM_STEP = (NT / 4) * APITCH;           // LDS distance between a thread's consecutive window items
     // K-major tap tile: 32 rows of ROWB bytes, RPPK rows per 1 KB DMA piece, LPR lanes per row
     constexpr int ROWB = BN * 2, RPPK = 1024 / ROWB, LPR = 64 / RPPK;
@@ -1719,7 +1720,8 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         for (int j = 0; j < NIW; ++j) wload(j, 0, raw0[j]);
         if (tid < C0) { aff[tid] = t_sc * t_cd; aff[C0 + tid] = t_sh * t_cd; }
         neg_tile = __syncthreads_or((tid < C0 && sg0.relu && t_cd < 0.f) ? 1 : 0) != 0;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
+        if constexpr (NIW == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]) :: "memory");
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wwrite(j, raw0[j], ldsA0, 0);
     }
@@ -1930,11 +1932,11 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     // barrier ("dma3" form) wins on every shape; big tiles only where there are enough pixels to fill 256 CUs
     const bool rows256 = (256 >= 2 * p->W) || (HW <= 256), rows128 = (128 >= 2 * p->W) || (HW <= 128);
     // pipe 20: the software-pipelined form of the 3x3 main loop ("pp"), where its window / ring / item plan fits (pp_fits)
-    static const long pp_mode = env_long("MCGEN_PP", 7);       // tuning builds: bit 0 = the 256x256 tile, bit 1 = 256x128 (bit 2: gathered K)
+    static const long pp_mode = env_long("MCGEN_PP", 15);      // tuning builds: bit 0 = the 256x256 tile, bit 1 = 256x128, bit 3 = 128x256 (bit 2: gathered K)
     if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, ((pp_mode & 1) && pp_fits<256, 256, 2, 4, 5>(p)) ? 20 : 5};
     if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, 2, 4, 5>(p)) return {256, 128, 20};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
-    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, 5};
+    if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, ((pp_mode & 8) && pp_fits<128, 256, 2, 4, 5>(p)) ? 20 : 5};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
     // 64x64 tile on 8 waves (4 x 2): ~15 % faster than 4 waves on 8x8 maps, bit-identical outputs.  (Its BatchNorm partial
     // sums round differently in the last bit, which once looked like a defect: the bf16 full-size digest run is bimodal
@@ -2181,7 +2183,7 @@ static int dispatch_gk(const mcgen_conv_t* p, int dtype, hipStream_t st) {
 }
 
 // "pp" form (conv_pp_kernel): 3x3 first segment with whole 32-channel chunks, further segments 1x1, tile inside one image,
-// window small enough for PP_NIW items per thread, two windows + ring + table within the CU's LDS.
+// window of two or three items per thread, two windows + ring + table within the CU's LDS.
 template <int BM, int BN, int WM, int WN, int R, bool GK>
 static bool pp_fits_(const mcgen_conv_t* p) {
     using C = ConvCfg<bf16_t, BM, BN, WM, WN>;
@@ -2190,7 +2192,7 @@ static bool pp_fits_(const mcgen_conv_t* p) {
     if ((p->seg[0].cmap != nullptr) != GK) return false;               // gathered K: the first segment's rows come from its map
     for (int s = 1; s < p->nseg; ++s) if (p->seg[s].ksize != 1 || (!GK && p->seg[s].cmap)) return false;
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
-    if (PP * 4 > PP_NIW * C::NT) return false;
+    if (PP * 4 > PP_NIW_MAX * C::NT || PP * 4 <= C::NT) return false;
     const int a_bytes = round_up(PP * C::APITCH, 1024);
     const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + C::NT * 16;
     return lds <= 160 * 1024;
@@ -2252,6 +2254,7 @@ static const CfgEntry* bf16_table(int* n) {
         {64, 64, 11, launch_dma<T, 64, 64, 4, 2>},    {256, 16, 5, launch_dma<T, 256, 16, 8, 1>},
         {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},     {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
         {256, 256, 20, launch_pp<T, 256, 256, 2, 4, 5, false>}, {256, 128, 20, launch_pp<T, 256, 128, 2, 4, 5, false>},
+        {128, 256, 20, launch_pp<T, 128, 256, 2, 4, 5, false>},
 #ifdef MCGEN_TUNING
         {128, 256, 4, launch_dma1<T, 128, 256, 1, 4>}, {128, 256, 14, launch_dma1<T, 128, 256, 2, 4>},
         {256, 128, 15, launch_dma<T, 256, 128, 4, 1>}, {256, 128, 16, launch_dma<T, 256, 128, 2, 2>},
