@@ -1489,7 +1489,7 @@ static __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
-constexpr int PP_NIW_MAX = 3;        // at most three window items per thread and chunk (registers)
+constexpr int PP_NIW_MAX = 4;        // at most four window items per thread and chunk (registers)
 
 // (LGW = log2 of the map width is a template parameter: every LDS address of the main loop is one per-lane base plus a
 // compile-time offset, i.e. the immediate field of the ds instruction -- no address VALU, no per-fragment registers.)
@@ -1511,7 +1511,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     constexpr int PW0 = 10, PWS = 2;                       // window item j is stored in phase PW0 + PWS * j (<= 16)
     constexpr int W = 1 << LGW, TH = BM / W, PC = W + 2, PR = TH + 2, PP = PR * PC;
     constexpr int NIW = (PP * 4 + NT - 1) / NT;            // window items per thread and chunk
-    static_assert((NIW == 2 || NIW == 3) && NIW <= PP_NIW_MAX && W >= 16 && TH >= 1, "window items per thread");
+    static_assert(NIW >= 2 && NIW <= PP_NIW_MAX && W >= 16 && TH >= 1, "window items per thread");
     static_assert(PW0 + PWS * (NIW - 1) <= 16 && 2 * R < 18, "window stores end before the chunk's last barrier");
     constexpr int ITEM_STEP = (NT / 4) * APITCH;           // LDS distance between a thread's consecutive window items
     // K-major tap tile: 32 rows of ROWB bytes, RPPK rows per 1 KB DMA piece, LPR lanes per row
@@ -1521,7 +1521,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsA0 = smem;
     char* const ldsB0 = smem + 2 * a_bytes;
-    float* const aff = reinterpret_cast<float*>(ldsB0 + R * BB);   // [C0] scale * code, [C0] shift * code; then 16 B per thread: dump slots
+    float* const aff = reinterpret_cast<float*>(ldsB0 + R * BB);   // [C0] scale * code, [C0] shift * code; then one 16-byte dump slot
     float* epi = reinterpret_cast<float*>(smem);
 
     const int tid = threadIdx.x;
@@ -1690,7 +1690,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     };
     // (straight-line on purpose: with branches around the stores hipcc spills ~50 registers into the main loop)
     const float relu_lo = sg0.relu ? 0.f : -__builtin_inff();
-    const uint32_t lds_dump = (uint32_t)reinterpret_cast<uintptr_t>(reinterpret_cast<char*>(aff) + C0 * 8) + tid * 16;
+    const uint32_t lds_dump = (uint32_t)reinterpret_cast<uintptr_t>(reinterpret_cast<char*>(aff) + C0 * 8);      // one 16-byte dump slot for the whole workgroup
     auto wwrite = [&](int j, const u32x4& r, char* abuf, int c0) {
         union { bf16x8 h; u32x4 w; } o;
 #pragma unroll
@@ -1706,7 +1706,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         }
         if (it_src[j] < 0) o.w = u32x4{0u, 0u, 0u, 0u};               // the convolution's zero padding
         uint32_t la = (uint32_t)reinterpret_cast<uintptr_t>(abuf + lds_item0 + j * ITEM_STEP);
-        if (j == NIW - 1 && it_src[j] == -2) la = lds_dump;            // no such item: the store goes to this thread's dump slot
+        if (j == NIW - 1 && it_src[j] == -2) la = lds_dump;            // no such item: the store goes to the dump slot
         asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(o.w) : "memory");
     };
     // activation fragment fm of this lane: tile pixel wm * (BM / WM) + 16 fm + l15 (16 | W: the fm part is a constant)
@@ -1720,7 +1720,8 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
         for (int j = 0; j < NIW; ++j) wload(j, 0, raw0[j]);
         if (tid < C0) { aff[tid] = t_sc * t_cd; aff[C0 + tid] = t_sh * t_cd; }
         neg_tile = __syncthreads_or((tid < C0 && sg0.relu && t_cd < 0.f) ? 1 : 0) != 0;
-        if constexpr (NIW == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
+        if constexpr (NIW == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]), "+v"(raw0[3]) :: "memory");
+        else if constexpr (NIW == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]), "+v"(raw0[2]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw0[0]), "+v"(raw0[1]) :: "memory");
 #pragma unroll
         for (int j = 0; j < NIW; ++j) wwrite(j, raw0[j], ldsA0, 0);
@@ -1934,6 +1935,8 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     // pipe 20: the software-pipelined form of the 3x3 main loop ("pp"), where its window / ring / item plan fits (pp_fits)
     static const long pp_mode = env_long("MCGEN_PP", 15);      // tuning builds: bit 0 = the 256x256 tile, bit 1 = 256x128, bit 3 = 128x256 (bit 2: gathered K)
     if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, ((pp_mode & 1) && pp_fits<256, 256, 2, 4, 5>(p)) ? 20 : 5};
+    // (128-channel layers on a 128 x 128 FOUR-wave tile -- 76 KB of LDS, two workgroups per CU -- measured slower: the 32x32
+    // layer 106 -> 152 us, the step +0.6 ms; its window is 60 % halo and a wave keeps 16 MFMAs per tap either way)
     if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, 2, 4, 5>(p)) return {256, 128, 20};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, ((pp_mode & 8) && pp_fits<128, 256, 2, 4, 5>(p)) ? 20 : 5};
@@ -2194,7 +2197,7 @@ static bool pp_fits_(const mcgen_conv_t* p) {
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
     if (PP * 4 > PP_NIW_MAX * C::NT || PP * 4 <= C::NT) return false;
     const int a_bytes = round_up(PP * C::APITCH, 1024);
-    const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + C::NT * 16;
+    const int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + 16;
     return lds <= 160 * 1024;
 }
 template <int BM, int BN, int WM, int WN, int R>
@@ -2208,7 +2211,7 @@ static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
     const int nt = (p->Cout_w + BN - 1) / BN;
     const int PP = mcgen_patch_pixels(BM, p->H, p->W, 3);
     const int a_bytes = round_up(PP * C::APITCH, 1024);
-    int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + C::NT * 16;
+    int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + 16;
     const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
