@@ -8,6 +8,7 @@
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +32,11 @@ template <> struct Elem<float> {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
+    static __device__ __forceinline__ vec8 load8v(const float* p) { return *reinterpret_cast<const vec8*>(p); }
+    static __device__ __forceinline__ void unpack8(const vec8& r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r[i];
+    }
     static __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
         *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
@@ -47,6 +53,15 @@ template <> struct Elem<bf16_t> {
         for (int i = 0; i < 4; ++i) {
             v[2 * i] = __uint_as_float(r[i] << 16);
             v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ vec8 load8v(const bf16_t* p) { return *reinterpret_cast<const vec8*>(p); }
+    static __device__ __forceinline__ void unpack8(const vec8& r8, float (&v)[8]) {
+        union { vec8 h; u32x4 w; } u; u.h = r8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(u.w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(u.w[i] & 0xffff0000u);
         }
     }
     static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
