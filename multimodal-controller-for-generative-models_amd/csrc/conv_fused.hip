@@ -668,9 +668,15 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     using M = Mma<T>;
     constexpr int NT = C::NT, FM = C::FM, FN = C::FN, ESZ = C::ESZ, APITCH = C::APITCH, BROW = C::BROW;
-    constexpr int TPS = 3;
-    // 128-pixel tiles only: the 256x256 tile has no registers to spare (128 accumulators), 64-pixel tiles have 2 items per thread
-    constexpr bool STAGE2 = MCGEN_STAGE2 && (BM == 128 || (MCGEN_STAGE2_SMALL && BM < 128) || (MCGEN_STAGE2_BIG && BM * BN >= 256 * 256));
+    // taps per group: a kernel row; on the skinny Cout <= 16 tile the whole 3x3 filter of a chunk (9 KB).  That tile does 18
+    // MFMAs per wave and chunk, so with a row per group every group waited out the round trip of a DMA issued one (tiny)
+    // group earlier -- three exposed L2 latencies per chunk; with the chunk as the group the next chunk's taps are in flight
+    // behind a whole chunk's staging and MFMAs
+    constexpr int TPS = (BN <= 16) ? 9 : 3;
+    // 128-pixel tiles and the skinny Cout <= 16 tile (8 accumulators; item by item it exposed three round trips per chunk:
+    // 231 -> 184 us on the generator's 640-image head with this and the whole-chunk tap group below); the 256x256 tile has no
+    // registers to spare (128 accumulators), 64-pixel tiles have 2 items per thread
+    constexpr bool STAGE2 = MCGEN_STAGE2 && (BM == 128 || BN <= 16 || (MCGEN_STAGE2_SMALL && BM < 128) || (MCGEN_STAGE2_BIG && BM * BN >= 256 * 256));
     constexpr int NW = WM * WN;
     constexpr int KB = C::BBYTES / 1024;                   // 1 KB DMA pieces per weight tile
     constexpr int PPW = (KB + NW - 1) / NW;                // pieces per wave per tap
@@ -701,10 +707,10 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
     // group bookkeeping over the linear (segment, chunk, tap) sequence
     const int nt0 = p.seg[0].ksize * p.seg[0].ksize, nc0 = (p.seg[0].C + MCGEN_CK - 1) / MCGEN_CK;
-    const int gpc0 = (nt0 == 9) ? 3 : 1;                   // groups per chunk
+    const int gpc0 = (nt0 == 9) ? 9 / TPS : 1;                   // groups per chunk
     const int G0 = nc0 * gpc0, S0 = nc0 * nt0;
     int nt1 = 1, nc1 = 0, gpc1 = 1;
-    if (p.nseg > 1) { nt1 = p.seg[1].ksize * p.seg[1].ksize; nc1 = (p.seg[1].C + MCGEN_CK - 1) / MCGEN_CK; gpc1 = (nt1 == 9) ? 3 : 1; }
+    if (p.nseg > 1) { nt1 = p.seg[1].ksize * p.seg[1].ksize; nc1 = (p.seg[1].C + MCGEN_CK - 1) / MCGEN_CK; gpc1 = (nt1 == 9) ? 9 / TPS : 1; }
     const int GT = G0 + nc1 * gpc1;                        // total groups
 
     constexpr int UPR = C::UPR, RPP = 64 / UPR;
@@ -720,11 +726,12 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     auto G_dma = [&](int gi) {                             // all taps of group gi -> slot gi & 1
         if (gi >= GT) return;
         int blk0, ntg;
-        if (gi < G0) { ntg = (nt0 == 9) ? 3 : 1; blk0 = gi * ntg; }
-        else { const int gj = gi - G0; ntg = (nt1 == 9) ? 3 : 1; blk0 = S0 + gj * ntg; }
+        if (gi < G0) { ntg = (nt0 == 9) ? TPS : 1; blk0 = gi * ntg; }
+        else { const int gj = gi - G0; ntg = (nt1 == 9) ? TPS : 1; blk0 = S0 + gj * ntg; }
         char* slot = ldsB0 + (gi & 1) * SLOT;
 #pragma unroll
         for (int t = 0; t < TPS; ++t) {
+            if (TPS > 3 && t >= ntg) break;                        // (the waits below are vmcnt(0): no constant count needed)
             const int blk = blk0 + (t < ntg ? t : ntg - 1);        // short group: re-load the last tap (constant DMA count)
             const char* wb = wimg + (size_t)blk * wblock_bytes;
 #pragma unroll
@@ -763,7 +770,7 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
         }
         const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
         const int ntap = sg.ksize * sg.ksize;
-        const int gpc = (ntap == 9) ? 3 : 1, ntg = (ntap == 9) ? 3 : 1;
+        const int gpc = (ntap == 9) ? 9 / TPS : 1, ntg = (ntap == 9) ? TPS : 1;
 #pragma unroll 1
         for (int q = 0; q < nchunk; ++q) {
             __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
@@ -2157,7 +2164,7 @@ static int launch_dma(const mcgen_conv_t* p, hipStream_t st) {
     const bool grouped = p->nseg == 1 && p->seg[0].ksize == 1 && p->seg[0].C >= 12 * MCGEN_CK &&
                          (a3 > a_bytes ? a3 : a_bytes) + 6 * C::BBYTES <= 96 * 1024;
     if (grouped && a3 > a_bytes) a_bytes = a3;
-    int lds = a_bytes + 6 * C::BBYTES;
+    int lds = a_bytes + 2 * (BN <= 16 ? 9 : 3) * C::BBYTES;      // ring: two slots of a group's taps (conv_dma3_kernel: TPS)
     const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
     if (epi_bytes > lds) lds = epi_bytes;
     if (red_bytes > lds) lds = red_bytes;
