@@ -53,16 +53,26 @@ constexpr int YTAB_COLS = 320, YTAB_BYTES = YTAB_COLS * 2 + YTAB_COLS * 4;
 // fp32 math, a residual / gate load whose latency is exposed in every iteration -- goes: the pass's residual and gate rows
 // are requested before the accumulators take their turn through LDS, the math runs on float2 (v_pk_fma_f32 / v_pk_add_f32),
 // and nothing is predicated per channel.  Same arithmetic per element and same accumulation order of the statistics as the
-// general loop: results are bit-identical (measured on the 256 x 256 tile: 12 us -> 4 us of a 74 us tile).
-template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL>
+// general loop: results are bit-identical with NP = 0.  Measured on the 256 x 256 pp tile (tools/pp_fc.py, 74 us per tile at 256 input channels):
+// epilogue 12.1 -> 9.6 us, of which acc -> LDS 2.0, the read loop's LDS reads + math 4.0, its global stores 2.7; over the
+// whole step (every conv kernel shares this epilogue) 10.10 -> 9.62 ms.
+template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0>
 __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
                                                    float* epi, int tid, int wm, int wn, int l15, int lg,
                                                    int tile_m, int cout0, float alpha) {
     using E = Elem<T>;
-    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, EP = C::EP, CH = C::CH, PROWS = C::PROWS, PPX = C::PPX;
+    constexpr int NT = C::NT, FM = C::FM, FN = C::FN, EP = C::EP, CH = C::CH, PROWS = C::PROWS;
+    // NP > 0 (kernels whose LDS holds BM / NP pixel rows of fp32: the pp form): NP passes instead of EPX, and EVERY wave takes
+    // part in every pass -- pass k holds fragments [k FMP, (k + 1) FMP) of each wave row (GRP = 16 FMP pixels, whole image
+    // rows, pooling pairs inside).  Fewer write | barrier | read | barrier rounds: the 256 x 128 tile has one instead of four.
+    constexpr bool REMAP = NP > 0;
+    constexpr int NPASS = REMAP ? NP : C::EPX, PPX = BM / NPASS;
+    constexpr int FMP = REMAP ? FM / NPASS : FM, GRP = FMP * 16, WROW = BM / WM;
+    static_assert(!REMAP || (FM % NPASS == 0 && GRP % 64 == 0), "merged passes hold whole row pairs of every wave row");
     constexpr int OUT_PP = POOL ? PPX / 4 : PPX;                       // output pixels per pass
     constexpr int ITERS = (OUT_PP + PROWS - 1) / PROWS;
     constexpr bool RAGGED = OUT_PP % PROWS != 0;                       // (fewer output pixels per pass than thread rows)
+    constexpr int PB = ITERS < 4 ? ITERS : 4;                          // residual / gate rows requested ahead, per batch
     const int ch = tid % CH, prow = tid / CH;
     const int co = cout0 + ch * 8;
     const int W = p.W, Cy = p.Cy;
@@ -95,29 +105,43 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     for (int i = 0; i < 4; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     const int lgWo = POOL ? g.lgW - 1 : g.lgW, lgTHWo = POOL ? g.lgTHW - 2 : g.lgTHW;
 
-#pragma unroll
-    for (int pass = 0; pass < C::EPX; ++pass) {
-        // this pass's residual / gate rows: in flight while the accumulators go through LDS
-        typename E::vec8 rraw[ITERS], graw[ITERS];
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int mo = prow + it * PROWS;
-            if (!RAGGED || mo < OUT_PP) {
-                const int off = (pass * OUT_PP + mo) * Cy;
-                if (rb) rraw[it] = E::load8v(rb + off);
-                if (gb) graw[it] = E::load8v(gb + off);
-            }
+    // output pixel `mo` of pass `pass` -> pixel of the (pooled) tile
+    auto tile_pix = [&](int pass, int mo) -> int {
+        if constexpr (REMAP) {
+            constexpr int G = POOL ? GRP / 4 : GRP, WR = POOL ? WROW / 4 : WROW;
+            return (mo / G) * WR + pass * G + (mo % G);
+        } else {
+            return pass * OUT_PP + mo;
         }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        // residual / gate rows of the first PB iterations: in flight while the accumulators go through LDS
+        typename E::vec8 rraw[PB], graw[PB];
+        auto request = [&](int it0) {
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int mo = prow + (it0 + j) * PROWS;
+                if (it0 + j < ITERS && (!RAGGED || mo < OUT_PP)) {
+                    const int off = tile_pix(pass, mo) * Cy;
+                    if (rb) rraw[j] = E::load8v(rb + off);
+                    if (gb) graw[j] = E::load8v(gb + off);
+                }
+            }
+        };
+        request(0);
         if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
-                const int m0 = wm * (BM / WM) + fm * 16;
-                if (m0 / PPX == pass) {
-                    const int m = m0 - pass * PPX + l15;
-                    const int cc = wn * (BN / WN) + fn * 16 + lg * 4;
-                    *reinterpret_cast<f32x4*>(epi + m * EP + cc) = acc[fn][fm];
+                const int cc = wn * (BN / WN) + fn * 16 + lg * 4;
+                if constexpr (REMAP) {
+                    if (fm / FMP == pass)
+                        *reinterpret_cast<f32x4*>(epi + (wm * GRP + (fm - pass * FMP) * 16 + l15) * EP + cc) = acc[fn][fm];
+                } else {
+                    const int m0 = wm * (BM / WM) + fm * 16;
+                    if (m0 / PPX == pass) *reinterpret_cast<f32x4*>(epi + (m0 - pass * PPX + l15) * EP + cc) = acc[fn][fm];
                 }
             }
         __syncthreads();
@@ -125,12 +149,20 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
         for (int it = 0; it < ITERS; ++it) {
             const int mo = prow + it * PROWS;
             if (RAGGED && mo >= OUT_PP) continue;
-            const int mt = pass * OUT_PP + mo;
+            const int mt = tile_pix(pass, mo);
             f32x2 v[4];
             if constexpr (POOL) {
-                const int ti = mt >> lgTHWo, rem = mt & ((1 << lgTHWo) - 1);
-                const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
-                const int m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo - pass * PPX;
+                int m00;
+                if constexpr (REMAP) {
+                    constexpr int G = GRP / 4;
+                    const int gq = mo / G, within = mo % G;
+                    const int ro = within >> lgWo, wo = within & ((1 << lgWo) - 1);
+                    m00 = gq * GRP + ((2 * ro) << g.lgW) + 2 * wo;
+                } else {
+                    const int ti = mt >> lgTHWo, rem = mt & ((1 << lgTHWo) - 1);
+                    const int ro = rem >> lgWo, wo = rem & ((1 << lgWo) - 1);
+                    m00 = (ti << g.lgTHW) + ((2 * ro) << g.lgW) + 2 * wo - pass * PPX;
+                }
                 const float* e0 = epi + m00 * EP + ch * 8;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -152,7 +184,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
             }
             if (gb) {
                 float xv[8];
-                E::unpack8(graw[it], xv);
+                E::unpack8(graw[it % PB], xv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x2 x2 = {xv[2 * i], xv[2 * i + 1]};
@@ -164,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
             }
             if (rb) {
                 float rv[8];
-                E::unpack8(rraw[it], rv);
+                E::unpack8(rraw[it % PB], rv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += f32x2{rv[2 * i], rv[2 * i + 1]};
             }
@@ -173,10 +205,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
                 for (int i = 0; i < 4; ++i) { s1[i] += v[i]; s2[i] = __builtin_elementwise_fma(v[i], v[i], s2[i]); }
             }
             const float vo[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
-#ifdef MCGEN_EPI_NOSTORE
-            if (p.N < 0)
-#endif
             E::store8(yb + mt * Cy, vo);
+            if ((it + 1) % PB == 0 && it + 1 < ITERS) request(it + 1);        // the next batch's rows
         }
     }
 
@@ -199,7 +229,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
 }
 
 // Shared epilogue: accumulators -> LDS (fp32 [pixel][cout]) -> fused output pass, PPX pixels at a time.
-template <typename T, typename C, int BM, int BN, int WM, int WN>
+template <typename T, typename C, int BM, int BN, int WM, int WN, int NP = 0>
 __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
                                               float* epi, int tid, int wm, int wn, int l15, int lg,
                                               int tile_m, int cout0, float alpha) {
@@ -216,8 +246,8 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const bool chunk_live = co < spitch;
     // (workgroup-uniform) the whole tile is inside the output: the fast form above
     if (!p.ycmap && !p.tanh_out && (p.Cout & 7) == 0 && cout0 + BN <= p.Cout && g.n0 + g.TI <= N && (!p.ocode || g.TI == 1)) {
-        if (p.pool) conv_epilogue_fast<T, C, BM, BN, WM, WN, true>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
-        else conv_epilogue_fast<T, C, BM, BN, WM, WN, false>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+        if (p.pool) conv_epilogue_fast<T, C, BM, BN, WM, WN, true, NP>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+        else conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
         return;
     }
     T* y = reinterpret_cast<T*>(p.y);
@@ -1648,6 +1678,8 @@ constexpr int pp_vmcnt_w(int j, int pw, int NIW, int PPW) {
     for (int ph = j + 1; ph < pw; ++ph) n += pp_wl(ph, NIW) + pp_dma(ph, PPW);
     return n;
 }
+// epilogue passes of a pp tile (conv_epilogue_fast: NP): as few as keep BM / NP pixel rows of fp32 within 136 KB
+#define PP_EPI_PASSES(BM, BN) (((BM) * ((BN) + 4) * 4 <= 136 * 1024) ? 1 : 2)
 template <int NCNT> static __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCNT) : "memory"); }
 static __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -2040,7 +2072,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 #pragma unroll
             for (int j = 0; j < FM; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else {
-        conv_epilogue<T, C, BM, BN, WM, WN>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, neg_tile ? __builtin_nanf("") : p.alpha);
+        conv_epilogue<T, C, BM, BN, WM, WN, PP_EPI_PASSES(BM, BN)>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, neg_tile ? __builtin_nanf("") : p.alpha);
     }
 }
 
@@ -2372,7 +2404,9 @@ static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
     const int a_bytes = round_up(PP * C::APITCH, 1024);
     int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + 16;
     const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
+    const int epi_fast = (BM / PP_EPI_PASSES(BM, BN)) * C::EP * 4;      // the merged passes of the fast epilogue
     if (epi_bytes > lds) lds = epi_bytes;
+    if (epi_fast > lds) lds = epi_fast;
     if (red_bytes > lds) lds = red_bytes;
     MCGEN_CHECK(lds <= 160 * 1024, "conv_fused(pp): tile %dx%d needs %d bytes of LDS", BM, BN, lds);
     void (*kern)(const mcgen_conv_t, const int) = p->W == 32 ? conv_pp_kernel<BM, BN, WM, WN, R, 5, GK> : conv_pp_kernel<BM, BN, WM, WN, R, 4, GK>;

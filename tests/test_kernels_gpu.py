@@ -954,7 +954,7 @@ def test_compacted_activation_chain_matches_dense(n, h, t):
     channels the consumer's MultimodalController keeps (ycmap), the consumer ('gk' form) stages them contiguously and
     gathers the matching rows of its K-major weight image.  Against the dense chain conv -> BN -> ReLU -> MC -> conv
     (+ an upsampled 1x1 shortcut segment that stays dense): the stored channels are bit-identical, the statistics are
-    the same sums, and the consumer's output is the dense launch's up to a bf16 rounding step."""
+    the same sums (up to fp32 summation order), and the consumer's output is the dense launch's up to a bf16 rounding step."""
     ops = _ops()
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(951 + n + h)
@@ -977,7 +977,8 @@ def test_compacted_activation_chain_matches_dense(n, h, t):
     h_d, st_d = ops.conv_fused([ops.Seg(x0t)], img1, c, bias=b1.cuda(), stats_mode=1)
     h_c, st_c = ops.conv_fused([ops.Seg(x0t)], img1, c, bias=b1.cuda(), stats_mode=1, ycmap=cm, cy=ccap)
     assert h_c.shape == (n, h, h, ccap)
-    assert torch.equal(st_c[..., :c], st_d[..., :c])
+    # (the same per-tile sums, accumulated in a different pixel order: the dense launch takes the merged epilogue passes)
+    torch.testing.assert_close(st_c[..., :c], st_d[..., :c], rtol=2e-5, atol=2e-3)
     cidx = cm[:, c:c + ccap].long()                           # [n, ccap], value c beyond the active count
     gathered = torch.gather(torch.nn.functional.pad(h_d, (0, 1)), 3, cidx.view(n, 1, 1, ccap).expand(n, h, h, ccap))
     assert torch.equal(h_c, gathered)
