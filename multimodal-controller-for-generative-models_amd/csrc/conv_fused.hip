@@ -56,7 +56,12 @@ constexpr int YTAB_COLS = 320, YTAB_BYTES = YTAB_COLS * 2 + YTAB_COLS * 4;
 // general loop: results are bit-identical with NP = 0.  Measured on the 256 x 256 pp tile (tools/pp_fc.py, 74 us per tile at 256 input channels):
 // epilogue 12.1 -> 9.6 us, of which acc -> LDS 2.0, the read loop's LDS reads + math 4.0, its global stores 2.7; over the
 // whole step (every conv kernel shares this epilogue) 10.10 -> 9.62 ms.
-template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0>
+// MODE: what the launch fuses behind alpha / bias, decided once per workgroup -- with everything optional in one loop the
+// compiler if-converts the cheap options into selects and keeps every option's per-channel vectors live (measured on the
+// 256 x 256 tile: 3.5 us of the epilogue's 9.6; 9.62 -> 9.49 ms/step).  1 plain (the forward convolutions in front of a
+// BatchNorm: statistics and the store only), 0 any combination.  (2 residual only and 3 gate only compile, and measured no
+// faster than 0 on the step: not dispatched.)
+template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0, int MODE = 0>
 __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
                                                    float* epi, int tid, int wm, int wn, int l15, int lg,
                                                    int tile_m, int cout0, float alpha) {
@@ -79,8 +84,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     const int Ho = POOL ? (p.H >> 1) : p.H, Wo = POOL ? (W >> 1) : W;
     const size_t opix0 = ((size_t)g.n0 * Ho + (POOL ? (g.h0 >> 1) : g.h0)) * Wo;
     T* yb = reinterpret_cast<T*>(p.y) + opix0 * Cy + co;
-    const T* rb = p.res ? reinterpret_cast<const T*>(p.res) + opix0 * Cy + co : nullptr;
-    const T* gb = p.gate_x ? reinterpret_cast<const T*>(p.gate_x) + opix0 * Cy + co : nullptr;
+    constexpr bool HAS_OC = MODE == 0, HAS_RES = MODE == 0 || MODE == 2, HAS_GATE = MODE == 0 || MODE == 3, PLAIN = MODE == 1;
+    const T* rb = (HAS_RES && p.res) ? reinterpret_cast<const T*>(p.res) + opix0 * Cy + co : nullptr;
+    const T* gb = (HAS_GATE && p.gate_x) ? reinterpret_cast<const T*>(p.gate_x) + opix0 * Cy + co : nullptr;
+    const bool use_res = MODE == 2 || rb != nullptr, use_gate = MODE == 3 || gb != nullptr;
     const int stats_mode = p.stats_mode;
 
     auto ld4 = [&](const float* q, float dflt, f32x2 (&o)[4]) {
@@ -94,7 +101,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     };
     f32x2 bias[4], oc[4], gsc[4], gsh[4], gme[4], grs[4];
     ld4(p.bias, 0.f, bias);
-    ld4(p.ocode ? p.ocode + (size_t)g.n0 * p.Cout : nullptr, 1.f, oc);
+    ld4((HAS_OC && p.ocode) ? p.ocode + (size_t)g.n0 * p.Cout : nullptr, 1.f, oc);
     ld4(gb ? p.gscale : nullptr, 1.f, gsc);
     ld4(gb && p.gscale ? p.gshift : nullptr, 0.f, gsh);
     ld4(gb && stats_mode == 2 ? p.gmean : nullptr, 0.f, gme);
@@ -124,12 +131,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
                 const int mo = prow + (it0 + j) * PROWS;
                 if (it0 + j < ITERS && (!RAGGED || mo < OUT_PP)) {
                     const int off = tile_pix(pass, mo) * Cy;
-                    if (rb) rraw[j] = E::load8v(rb + off);
-                    if (gb) graw[j] = E::load8v(gb + off);
+                    if (use_res) rraw[j] = E::load8v(rb + off);
+                    if (use_gate) graw[j] = E::load8v(gb + off);
                 }
             }
         };
-        request(0);
+        if constexpr (!PLAIN) request(0);
         if (pass > 0) __syncthreads();                     // previous pass's reads of epi are done
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
@@ -178,11 +185,11 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(v[i], al, bias[i]);
-            if (p.ocode) {
+            if (HAS_OC && p.ocode) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] *= oc[i];
             }
-            if (gb) {
+            if (use_gate) {
                 float xv[8];
                 E::unpack8(graw[it % PB], xv);
 #pragma unroll
@@ -194,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
                     if (stats_mode == 2) { s1[i] += v[i]; s2[i] = __builtin_elementwise_fma(v[i], (x2 - gme[i]) * grs[i], s2[i]); }
                 }
             }
-            if (rb) {
+            if (use_res) {
                 float rv[8];
                 E::unpack8(rraw[it % PB], rv);
 #pragma unroll
@@ -206,7 +213,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
             }
             const float vo[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
             E::store8(yb + mt * Cy, vo);
-            if ((it + 1) % PB == 0 && it + 1 < ITERS) request(it + 1);        // the next batch's rows
+            if constexpr (!PLAIN) if ((it + 1) % PB == 0 && it + 1 < ITERS) request(it + 1);        // the next batch's rows
         }
     }
 
@@ -246,8 +253,11 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const bool chunk_live = co < spitch;
     // (workgroup-uniform) the whole tile is inside the output: the fast form above
     if (!p.ycmap && !p.tanh_out && (p.Cout & 7) == 0 && cout0 + BN <= p.Cout && g.n0 + g.TI <= N && (!p.ocode || g.TI == 1)) {
-        if (p.pool) conv_epilogue_fast<T, C, BM, BN, WM, WN, true, NP>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
-        else conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+#define MCGEN_EPI_CASE(POOLV, MODEV) conv_epilogue_fast<T, C, BM, BN, WM, WN, POOLV, NP, MODEV>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha)
+        if (p.pool) MCGEN_EPI_CASE(true, 0);
+        else if (!p.ocode && !p.gate_x && !p.res) MCGEN_EPI_CASE(false, 1);
+        else MCGEN_EPI_CASE(false, 0);
+#undef MCGEN_EPI_CASE
         return;
     }
     T* y = reinterpret_cast<T*>(p.y);
