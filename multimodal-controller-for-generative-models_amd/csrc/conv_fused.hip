@@ -61,7 +61,9 @@ constexpr int YTAB_COLS = 320, YTAB_BYTES = YTAB_COLS * 2 + YTAB_COLS * 4;
 // 256 x 256 tile: 3.5 us of the epilogue's 9.6; 9.62 -> 9.49 ms/step).  1 plain (the forward convolutions in front of a
 // BatchNorm: statistics and the store only), 0 any combination.  (2 residual only and 3 gate only compile, and measured no
 // faster than 0 on the step: not dispatched.)
-template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0, int MODE = 0>
+// YC (with MODE 1): compacted output -- the loop accumulates the statistics only, a gather pass per round stores, per pixel,
+// the channels of the image's map (the table sits behind the accumulator rows).
+template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0, int MODE = 0, bool YC = false>
 __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
                                                    float* epi, int tid, int wm, int wn, int l15, int lg,
                                                    int tile_m, int cout0, float alpha) {
@@ -112,6 +114,20 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     for (int i = 0; i < 4; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     const int lgWo = POOL ? g.lgW - 1 : g.lgW, lgTHWo = POOL ? g.lgTHW - 2 : g.lgTHW;
 
+    static_assert(!YC || (MODE == 1 && !POOL), "a compacted output takes bias and statistics only");
+    int16_t* ycol = reinterpret_cast<int16_t*>(epi + PPX * EP);       // tile column (or -1) and bias of every output slot
+    float* ybias = reinterpret_cast<float*>(ycol + YTAB_COLS);
+    const int ycgrp = Cy >> 3;
+    if constexpr (YC) {
+        const int16_t* cidx = p.ycmap + (size_t)g.n0 * p.ycmap_stride + ((p.Cout + 7) & ~7);   // record: [cpos: C][cidx: C + 32]...
+        for (int j = tid; j < Cy; j += NT) {
+            const int ct = (int)(uint16_t)cidx[j];                     // true channel (the zero row's index beyond the image's count)
+            const int c = ct - cout0;
+            const bool ok = c >= 0 && c < BN && ct < p.Cout;
+            ycol[j] = (int16_t)(ok ? c : -1);
+            ybias[j] = (ok && p.bias) ? p.bias[ct] : 0.f;
+        }
+    }
     // output pixel `mo` of pass `pass` -> pixel of the (pooled) tile
     auto tile_pix = [&](int pass, int mo) -> int {
         if constexpr (REMAP) {
@@ -212,8 +228,26 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
                 for (int i = 0; i < 4; ++i) { s1[i] += v[i]; s2[i] = __builtin_elementwise_fma(v[i], v[i], s2[i]); }
             }
             const float vo[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
-            E::store8(yb + mt * Cy, vo);
+            if constexpr (!YC) E::store8(yb + mt * Cy, vo);
             if constexpr (!PLAIN) if ((it + 1) % PB == 0 && it + 1 < ITERS) request(it + 1);        // the next batch's rows
+        }
+        if constexpr (YC) {
+            // gather: output slot group jg of local row mo <- tile columns ycol[8 jg ..] (zeros beyond the image's count); reads
+            // the accumulator rows only, like the loop above: no barrier between them
+            T* y0 = reinterpret_cast<T*>(p.y) + opix0 * Cy;
+            const float yrcp = 1.0f / (float)ycgrp;
+            for (int u = tid; u < OUT_PP * ycgrp; u += NT) {
+                const int mo = (int)(((float)u + 0.5f) * yrcp), jg = u - mo * ycgrp;       // u / ycgrp (exact: u < 2^16, ycgrp <= 40)
+                const u32x4 c4 = *reinterpret_cast<const u32x4*>(ycol + jg * 8);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ybias + jg * 8), b1 = *reinterpret_cast<const f32x4*>(ybias + jg * 8 + 4);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = (int)(int16_t)((i & 1) ? (c4[i >> 1] >> 16) : (c4[i >> 1] & 0xffffu));
+                    v[i] = c >= 0 ? fmaf(epi[mo * EP + c], alpha, i < 4 ? b0[i & 3] : b1[i & 3]) : 0.f;
+                }
+                E::store8(y0 + tile_pix(pass, mo) * Cy + jg * 8, v);
+            }
         }
     }
 
@@ -229,8 +263,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
         for (int c = tid; c < BN; c += NT) {
             float a = 0.f, b = 0.f;
             for (int r = 0; r < PROWS; ++r) { const f32x2 t = red[r * BN + c]; a += t[0]; b += t[1]; }
-            p.stats[((size_t)tile_m * 2 + 0) * Cy + cout0 + c] = a;
-            p.stats[((size_t)tile_m * 2 + 1) * Cy + cout0 + c] = b;
+            const int spitch = YC ? p.Cout_w : Cy;                    // (compacted output: statistics over the true channels)
+            p.stats[((size_t)tile_m * 2 + 0) * spitch + cout0 + c] = a;
+            p.stats[((size_t)tile_m * 2 + 1) * spitch + cout0 + c] = b;
         }
     }
 }
@@ -252,6 +287,13 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     const int spitch = p.ycmap ? p.Cout_w : p.Cy;
     const bool chunk_live = co < spitch;
     // (workgroup-uniform) the whole tile is inside the output: the fast form above
+    if constexpr (sizeof(T) == 2) {
+        // compacted output of a whole tile (validated: bf16, one image, every channel in this tile, bias and statistics only)
+        if (p.ycmap && cout0 == 0 && BN == p.Cout && g.n0 < N && p.Cy <= YTAB_COLS) {
+            conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP, 1, true>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+            return;
+        }
+    }
     if (!p.ycmap && !p.tanh_out && (p.Cout & 7) == 0 && cout0 + BN <= p.Cout && g.n0 + g.TI <= N && (!p.ocode || g.TI == 1)) {
 #define MCGEN_EPI_CASE(POOLV, MODEV) conv_epilogue_fast<T, C, BM, BN, WM, WN, POOLV, NP, MODEV>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha)
         if (p.pool) MCGEN_EPI_CASE(true, 0);
@@ -2414,7 +2456,7 @@ static int launch_pp(const mcgen_conv_t* p, hipStream_t st) {
     const int a_bytes = round_up(PP * C::APITCH, 1024);
     int lds = 2 * a_bytes + R * C::BBYTES + p->seg[0].C * 8 + 16;
     const int epi_bytes = C::PPX * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0), red_bytes = C::PROWS * BN * 2 * 4;
-    const int epi_fast = (BM / PP_EPI_PASSES(BM, BN)) * C::EP * 4;      // the merged passes of the fast epilogue
+    const int epi_fast = (BM / PP_EPI_PASSES(BM, BN)) * C::EP * 4 + (p->ycmap ? YTAB_BYTES : 0);      // the merged passes of the fast epilogue
     if (epi_bytes > lds) lds = epi_bytes;
     if (epi_fast > lds) lds = epi_fast;
     if (red_bytes > lds) lds = red_bytes;
