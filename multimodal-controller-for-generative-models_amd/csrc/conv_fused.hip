@@ -1730,6 +1730,9 @@ constexpr int pp_vmcnt_w(int j, int pw, int NIW, int PPW) {
     for (int ph = j + 1; ph < pw; ++ph) n += pp_wl(ph, NIW) + pp_dma(ph, PPW);
     return n;
 }
+#ifndef MCGEN_PP128_WM
+#define MCGEN_PP128_WM 4                   // wave rows of the 256 x 128 pp tile (4 x 2 waves of 64 x 64; 2 x 4 of 128 x 32 measured slower)
+#endif
 // epilogue passes of a pp tile (conv_epilogue_fast: NP): as few as keep BM / NP pixel rows of fp32 within 136 KB
 #define PP_EPI_PASSES(BM, BN) (((BM) * ((BN) + 4) * 4 <= 136 * 1024) ? 1 : 2)
 template <int NCNT> static __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCNT) : "memory"); }
@@ -2180,7 +2183,7 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 65536 && rows256 && p->Cout_w > 128) return {256, 256, ((pp_mode & 1) && pp_fits<256, 256, 2, 4, 5>(p)) ? 20 : 5};
     // (128-channel layers on a 128 x 128 FOUR-wave tile -- 76 KB of LDS, two workgroups per CU -- measured slower: the 32x32
     // layer 106 -> 152 us, the step +0.6 ms; its window is 60 % halo and a wave keeps 16 MFMAs per tap either way)
-    if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, 2, 4, 5>(p)) return {256, 128, 20};
+    if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, MCGEN_PP128_WM, 8 / MCGEN_PP128_WM, 5>(p)) return {256, 128, 20};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, ((pp_mode & 8) && pp_fits<128, 256, 2, 4, 5>(p)) ? 20 : 5};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
@@ -2501,7 +2504,7 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 128, 5, launch_dma<T, 128, 128, 2, 2>}, {64, 128, 5, launch_dma<T, 64, 128, 2, 2>},
         {64, 64, 11, launch_dma<T, 64, 64, 4, 2>},    {256, 16, 5, launch_dma<T, 256, 16, 8, 1>},
         {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},     {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
-        {256, 256, 20, launch_pp<T, 256, 256, 2, 4, 5, false>}, {256, 128, 20, launch_pp<T, 256, 128, 2, 4, 5, false>},
+        {256, 256, 20, launch_pp<T, 256, 256, 2, 4, 5, false>}, {256, 128, 20, launch_pp<T, 256, 128, MCGEN_PP128_WM, 8 / MCGEN_PP128_WM, 5, false>},
         {128, 256, 20, launch_pp<T, 128, 256, 2, 4, 5, false>},
 #ifdef MCGEN_TUNING
         {128, 256, 4, launch_dma1<T, 128, 256, 1, 4>}, {128, 256, 14, launch_dma1<T, 128, 256, 2, 4>},
