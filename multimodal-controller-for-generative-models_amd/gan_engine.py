@@ -97,6 +97,8 @@ _MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
 # gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
 _GK = __import__('os').environ.get('MCGEN_GK', '1') != '0'
 _LOWRES_SC_BWD = __import__('os').environ.get('MCGEN_LOWRES_SC_BWD', '1') != '0'
+# FirstDisResBlock: the 1x1 shortcut as a second K segment of conv2's launch (0: its own launch + a residual read)
+_D0_FUSE = __import__('os').environ.get('MCGEN_D0_FUSE', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -562,9 +564,13 @@ class DiscriminatorEngine:
         W = lambda s: s.m.weight_orig.detach()                                # noqa: E731
         b0 = self.res[0]
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
-        fwd += [(W(c1m), img('0.c1', c1m, False), False, 1, c1m.idx, 1.0),
-                (W(scm), img('0.sc', scm, False), False, 1, scm.idx, 1.0),
-                (W(c2m), img('0.c2', c2m, False), False, 1, c2m.idx, 1.0)]
+        fwd.append((W(c1m), img('0.c1', c1m, False), False, 1, c1m.idx, 1.0))
+        if _D0_FUSE:
+            ta, tb = cat('0.c2s', c2m, scm, False)                           # conv2 + the 1x1 shortcut: one launch, two K segments
+            fwd += [(W(c2m), ta, False, 1, c2m.idx, 1.0), (W(scm), tb, False, 1, scm.idx, 1.0)]
+        else:
+            fwd += [(W(scm), img('0.sc', scm, False), False, 1, scm.idx, 1.0),
+                    (W(c2m), img('0.c2', c2m, False), False, 1, c2m.idx, 1.0)]
         bwd.append((W(c2m), img('0.c2t', c2m, True), True, 1, c2m.idx, 0.25))
         ta, tb = cat('0.dimg', c1m, scm, True)
         bwd += [(W(c1m), ta, True, 1, c1m.idx, 1.0), (W(scm), tb, True, 1, scm.idx, 0.25)]
@@ -681,10 +687,15 @@ class DiscriminatorEngine:
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
         co = c1m.cout
         c1, _ = ops.conv_fused([Seg(img, code=code_of(None, c1m.idx))], I['0.c1'], co, bias=c1m.m.bias)
-        sc, _ = ops.conv_fused([Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
+        # conv2 and the shortcut's 1x1 (mcgan.py:83-86: conv then AvgPool, like conv2) share the pooled epilogue: the shortcut is
+        # a second K segment of the same launch, as in the later blocks (its own launch + the residual read: 21 us of 80)
         code = code_of(0, c2m.idx)
-        y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], I['0.c2'], co, bias=c2m.m.bias,
-                              pool=True, alpha=0.25, res=sc)
+        if _D0_FUSE:
+            y, _ = ops.conv_fused([Seg(c1, code=code, relu=True), Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.c2s'], co,
+                                  bias=c2m.m.bias.detach() + scm.m.bias.detach(), pool=True, alpha=0.25)
+        else:
+            sc, _ = ops.conv_fused([Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
+            y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], I['0.c2'], co, bias=c2m.m.bias, pool=True, alpha=0.25, res=sc)
         ctx['blocks'].append({'c1': c1, 'code': code})
         x = y
         # --- DisResBlocks (mcgan.py:96-138)
