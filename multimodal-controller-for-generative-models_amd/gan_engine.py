@@ -97,6 +97,21 @@ _MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
 # gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
 _GK = __import__('os').environ.get('MCGEN_GK', '1') != '0'
 _LOWRES_SC_BWD = __import__('os').environ.get('MCGEN_LOWRES_SC_BWD', '1') != '0'
+class Nhwc:
+    """An image batch in the engines' own layout ([N, H, W, C padded to 8] of the compute dtype, padding channels zero) with
+    its true channel count: what the trainer hands from one engine to the other, instead of converting to the module
+    boundary's NCHW fp32 and straight back (the values are the same bits either way)."""
+    __slots__ = ('t', 'c')
+
+    def __init__(self, t: Tensor, c: int):
+        self.t, self.c = t, c
+
+    @property
+    def shape(self):                                        # the NCHW shape a caller would see
+        n, h, w, _ = self.t.shape
+        return torch.Size((n, self.c, h, w))
+
+
 # FirstDisResBlock: the 1x1 shortcut as a second K segment of conv2's launch (0: its own launch + a residual read)
 _D0_FUSE = __import__('os').environ.get('MCGEN_D0_FUSE', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
@@ -301,10 +316,11 @@ class GeneratorEngine:
         shapes.append((side, head_conv.out_channels))
         return all(gn % ops.tile_images(n_total, sd, sd, co, self.dtype) == 0 for sd, co in shapes)
 
-    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1):
+    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1, nhwc: bool = False):
         """`groups` > 1 (training mode, forward only): z / indicator hold `groups` batches back to back, each normalised
         with its OWN BatchNorm batch statistics -- `groups` successive generator forwards on unchanged weights
-        (the five discriminator updates of train_gan.py:139-158) as one pass over groups * N images."""
+        (the five discriminator updates of train_gan.py:139-158) as one pass over groups * N images.
+        `nhwc`: return the images as `Nhwc` (for the discriminator engine) instead of NCHW fp32."""
         self.flat_p.ensure()
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype
@@ -384,7 +400,7 @@ class GeneratorEngine:
         out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
         _flush_counters()
-        return ops.to_nchw(out, head_conv.out_channels), ctx
+        return (Nhwc(out, head_conv.out_channels) if nhwc else ops.to_nchw(out, head_conv.out_channels)), ctx
 
     # ---- backward ----------------------------------------------------------------------------------
     def backward(self, ctx, dimg: Tensor, gflat: Tensor, accumulate: bool = False):
@@ -412,7 +428,7 @@ class GeneratorEngine:
         acc = accumulate
         out = ctx['out']
         self._prep_backward_images()
-        dout = ops.to_nhwc(dimg.contiguous(), dt, out.shape[-1])
+        dout = dimg.t if isinstance(dimg, Nhwc) else ops.to_nhwc(dimg.contiguous(), dt, out.shape[-1])
         dtn = ops.tanh_bwd(dout, out)
         y, bnh, codeh = ctx['y'], ctx['bnh'], ctx['codeh']
         c_img, c = head_conv.out_channels, head_conv.in_channels
@@ -627,13 +643,15 @@ class DiscriminatorEngine:
         ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None}
         return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
 
-    def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None):
+    def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None,
+                     x2: Optional[Nhwc] = None):
         """D(real) and D(fake) of one discriminator update (train_gan.py:144-150) as ONE pass over the 2N batch.
         The two forwards of the reference differ only in the spectral-norm state (each runs its own power iteration,
         which depends on the weights alone): conv(x; W / sigma_2) = (sigma_1 / sigma_2) * conv(x; W / sigma_1), so the
         fake half runs on the first pass's weight images with sigma_1 / sigma_2 folded into its per-sample
-        MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input)."""
-        n = real_nchw.shape[0]
+        MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input).
+        `x2` (optional, then real / fake are ignored): the 2N batch real (+) fake already in the engine's layout."""
+        n = x2.shape[0] // 2 if x2 is not None else real_nchw.shape[0]
         (sigma1, uv1), (sigma2, uv2) = self._power_iters(2, True)
         ratio = sigma1 / sigma2
         if ind2 is None:
@@ -652,7 +670,7 @@ class DiscriminatorEngine:
         outs = self._codes_pair.run(ind2, ratio, n)            # all scaled codes of the pass: one launch
         scaled = dict(zip(uses, outs))
         codes = self._codes.run(ind2)                          # unscaled [2N, C] codes: the weight gradients' conv inputs
-        x = torch.cat([real_nchw.detach(), fake_nchw.detach()])
+        x = x2 if x2 is not None else torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
         return self._forward_body(x, ctx, lambda mc_i, sn_idx: scaled[(mc_i, sn_idx)])
@@ -680,8 +698,10 @@ class DiscriminatorEngine:
         self._ensure_preps()
         self._prep_fwd.run(sigma)                 # every W / sigma image of this pass in one launch
         I = self.img
-        img = ops.to_nhwc(x_nchw.detach().contiguous(), dt)
-        ctx['img'] = img
+        img = x_nchw.t if isinstance(x_nchw, Nhwc) else ops.to_nhwc(x_nchw.detach().contiguous(), dt)
+        if img.dtype != dt:
+            raise RuntimeError(f'Nhwc input is {img.dtype}, the engine computes in {dt}')
+        ctx['img'], ctx['nhwc'] = img, isinstance(x_nchw, Nhwc)
         # --- FirstDisResBlock (mcgan.py:72-93)
         b0 = self.res[0]
         c1m, c2m, scm = (self.sn_of[b0.conv[0].module], self.sn_of[b0.conv[3].module], self.sn_of[b0.shortcut[0].module])
@@ -886,7 +906,7 @@ class DiscriminatorEngine:
                 if pair is not None:
                     raise RuntimeError('input gradients of a paired pass are not needed by the D update and not built')
                 dimg_t, _ = ops.conv_fused([Seg(dc1), Seg(dy, ksize=1, ups=True)], I['0.dimg'], c1m.cin, cy=img.shape[-1])
-                dimg = ops.to_nchw(dimg_t, c1m.cin)
+                dimg = Nhwc(dimg_t, c1m.cin) if ctx.get('nhwc') else ops.to_nchw(dimg_t, c1m.cin)
         except BaseException as e:
             red.__exit__(type(e), e, None)
             raise

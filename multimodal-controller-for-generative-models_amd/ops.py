@@ -168,11 +168,13 @@ class Seg:
 
 
 # --------------------------------------------------------------------------- #
-def to_nhwc(x: Tensor, dtype: torch.dtype, cp: Optional[int] = None) -> Tensor:
-    """NCHW fp32 -> NHWC `dtype`, channels zero-padded to a multiple of 8."""
+def to_nhwc(x: Tensor, dtype: torch.dtype, cp: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    """NCHW fp32 -> NHWC `dtype`, channels zero-padded to a multiple of 8 (`out`: a contiguous [N, H, W, cp] buffer to fill)."""
     n, c, h, w = x.shape
     cp = cp or pad8(c)
-    y = torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    y = out if out is not None else torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    if tuple(y.shape) != (n, h, w, cp) or y.dtype != dtype or not y.is_contiguous():
+        raise _lib.McgenError(f'to_nhwc: out must be a contiguous {(n, h, w, cp)} {dtype} tensor')
     check(_lib.load().mcgen_nchw_to_nhwc(_f32(x.contiguous()), _p(y), _dt(dtype), n, c, h, w, cp, _stream()), 'nchw_to_nhwc')
     return y
 

@@ -22,13 +22,14 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .gan_engine import FlatState, _bump
+from .gan_engine import FlatState, Nhwc, _bump
 
 # 'thread_local': other threads of the process (the RCCL watchdog of a multi-rank run polls events) may keep
 # making HIP calls while this thread captures; only this thread's illegal calls abort the capture.
 _CAPTURE_MODE = 'thread_local'
 
 import os as _os
+_NHWC_PAIR = _os.environ.get('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images stay NHWC (0: through NCHW fp32, as round 1)
 _PAIR_D = _os.environ.get('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
 _GROUP_G = _os.environ.get('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
 
@@ -155,21 +156,45 @@ class GANTrainer:
             return self.d_iters
         return 1
 
-    def g_fakes(self, ind_rep, z_cat, groups: int):
-        """Training-mode generator forward(s) for `groups` discriminator updates: [groups * N, C, H, W], detached."""
-        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups)
+    def g_fakes(self, ind_rep, z_cat, groups: int, nhwc: bool = False):
+        """Training-mode generator forward(s) for `groups` discriminator updates: [groups * N, C, H, W], detached
+        (`nhwc`: as the engines' own `Nhwc`, for `pair_buffer`)."""
+        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups, nhwc=nhwc)
         return fake
+
+    # The real batch is the same for the d_iters updates of an iteration and the generated batches come out of the generator
+    # engine in the discriminator engine's layout: the 2N batch of a paired update is assembled in that layout -- real half
+    # converted once per iteration, fake half one device copy per update (instead of slice copy + cat + conversion per update).
+    def pair_buffer(self, img: torch.Tensor):
+        """-> `Nhwc` [2N, H, W, 8] whose first half holds `img` (NCHW fp32), converted now."""
+        n, c, h, w = img.shape
+        dt = self.deng.dtype
+        shape = (2 * n, h, w, ops.pad8(c))
+        buf = getattr(self, '_x2', None)
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != dt or buf.device != img.device:
+            buf = self._x2 = torch.empty(shape, dtype=dt, device=img.device)
+        ops.to_nhwc(img.detach().contiguous(), dt, out=buf[:n])
+        return Nhwc(buf, c)
+
+    @staticmethod
+    def pair_set_fake(x2: 'Nhwc', fakes: 'Nhwc', j: int):
+        n = x2.t.shape[0] // 2
+        x2.t[n:].copy_(fakes.t[j * n:(j + 1) * n])
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
-    def d_compute_iter(self, img, ind, fake, ind2=None):
+    def d_compute_iter(self, img, ind, fake, ind2=None, x2=None):
         """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
-        [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once."""
+        [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once.  `x2` (optional, instead
+        of img / fake): real (+) fake as `pair_buffer` / `pair_set_fake` left them."""
+        if x2 is not None and not _PAIR_D:
+            n = x2.t.shape[0] // 2
+            img, fake, x2 = Nhwc(x2.t[:n], x2.c), Nhwc(x2.t[n:], x2.c), None
         if _PAIR_D:
             # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
             # power iterations of the two reference forwards depend on the weights alone and run first, in order
-            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2)
-            n = img.shape[0]
+            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2, x2=x2)
+            n = ind.shape[0]
             lg = logits.view(-1)
             self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
             yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False, split=self.world > 1)
@@ -180,8 +205,8 @@ class GANTrainer:
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
         yield from self.deng.backward_iter(ctx_f, dfake, self.grad_d, True, False, split=self.world > 1)   # final once the second pass added
 
-    def d_compute(self, img, ind, fake, ind2=None):
-        for _ in self.d_compute_iter(img, ind, fake, ind2):
+    def d_compute(self, img, ind, fake, ind2=None, x2=None):
+        for _ in self.d_compute_iter(img, ind, fake, ind2, x2):
             pass
         return self.loss_d
 
@@ -189,7 +214,7 @@ class GANTrainer:
         self.opt_d.step(self.grad_d)
 
     def g_compute_iter(self, ind, z):
-        fake, gctx = self.geng.forward(z, ind, True)
+        fake, gctx = self.geng.forward(z, ind, True, nhwc=_NHWC_PAIR)  # (engine to engine: images and their gradient stay NHWC)
         d_fake, dctx = self.deng.forward(fake, ind, True)
         self.loss_g, dfake = ops.hinge_g(d_fake.view(-1))
         dimg = self.deng.backward(dctx, dfake, None, False, True)
@@ -204,8 +229,8 @@ class GANTrainer:
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
 
-    def d_update(self, img, ind, fake, ind2=None):
-        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2):
+    def d_update(self, img, ind, fake, ind2=None, x2=None):
+        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2, x2):
             self._reduce_bucket(self.grad_d, lo, hi)
         self._join_comm()
         self.d_apply()
@@ -232,12 +257,17 @@ class GANTrainer:
         fg = self.fake_groups(n)
         ind_rep = ind.repeat(fg, 1) if fg > 1 else ind
         fakes = None
+        x2 = self.pair_buffer(img) if _NHWC_PAIR else None
         for k in range(self.d_iters):
             if k % fg == 0:
                 z_cat = torch.cat([draw() for _ in range(fg)]) if fg > 1 else draw()
-                fakes = self.g_fakes(ind_rep, z_cat, fg)
+                fakes = self.g_fakes(ind_rep, z_cat, fg, nhwc=_NHWC_PAIR)
             j = k % fg
-            d_loss = self.d_update(img, ind, fakes[j * n:(j + 1) * n], ind2)
+            if _NHWC_PAIR:
+                self.pair_set_fake(x2, fakes, j)
+                d_loss = self.d_update(None, ind, None, ind2, x2=x2)
+            else:
+                d_loss = self.d_update(img, ind, fakes[j * n:(j + 1) * n], ind2)
         for _ in range(self.g_iters):
             g_loss = self.g_update(ind, draw())
         return d_loss, g_loss
@@ -286,16 +316,21 @@ class GraphedGANTrainer(GANTrainer):
         self.s_indg = self.s_ind.repeat(fg, 1) if fg > 1 else self.s_ind     # indicator of the generator pass(es)
         self.s_z = torch.randn(n, self.latent, device=dev)                  # latent of the generator update
         self.s_zd = torch.randn(fg * n, self.latent, device=dev)            # latents of fg discriminator updates
-        self.s_fake = torch.empty_like(self.s_img)                          # the generated batch of the current D update
+        self.s_x2 = self.pair_buffer(self.s_img) if _NHWC_PAIR else None    # real (+) the generated batch of the current D update
+        self.s_fake = None if _NHWC_PAIR else torch.empty_like(self.s_img)
         self.model.train(True)
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                fakes = self.g_fakes(self.s_indg, self.s_zd, fg)
-                self.s_fake.copy_(fakes[:n])
-                self.d_update(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
+                fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
+                if _NHWC_PAIR:
+                    self.pair_set_fake(self.s_x2, fakes, 0)
+                    self.d_update(None, self.s_ind, None, self.s_ind2, x2=self.s_x2)
+                else:
+                    self.s_fake.copy_(fakes[:n])
+                    self.d_update(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
                 self.g_update(self.s_ind, self.s_z)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -305,7 +340,9 @@ class GraphedGANTrainer(GANTrainer):
         self.g_zd, self.g_gf, self.g_z = G(), G(), G()
         self.g_da, self.g_ga = G(), G()
         with torch.cuda.graph(self.g_gf, capture_error_mode=_CAPTURE_MODE):
-            self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg)
+            self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
+            if _NHWC_PAIR:
+                self.pair_buffer(self.s_img)                                # the iteration's real batch -> first half of s_x2
         pool = self.g_gf.pool()
 
         def capture_buckets(gen):
@@ -319,7 +356,8 @@ class GraphedGANTrainer(GANTrainer):
                     lo, hi, last = next(gen)
                 graphs.append((gk, (lo, hi)))
             return graphs
-        self.g_dc = capture_buckets(self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
+        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2) if _NHWC_PAIR else
+                                    self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_zd.normal_()
         with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):
@@ -353,7 +391,10 @@ class GraphedGANTrainer(GANTrainer):
                     self.s_zd.copy_(torch.cat([next(zi) for _ in range(fg)]) if fg > 1 else next(zi), non_blocking=True)
                 self.g_gf.replay()
             j = k % fg
-            self.s_fake.copy_(self.s_fakes[j * n:(j + 1) * n], non_blocking=True)
+            if _NHWC_PAIR:
+                self.pair_set_fake(self.s_x2, self.s_fakes, j)
+            else:
+                self.s_fake.copy_(self.s_fakes[j * n:(j + 1) * n], non_blocking=True)
             for gk, (lo, hi) in self.g_dc:
                 gk.replay()
                 self._reduce_bucket(self.grad_d, lo, hi)

@@ -578,3 +578,33 @@ def test_graphed_trainer_full_width_bf16_matches_eager():
             assert float((a[k].float() - b[k].float()).abs().max()) <= 2e-3 * (1 + float(a[k].float().abs().max())), k
     d = gu.load_npz('mcgan_full_digest_b128.npz')
     np.testing.assert_allclose([float(l_g[0]), float(l_g[1])], d['losses'][0], rtol=0, atol=5e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_engine_to_engine_images_stay_nhwc_bit_identically(dtype):
+    """MCGEN_NHWC_PAIR (trainer.py): inside the trainer the generated batches, the real (+) fake batch of a paired update
+    and the image gradient of the generator update go from one engine to the other in the engines' own layout (`Nhwc`)
+    instead of through the module boundary's NCHW fp32.  Same bits: one train iteration either way gives identical losses
+    and identical parameters (small model, 5 D + 1 G updates, injected latents)."""
+    from mcgen_amd import trainer as T
+    gh, dh, modes = [32, 32, 32, 32], [32, 32, 32, 32], 10
+    sd = gu.procedural_state(gu.mcgan_shapes(gh, dh, modes), seed=77, num_mode=modes)
+    img, lab = gu.synthetic_batch(16, modes, seed=3)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(6, 16, 128, seed=4)]
+
+    def run(flag):
+        old = T._NHWC_PAIR
+        T._NHWC_PAIR = flag
+        try:
+            m = _build(gh, dh, modes, 'CIFAR10', sd, dtype)
+            m.train(True)
+            d, g = T.GANTrainer(m, modes).train_iteration(img, lab, zs)
+            return float(d), float(g), {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+        finally:
+            T._NHWC_PAIR = old
+    d1, g1, s1 = run(True)
+    d0, g0, s0 = run(False)
+    assert (d1, g1) == (d0, g0), ((d1, g1), (d0, g0))
+    for k in s1:
+        assert torch.equal(s1[k], s0[k]), k
