@@ -278,6 +278,11 @@ typedef struct { int64_t w_off, u_off, v_off; int32_t rows, cols; } mcgen_sn_lay
 int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                         int do_iter, float* sigma, float* workspace /* nlayers * (32*max_cols + max_rows) floats */,
                         int max_rows, int max_cols, void* stream);
+/* One training-mode iteration (do_iter = 1) that also leaves the new u, v in `uv_snap` (same offsets as uv_base): the
+ * forward's own copy for the backward pass -- torch's spectral_norm hook clones u and v (torch/nn/utils/spectral_norm.py),
+ * this writes the clone from the kernels that produce the values.  Every float of the u/v buffer must belong to a layer. */
+int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                             float* sigma, float* workspace, int max_rows, int max_cols, float* uv_snap, void* stream);
 /* `rounds` successive power iterations of every layer in ONE launch (one workgroup per layer; u, v, W v stay in LDS):
  * sigma[r][l] and -- when uv_snap != NULL -- the whole u/v buffer as it stands after round r (uv_snap[r][uv_total]:
  * torch's hook clones u, v for the backward, torch/nn/utils/spectral_norm.py) are written per round; uv_base holds the

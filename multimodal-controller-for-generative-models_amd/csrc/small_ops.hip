@@ -437,7 +437,7 @@ __global__ void sn_k1_wtu(const float* __restrict__ wb, const float* __restrict_
         part[j] = s;
     }
 }
-__global__ void sn_k2_v(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws, int ws_stride) {
+__global__ void sn_k2_v(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws, int ws_stride, float* snap) {
     __shared__ float red[32];
     extern __shared__ float sv[];
     const mcgen_sn_layer_t L = layers[blockIdx.x];
@@ -451,7 +451,11 @@ __global__ void sn_k2_v(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
     nrm = sqrtf(block_sum(nrm, red));
     const float inv = 1.f / fmaxf(nrm, 1e-12f);
     float* v = uvb + L.v_off;
-    for (int j = threadIdx.x; j < L.cols; j += blockDim.x) v[j] = sv[j] * inv;
+    for (int j = threadIdx.x; j < L.cols; j += blockDim.x) {
+        const float x = sv[j] * inv;
+        v[j] = x;
+        if (snap) snap[L.v_off + j] = x;                  // the forward's copy of v (torch's hook clones it for the backward)
+    }
 }
 __global__ void sn_k3_wv(const float* __restrict__ wb, const float* __restrict__ uvb,
                          const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws, int ws_stride, int t_off) {
@@ -469,7 +473,7 @@ __global__ void sn_k3_wv(const float* __restrict__ wb, const float* __restrict__
     }
 }
 __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws,
-                        int ws_stride, int t_off, int do_iter, float* sigma) {
+                        int ws_stride, int t_off, int do_iter, float* sigma, float* snap) {
     __shared__ float red[32];
     const mcgen_sn_layer_t L = layers[blockIdx.x];
     const float* t = ws + (size_t)blockIdx.x * ws_stride + t_off;
@@ -479,7 +483,11 @@ __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
     a = block_sum(a, red);
     if (do_iter) {
         const float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
-        for (int i = threadIdx.x; i < L.rows; i += blockDim.x) u[i] = t[i] * inv;
+        for (int i = threadIdx.x; i < L.rows; i += blockDim.x) {
+            const float x = t[i] * inv;
+            u[i] = x;
+            if (snap) snap[L.u_off + i] = x;
+        }
         if (threadIdx.x == 0) sigma[blockIdx.x] = a * inv;
     } else if (threadIdx.x == 0) sigma[blockIdx.x] = a;
 }
@@ -1001,19 +1009,28 @@ extern "C" int mcgen_colsum(const void* x, int dtype, int64_t rows, int C, int p
     MCGEN_LAUNCH_CHECK("colsum"); return 0;
 }
 
-extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
-                                   int do_iter, float* sigma, float* workspace, int max_rows, int max_cols, void* stream) {
+static int sn_power_iter_impl(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                              int do_iter, float* sigma, float* workspace, int max_rows, int max_cols, float* uv_snap, void* stream) {
     MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0 && max_rows > 0 && max_cols > 0,
                 "sn_power_iter: bad arguments (workspace: nlayers * (32 * max_cols + max_rows) floats)");
     MCGEN_CHECK(max_cols * 4 <= 60 * 1024, "sn_power_iter: layers wider than 15360 columns are not supported");
     const int t_off = SN_RS * max_cols, ws_stride = t_off + max_rows;
     if (do_iter) {
         hipLaunchKernelGGL(sn_k1_wtu, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride);
-        hipLaunchKernelGGL(sn_k2_v, dim3(nlayers), dim3(256), max_cols * 4, STREAM(stream), uv_base, layers_dev, workspace, ws_stride);
+        hipLaunchKernelGGL(sn_k2_v, dim3(nlayers), dim3(256), max_cols * 4, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, uv_snap);
     }
     hipLaunchKernelGGL(sn_k3_wv, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride, t_off);
-    hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, do_iter, sigma);
+    hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, do_iter, sigma, uv_snap);
     MCGEN_LAUNCH_CHECK("sn_power_iter"); return 0;
+}
+extern "C" int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                   int do_iter, float* sigma, float* workspace, int max_rows, int max_cols, void* stream) {
+    return sn_power_iter_impl(w_base, uv_base, layers_dev, nlayers, do_iter, sigma, workspace, max_rows, max_cols, nullptr, stream);
+}
+extern "C" int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                        float* sigma, float* workspace, int max_rows, int max_cols, float* uv_snap, void* stream) {
+    MCGEN_CHECK(uv_snap, "sn_power_iter_snap: uv_snap is NULL");
+    return sn_power_iter_impl(w_base, uv_base, layers_dev, nlayers, 1, sigma, workspace, max_rows, max_cols, uv_snap, stream);
 }
 extern "C" int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                          int rounds, int do_iter, float* sigma, float* uv_snap, int64_t uv_total,

@@ -112,6 +112,7 @@ class Nhwc:
         return torch.Size((n, self.c, h, w))
 
 
+_SN_SNAP = __import__('os').environ.get('MCGEN_SN_SNAP', '1') != '0'    # the power iteration's kernels write the forward's u/v copy (0: clone afterwards)
 # FirstDisResBlock: the 1x1 shortcut as a second K segment of conv2's launch (0: its own launch + a residual read)
 _D0_FUSE = __import__('os').environ.get('MCGEN_D0_FUSE', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
@@ -620,9 +621,11 @@ class DiscriminatorEngine:
             out = []
             for _ in range(rounds):
                 sg = torch.empty(nsn, dtype=torch.float32, device=fp.device)
+                # (training mode: the kernels that produce the new u, v also write this forward's copy of them)
+                snap = torch.empty_like(fuv) if (train and _SN_SNAP) else None
                 ops.sn_power_iter(fp, fuv, self._layers_dev, nsn, train, sg,
-                                  max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
-                out.append((sg, fuv.clone()))
+                                  max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn), snap=snap)
+                out.append((sg, snap if snap is not None else fuv.clone()))
             if train:
                 for s in self.sn:
                     _bump(s.m.weight_u); _bump(s.m.weight_v)

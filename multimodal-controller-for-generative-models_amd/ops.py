@@ -625,8 +625,15 @@ def sn_layers_tensor(layers, device) -> Tensor:
 
 
 def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, do_iter: bool, sigma: Tensor,
-                  max_rows: int, max_cols: int):
+                  max_rows: int, max_cols: int, snap: Optional[Tensor] = None):
+    """`snap` (training mode): a buffer shaped like uv_base that receives the new u, v as well (the forward's own copy)."""
     ws = torch.empty(nlayers * (32 * max_cols + max_rows), dtype=torch.float32, device=w_base.device)
+    if snap is not None:
+        if not do_iter or snap.numel() != uv_base.numel() or snap.dtype != torch.float32:
+            raise _lib.McgenError('sn_power_iter: snap needs a training-mode iteration and a float32 buffer like uv_base')
+        check(_lib.load().mcgen_sn_power_iter_snap(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, _f32(sigma), _f32(ws),
+                                                   max_rows, max_cols, _f32(snap), _stream()), 'sn_power_iter_snap')
+        return
     check(_lib.load().mcgen_sn_power_iter(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, int(do_iter),
                                           _f32(sigma), _f32(ws), max_rows, max_cols, _stream()), 'sn_power_iter')
 
