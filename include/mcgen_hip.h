@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 4: + compacted activations between forward-only launches (ycmap, Cw, w_layout 2) */
+int mcgen_abi_version(void);      /* 5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap (4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -116,6 +116,8 @@ typedef struct {
                             * one channel tile.  NULL: dense output.                              */
     int32_t ycmap_stride;
     int32_t reserved_;
+    const float* bias2;    /* [Cout] or NULL: added to `bias` (a fused shortcut segment's own bias: the sum is formed in
+                            * fp32 before it meets the accumulator, as bias + bias2 on the host would be)   */
 } mcgen_conv_t;
 
 /* number of M tiles (rows of `stats`) the launch of `p` will use */

@@ -103,6 +103,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     };
     f32x2 bias[4], oc[4], gsc[4], gsh[4], gme[4], grs[4];
     ld4(p.bias, 0.f, bias);
+    if (p.bias2) {
+        f32x2 b2[4];
+        ld4(p.bias2, 0.f, b2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] += b2[i];
+    }
     ld4((HAS_OC && p.ocode) ? p.ocode + (size_t)g.n0 * p.Cout : nullptr, 1.f, oc);
     ld4(gb ? p.gscale : nullptr, 1.f, gsc);
     ld4(gb && p.gscale ? p.gshift : nullptr, 0.f, gsh);
@@ -313,6 +319,7 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     for (int i = 0; i < 8; ++i) {
         const bool ok = (co + i) < p.Cout;
         bias[i] = (p.bias && ok) ? p.bias[co + i] : 0.f;
+        if (p.bias2 && ok) bias[i] += p.bias2[co + i];
         gsc[i] = (p.gscale && ok) ? p.gscale[co + i] : 1.f;
         gsh[i] = (p.gscale && ok) ? p.gshift[co + i] : 0.f;
         gme[i] = (p.gmean && ok) ? p.gmean[co + i] : 0.f;
@@ -2548,7 +2555,7 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->stats_mode == 0 || p->stats, "conv_fused: stats_mode set without a stats buffer");
     MCGEN_CHECK(p->w_layout >= 0 && p->w_layout <= 2, "conv_fused: unknown weight layout %d", p->w_layout);
     if (p->ycmap) {
-        MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out, "conv_fused: a compacted output takes bias and statistics only");
+        MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out && !p->bias2, "conv_fused: a compacted output takes bias and statistics only");
         MCGEN_CHECK(p->Cy % 32 == 0 && p->Cy <= round_up(p->Cout, 8) + 32 && p->ycmap_stride >= 2 * round_up(p->Cout, 8) + 32,
                     "conv_fused: compacted output: bad pitch %d / map stride %d", p->Cy, p->ycmap_stride);
         MCGEN_CHECK(p->Cout_w <= 256, "conv_fused: a compacted output needs all channels in one tile");

@@ -715,7 +715,7 @@ class DiscriminatorEngine:
         code = code_of(0, c2m.idx)
         if _D0_FUSE:
             y, _ = ops.conv_fused([Seg(c1, code=code, relu=True), Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.c2s'], co,
-                                  bias=c2m.m.bias.detach() + scm.m.bias.detach(), pool=True, alpha=0.25)
+                                  bias=c2m.m.bias, bias2=scm.m.bias, pool=True, alpha=0.25)
         else:
             sc, _ = ops.conv_fused([Seg(img, ksize=1, code=code_of(None, scm.idx))], I['0.sc'], co, bias=scm.m.bias, pool=True, alpha=0.25)
             y, _ = ops.conv_fused([Seg(c1, code=code, relu=True)], I['0.c2'], co, bias=c2m.m.bias, pool=True, alpha=0.25, res=sc)
@@ -732,9 +732,8 @@ class DiscriminatorEngine:
             if has_sc:
                 scm = self.sn_of[b.shortcut[1].module]
                 code1s = code_of(2 * i - 1, scm.idx)
-                bias = c2m.m.bias.detach() + scm.m.bias.detach()
                 y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True), Seg(x, ksize=1, code=code1s)], I[f'{i}.c2s'], c2m.cout,
-                                      bias=bias, pool=pooled, alpha=0.25 if pooled else 1.0)
+                                      bias=c2m.m.bias, bias2=scm.m.bias, pool=pooled, alpha=0.25 if pooled else 1.0)
             else:
                 y, _ = ops.conv_fused([Seg(c1, code=code2, relu=True)], I[f'{i}.c2'], c2m.cout,
                                       bias=c2m.m.bias, res=x)

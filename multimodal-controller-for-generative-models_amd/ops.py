@@ -284,7 +284,7 @@ def prep_weight(w: Tensor, dtype: torch.dtype, transpose: bool = False, row_perm
     return out
 
 
-def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[Tensor] = None,
+def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[Tensor] = None, bias2: Optional[Tensor] = None,
                pool: bool = False, alpha: float = 1.0, res: Optional[Tensor] = None,
                ocode: Optional[Tensor] = None, gate_x: Optional[Tensor] = None,
                gscale: Optional[Tensor] = None, gshift: Optional[Tensor] = None,
@@ -322,6 +322,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=dtype, device=s0.x.device)
     assert tuple(y.shape) == (n, ho, wo, cy) and y.dtype == dtype
     p.w, p.bias, p.y = _p(wimg), _f32(bias), _p(y)
+    p.bias2 = _f32(bias2)
     p.N, p.H, p.W = n, h, w
     p.Cout, p.Cout_w, p.Cy = cout, pad16(cout), cy
     p.pool, p.alpha = int(pool), float(alpha)
