@@ -2,13 +2,13 @@
 """DESIGN.md section 2, COIL100 full-width item: is the generator-loss residual Adam amplifying rounding residues?
 Several discriminator gradients in this case are pure cancellation residues (the true value is 0: the real and fake halves
 contribute +-w/N times an equal count of live pixels), so they come out 0 or +-2^-26 depending on summation order, and
-Adam(eps 1e-8) turns a +-1.5e-8 gradient into a +-1.2e-4 step (tools/diag_elem.py).  This runs the SAME iteration on the
+Adam(eps 1e-8) turns a +-1.5e-8 gradient into a +-1.2e-4 step (tests/diag/diag_elem.py).  This runs the SAME iteration on the
 HIP path (fp32) and on the oracle for a sweep of Adam eps: the arithmetic of every kernel is unchanged, only the
 optimiser's amplification of |g| ~ 1e-8 is switched off as eps grows.  Diagnostic only (needs a GPU)."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import golden_util as gu  # noqa: E402

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One parameter element through the first discriminator update, HIP vs oracle (diagnostic, fp32).
-usage: tools/diag_elem.py <state_dict key under discriminator.> <index> [<index> ...]"""
+usage: tests/diag/diag_elem.py <state_dict key under discriminator.> <index> [<index> ...]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

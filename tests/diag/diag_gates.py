@@ -2,11 +2,11 @@
 """Which ReLU gates does the HIP discriminator forward decide differently from the CPU oracle on identical weights?
 (diagnostic, fp32).  The oracle takes `nupd` discriminator updates, its state is loaded into the HIP model, and every
 pre-ReLU tensor of one forward over the real batch is compared element by element.
-usage: tools/diag_gates.py coil|cifar [batch] [nupd]"""
+usage: tests/diag/diag_gates.py coil|cifar [batch] [nupd]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

@@ -2,11 +2,11 @@
 """Element-level comparison of the HIP discriminator-update gradient with autograd through the CPU oracle on a
 full-size config (diagnostic, fp32): per tensor the max-norm error AND the error on the small-magnitude elements
 (Adam turns every non-zero gradient into a +-lr step, so a wrong tiny gradient moves a weight a full step).
-usage: tools/diag_grads.py coil|cifar [batch]"""
+usage: tests/diag/diag_grads.py coil|cifar [batch]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

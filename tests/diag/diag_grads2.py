@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""As tools/diag_grads.py, but for the SECOND (and later) discriminator updates of an iteration: both sides first run
+"""As tests/diag/diag_grads.py, but for the SECOND (and later) discriminator updates of an iteration: both sides first run
 `k` whole D updates (their states then differ by Adam-level amounts only), then the gradients of update k are compared
-element by element.  usage: tools/diag_grads2.py coil|cifar [batch] [k]"""
+element by element.  usage: tests/diag/diag_grads2.py coil|cifar [batch] [k]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

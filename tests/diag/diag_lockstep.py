@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Lock-step diagnostic (fp32): before every discriminator update the HIP model is loaded with the ORACLE's current
 state, so each update's HIP gradient is compared with autograd on identical weights / u / v; then both take their own
-Adam step (FusedAdam state vs torch.optim.Adam state are compared too).  usage: tools/diag_lockstep.py coil|cifar [batch]"""
+Adam step (FusedAdam state vs torch.optim.Adam state are compared too).  usage: tests/diag/diag_lockstep.py coil|cifar [batch]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

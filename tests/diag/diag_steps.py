@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Step-by-step comparison of the HIP trainer with the CPU oracle on a full-size config (diagnostic, fp32):
 per discriminator update the hinge loss and the mean logits, after the updates the largest parameter differences,
-then the generator loss.  usage: tools/diag_steps.py coil|cifar [batch]"""
+then the generator loss.  usage: tests/diag/diag_steps.py coil|cifar [batch]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

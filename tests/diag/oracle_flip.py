@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU-only: DESIGN.md section 2, COIL100 full-width item.  tools/diag_elem.py shows that in the FIRST discriminator update
+"""CPU-only: DESIGN.md section 2, COIL100 full-width item.  tests/diag/diag_elem.py shows that in the FIRST discriminator update
 the gradient of `discriminator.blocks.3.conv.5.module.bias[146]` (and of the shortcut bias that shares it) is a pure
 cancellation residue: +1.49e-8 (= 2^-26) in the oracle / reference, -1.49e-8 on the HIP path; element 58 is exactly 0 in
 the oracle and +3.7e-9 on the HIP path.  Adam turns either into a step of about lr/2 with the residue's sign.  This script
@@ -9,7 +9,7 @@ amplified by Adam and a ReLU boundary -- not a difference in the computation."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import golden_util as gu  # noqa: E402

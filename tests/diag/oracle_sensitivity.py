@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """CPU-only probe for DESIGN.md section 2's open item: how far does the COIL100 full-width G loss of the pinned CPU
 oracle move when the discriminator gradients of its five D updates carry errors of the size the HIP path's fp32
-gradients show against it (tools/diag_grads.py: absolute errors up to ~1e-8 on elements of magnitude <= 1e-5, relative
+gradients show against it (tests/diag/diag_grads.py: absolute errors up to ~1e-8 on elements of magnitude <= 1e-5, relative
 ~1e-6 elsewhere)?  Adam turns a gradient element of size comparable to that error into a step of up to lr with a
-different sign.  usage: python tools/oracle_sensitivity.py [abs_err] [rel_err] [seeds]"""
+different sign.  usage: python tests/diag/oracle_sensitivity.py [abs_err] [rel_err] [seeds]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import golden_util as gu  # noqa: E402

@@ -152,6 +152,11 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dp, f)
+    # tools/ is not test infrastructure either: scripts that run the oracle live under tests/diag/
+    for f in os.listdir(os.path.join(ROOT, 'tools')):
+        if f.endswith('.py'):
+            src = open(os.path.join(ROOT, 'tools', f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
 
 
 @pytest.mark.parametrize('fixture, model_name, extra', [

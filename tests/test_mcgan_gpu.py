@@ -321,7 +321,7 @@ def test_coil100_full_width(dtype, tol):
     # optimiser, not a kernel: some discriminator gradients here are pure cancellation residues (true value 0; 0 or
     # +-2^-26 depending on summation order -- the oracle itself gives 0 on one host and +1.5e-8 on another), and
     # Adam(eps 1e-8) turns a +-1.5e-8 gradient into a +-1.2e-4 step, which then moves a ReLU boundary
-    # (tools/diag_elem.py).  test_coil100_full_width_follows_the_oracle_once_adam_stops_amplifying_residues below runs
+    # (tests/diag/diag_elem.py).  test_coil100_full_width_follows_the_oracle_once_adam_stops_amplifying_residues below runs
     # the same iteration with eps 1e-6 on both sides and holds 2e-5 on both losses.  DESIGN.md section 2.
     np.testing.assert_allclose(float(l0[0]), d['losses'][0][0], rtol=0, atol=tol)
     np.testing.assert_allclose(float(l0[1]), d['losses'][0][1], rtol=0, atol=max(tol, 3e-2))
