@@ -34,6 +34,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.mcgen_weight_image_elems(4096, 128, 1, 0) == 4 * 4096 * 32
 
 
+def test_graft_entry_build_runs_clean():
+    """The driver's "does it build" entry point: compiles what changed (nothing, normally) and checks the ABI version it
+    expects against the library -- this is the call that breaks when the version is bumped in one place only."""
+    import __graft_entry__
+    __graft_entry__.build()
+
+
 def test_bad_arguments_are_rejected_before_launch():
     from mcgen_amd import _lib
     lib = _lib.load()
