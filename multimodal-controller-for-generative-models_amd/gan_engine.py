@@ -646,14 +646,20 @@ class DiscriminatorEngine:
         ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None}
         return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
 
+    def pair_codes(self, ind2: Tensor):
+        """The UNSCALED MultimodalController codes of a paired pass ([2N, C] per MC: what the weight gradients multiply their
+        conv inputs with).  They depend on the labels alone, so the d_iters updates of one iteration can share them."""
+        return self._codes.run(ind2)
+
     def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None,
-                     x2: Optional[Nhwc] = None):
+                     x2: Optional[Nhwc] = None, codes=None):
         """D(real) and D(fake) of one discriminator update (train_gan.py:144-150) as ONE pass over the 2N batch.
         The two forwards of the reference differ only in the spectral-norm state (each runs its own power iteration,
         which depends on the weights alone): conv(x; W / sigma_2) = (sigma_1 / sigma_2) * conv(x; W / sigma_1), so the
         fake half runs on the first pass's weight images with sigma_1 / sigma_2 folded into its per-sample
         MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input).
-        `x2` (optional, then real / fake are ignored): the 2N batch real (+) fake already in the engine's layout."""
+        `x2` (optional, then real / fake are ignored): the 2N batch real (+) fake already in the engine's layout.
+        `codes` (optional): `pair_codes(ind2)`, computed once for several updates on the same labels."""
         n = x2.shape[0] // 2 if x2 is not None else real_nchw.shape[0]
         (sigma1, uv1), (sigma2, uv2) = self._power_iters(2, True)
         ratio = sigma1 / sigma2
@@ -672,7 +678,8 @@ class DiscriminatorEngine:
                                              [u[1] for u in uses])
         outs = self._codes_pair.run(ind2, ratio, n)            # all scaled codes of the pass: one launch
         scaled = dict(zip(uses, outs))
-        codes = self._codes.run(ind2)                          # unscaled [2N, C] codes: the weight gradients' conv inputs
+        if codes is None:
+            codes = self._codes.run(ind2)                      # unscaled [2N, C] codes: the weight gradients' conv inputs
         x = x2 if x2 is not None else torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}

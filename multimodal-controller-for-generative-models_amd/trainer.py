@@ -183,7 +183,7 @@ class GANTrainer:
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
-    def d_compute_iter(self, img, ind, fake, ind2=None, x2=None):
+    def d_compute_iter(self, img, ind, fake, ind2=None, x2=None, codes=None):
         """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
         [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once.  `x2` (optional, instead
         of img / fake): real (+) fake as `pair_buffer` / `pair_set_fake` left them."""
@@ -193,7 +193,7 @@ class GANTrainer:
         if _PAIR_D:
             # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
             # power iterations of the two reference forwards depend on the weights alone and run first, in order
-            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2, x2=x2)
+            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2, x2=x2, codes=codes)
             n = ind.shape[0]
             lg = logits.view(-1)
             self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
@@ -205,8 +205,8 @@ class GANTrainer:
         self.deng.backward(ctx_r, dreal, self.grad_d, False, False)
         yield from self.deng.backward_iter(ctx_f, dfake, self.grad_d, True, False, split=self.world > 1)   # final once the second pass added
 
-    def d_compute(self, img, ind, fake, ind2=None, x2=None):
-        for _ in self.d_compute_iter(img, ind, fake, ind2, x2):
+    def d_compute(self, img, ind, fake, ind2=None, x2=None, codes=None):
+        for _ in self.d_compute_iter(img, ind, fake, ind2, x2, codes):
             pass
         return self.loss_d
 
@@ -229,8 +229,8 @@ class GANTrainer:
         self.opt_g.step(self.grad_g)
         self.geng.refresh_images(force=True)
 
-    def d_update(self, img, ind, fake, ind2=None, x2=None):
-        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2, x2):
+    def d_update(self, img, ind, fake, ind2=None, x2=None, codes=None):
+        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2, x2, codes):
             self._reduce_bucket(self.grad_d, lo, hi)
         self._join_comm()
         self.d_apply()
@@ -258,6 +258,7 @@ class GANTrainer:
         ind_rep = ind.repeat(fg, 1) if fg > 1 else ind
         fakes = None
         x2 = self.pair_buffer(img) if _NHWC_PAIR else None
+        codes = self.deng.pair_codes(ind2) if (_NHWC_PAIR and _PAIR_D) else None     # the labels' codes: once for the d_iters updates
         for k in range(self.d_iters):
             if k % fg == 0:
                 z_cat = torch.cat([draw() for _ in range(fg)]) if fg > 1 else draw()
@@ -265,7 +266,7 @@ class GANTrainer:
             j = k % fg
             if _NHWC_PAIR:
                 self.pair_set_fake(x2, fakes, j)
-                d_loss = self.d_update(None, ind, None, ind2, x2=x2)
+                d_loss = self.d_update(None, ind, None, ind2, x2=x2, codes=codes)
             else:
                 d_loss = self.d_update(img, ind, fakes[j * n:(j + 1) * n], ind2)
         for _ in range(self.g_iters):
@@ -327,7 +328,8 @@ class GraphedGANTrainer(GANTrainer):
                 fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
                 if _NHWC_PAIR:
                     self.pair_set_fake(self.s_x2, fakes, 0)
-                    self.d_update(None, self.s_ind, None, self.s_ind2, x2=self.s_x2)
+                    self.d_update(None, self.s_ind, None, self.s_ind2, x2=self.s_x2,
+                                  codes=self.deng.pair_codes(self.s_ind2) if _PAIR_D else None)
                 else:
                     self.s_fake.copy_(fakes[:n])
                     self.d_update(self.s_img, self.s_ind, self.s_fake, self.s_ind2)
@@ -343,6 +345,7 @@ class GraphedGANTrainer(GANTrainer):
             self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
             if _NHWC_PAIR:
                 self.pair_buffer(self.s_img)                                # the iteration's real batch -> first half of s_x2
+                self.s_codes = self.deng.pair_codes(self.s_ind2) if _PAIR_D else None
         pool = self.g_gf.pool()
 
         def capture_buckets(gen):
@@ -356,7 +359,7 @@ class GraphedGANTrainer(GANTrainer):
                     lo, hi, last = next(gen)
                 graphs.append((gk, (lo, hi)))
             return graphs
-        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2) if _NHWC_PAIR else
+        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2, codes=self.s_codes) if _NHWC_PAIR else
                                     self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_zd.normal_()
