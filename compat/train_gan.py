@@ -11,8 +11,12 @@ What differs, and why:
   * `--engine fused` (default) runs the loop body as `GraphedGANTrainer` (fused Adam, HIP-graph replay);
     `--engine autograd` runs the reference's own Python loop on the nn.Module surface with torch.optim.Adam;
   * --world_size > 1 means one process per GPU under torch.distributed.run (RCCL), not nn.DataParallel;
-  * test() generates `generate_per_mode` images per class (train_gan.py:197-207) and reports their statistics;
-    the Inception-based IS / FID of train_gan.py:208-216 need downloaded weights and are not computed.
+  * test() generates `generate_per_mode` images per class (train_gan.py:197-207) and logs the pixel statistics of the
+    generated set under 'test/GeneratedMean', 'test/GeneratedStd' -- a STAND-IN, named as such in its log line: the
+    Inception-based IS / FID of train_gan.py:208-216 need downloaded inception_v3 weights (`metrics.Metric` raises for them
+    on CIFAR-10; on COIL100 / Omniglot it evaluates them through the reference's small classifier);
+  * the checkpoint is the reference's dict INCLUDING `scheduler_dict` (torch MultiStepLR state, train_gan.py:239-240) and the
+    pickled `logger.Logger`, so `--resume_mode 1` of the reference's own driver can read a file written here.
 """
 import argparse
 import os
@@ -26,8 +30,11 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 import models  # noqa: E402  (the compat shim: mcgen_amd's module trees under the reference's names)
+import data as data_shim  # noqa: E402
 from config import cfg  # noqa: E402
-from utils import process_control, save, load  # noqa: E402
+from data import fetch_dataset, make_data_loader  # noqa: E402
+from logger import Logger  # noqa: E402
+from utils import process_control, process_dataset, save, load  # noqa: E402
 
 
 def parse():
@@ -56,6 +63,50 @@ def make_optimizer(model, lr, betas):                        # train_gan.py:222-
     return torch.optim.Adam(model.parameters(), lr=lr, weight_decay=cfg['weight_decay'], betas=betas)
 
 
+def make_scheduler(optimizer):                               # train_gan.py:239-256 ('None' and the epoch-stepped ones)
+    name = cfg.get('scheduler_name', 'None')
+    if name == 'None':
+        return torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[65535])
+    if name == 'StepLR':
+        return torch.optim.lr_scheduler.StepLR(optimizer, step_size=cfg['step_size'], gamma=cfg['factor'])
+    if name == 'MultiStepLR':
+        return torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=cfg['milestones'], gamma=cfg['factor'])
+    if name == 'ExponentialLR':
+        return torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.99)
+    if name == 'CosineAnnealingLR':
+        return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=int(cfg['num_epochs']))
+    raise ValueError('Not valid scheduler name')
+
+
+class FusedSchedule:
+    """A torch LR scheduler for a `FusedAdam` (which is not a torch Optimizer): the scheduler runs on a host-side
+    torch.optim.Adam over one dummy parameter with the same learning rate, and every step pushes the resulting rate
+    into the fused optimizer.  `state_dict()` is therefore exactly torch's scheduler state (what train_gan.py:116-117
+    saves and :270-271 loads)."""
+
+    def __init__(self, fused):
+        self.fused = fused
+        self.host = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=fused.lr)
+        self.sched = make_scheduler(self.host)
+
+    def _push(self):
+        self.fused.set_lr(self.host.param_groups[0]['lr'])
+
+    def step(self, *a, **k):
+        self.sched.step(*a, **k)
+        self._push()
+
+    def state_dict(self):
+        return self.sched.state_dict()
+
+    def load_state_dict(self, sd):
+        self.sched.load_state_dict(sd)
+        last = sd.get('_last_lr')
+        if last:
+            self.host.param_groups[0]['lr'] = last[0]
+        self._push()
+
+
 def train_autograd(loader, model, optimizer, epoch):
     """train_gan.py:128-194 on the module surface."""
     model.train(True)
@@ -80,15 +131,21 @@ def train_autograd(loader, model, optimizer, epoch):
     return last
 
 
-def test(model, per_mode):
-    """train_gan.py:197-207: generate_per_mode images per class in eval mode."""
+def test(model, per_mode, logger, epoch):
+    """train_gan.py:197-220: generate_per_mode images per class in eval mode, evaluate, log.  The metric logged here is
+    a STAND-IN (pixel mean / std of the generated set): see the module docstring."""
     model.train(False)
     with torch.no_grad():
         C = torch.arange(cfg['classes_size'], device=cfg['device']).repeat(per_mode)
         outs = [model.generate(c) for c in C.split(min(500, C.numel()))]
         generated = (torch.cat(outs) + 1) / 2 * 255
     model.train(True)
-    return {'mean': float(generated.mean()), 'std': float(generated.std()), 'n': int(generated.shape[0])}
+    stats = {'GeneratedMean': float(generated.mean()), 'GeneratedStd': float(generated.std())}
+    logger.append(stats, 'test')
+    logger.append({'info': ['Model: {}'.format(cfg['model_tag']), 'Test Epoch: {}({:.0f}%)'.format(epoch, 100.),
+                            '[stand-in metrics: IS / FID need inception_v3 weights]']}, 'test', mean=False)
+    logger.write('test', list(stats))
+    return dict(stats, n=int(generated.shape[0]))
 
 
 def run():
@@ -96,7 +153,6 @@ def run():
     process_control()
     from mcgen_amd import dist as mdist
     from mcgen_amd.checkpoint import make_checkpoint, resume
-    from mcgen_amd.data import DeviceLoader, synthetic_uint8_dataset
     from mcgen_amd.trainer import GraphedGANTrainer
     rank, world, local = mdist.init_from_env() if int(cfg['world_size']) > 1 else (0, 1, 0)
     cfg['device'] = f'cuda:{local}'
@@ -107,9 +163,11 @@ def run():
     cfg['model_tag'] = '_'.join([str(seed), cfg['data_name'], cfg['subset'], cfg['model_name'],
                                  cfg.get('control_name') or cfg['control']['controller_rate']])
     print(f'Experiment: {cfg["model_tag"]}')
-    images, labels = synthetic_uint8_dataset(extra['synthetic_size'], cfg['data_shape'], cfg['classes_size'], seed=seed + rank,
-                                             device=cfg['device'])
-    loader = DeviceLoader(images, labels, cfg['batch_size']['train'], shuffle=cfg['shuffle']['train'], drop_last=True)
+    data_shim._SYNTHETIC['train'] = extra['synthetic_size']
+    dataset = fetch_dataset(cfg['data_name'], cfg['subset'])                   # train_gan.py:71-73
+    process_dataset(dataset['train'])
+    loader = make_data_loader(dataset)['train']
+    loader.drop_last = True
     model = models.mcgan().to(cfg['device'])
     if cfg.get('compute_dtype') == 'bfloat16':
         model.set_compute_dtype(torch.bfloat16)
@@ -124,15 +182,19 @@ def run():
         tr = None
         optimizer = {'generator': make_optimizer(model.generator, 2e-4, (0.5, 0.999)),
                      'discriminator': make_optimizer(model.discriminator, 2e-4, (0.5, 0.999))}
-    last_epoch = 1
-    if int(cfg['resume_mode']) == 1 and os.path.exists(path):                  # train_gan.py:80-84
-        last_epoch, _ = resume(path, model, optimizer)
+    scheduler = {k: (FusedSchedule(o) if tr is not None else make_scheduler(o)) for k, o in optimizer.items()}
+    last_epoch, logger = 1, None
+    if int(cfg['resume_mode']) == 1 and os.path.exists(path):                  # train_gan.py:80-81,258-282
+        last_epoch, logger = resume(path, model, optimizer, scheduler)
         if tr is not None:
             tr.geng.refresh_images(force=True)
         print(f'Resume from {last_epoch}')
+    if logger is None:
+        logger = Logger(os.path.join(extra['output_dir'], 'runs', 'train_{}_{}'.format(cfg['model_tag'], time.strftime('%b%d_%H-%M-%S'))))
     per_mode = extra['generate_per_mode'] or cfg['generate_per_mode']
     for epoch in range(last_epoch, int(cfg['num_epochs']) + 1):
         t0 = time.time()
+        logger.safe(True)
         if tr is not None:
             last = None
             for input in loader:
@@ -143,11 +205,21 @@ def run():
             last = (float(last[0]), float(last[1]))
         else:
             last = train_autograd(loader, model, optimizer, epoch)
-        stats = test(model, per_mode)
+        n_img = len(loader) * loader.batch_size
+        logger.append({'Loss_D': last[0], 'Loss_G': last[1], 'Loss': abs(last[0] - last[1])}, 'train', n=n_img)   # train_gan.py:177-180
+        rate = n_img * world / (time.time() - t0)
+        logger.append({'info': ['Model: {}'.format(cfg['model_tag']), 'Train Epoch: {}(100%)'.format(epoch),
+                                '{:.0f} images/s'.format(rate)]}, 'train', mean=False)
         if rank == 0:
-            print(f'Train Epoch: {epoch}  D_loss {last[0]:.4f}  G_loss {last[1]:.4f}  '
-                  f'{len(loader) * loader.batch_size * world / (time.time() - t0):.0f} images/s  generated {stats}')
-            save(make_checkpoint(model, optimizer, epoch + 1, cfg), path)
+            logger.write('train', ['Loss', 'Loss_D', 'Loss_G'])
+        test(model, per_mode, logger, epoch)
+        for sch in scheduler.values():                                         # train_gan.py:105-106
+            sch.step()
+        logger.safe(False)
+        if rank == 0:
+            save(make_checkpoint(model, optimizer, epoch + 1, cfg, scheduler=scheduler, logger=logger), path)   # train_gan.py:111-119
+        logger.reset()
+    logger.safe(False)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -955,7 +955,12 @@ extern "C" int mcgen_mc_apply(const void* x, const float* code, void* y, int dty
 }
 
 // sensitivity probe (tools/digest_probe.py): MCGEN_BN_PERTURB=1e-7 nudges the batch sums by that relative amount
+// -- tuning builds (-DMCGEN_TUNING) only: the shipped library reads no environment variable
+#ifdef MCGEN_TUNING
 static double bn_perturb() { static const double v = getenv("MCGEN_BN_PERTURB") ? atof(getenv("MCGEN_BN_PERTURB")) : 0.0; return v; }
+#else
+static constexpr double bn_perturb() { return 0.0; }
+#endif
 extern "C" int mcgen_bn_finalize_groups(const float* partials, int tiles, int pitch, int fold, int C, double count, int groups,
                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                                         float momentum, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {

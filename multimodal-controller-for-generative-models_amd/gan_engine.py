@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._tuning import flag as _flag
 from .ops import Seg
 
 Tensor = torch.Tensor
@@ -85,18 +86,18 @@ class _BN:
     __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
 
-_PAIR_WGRAD = __import__('os').environ.get('MCGEN_PAIR_WGRAD', '1') != '0'
+_PAIR_WGRAD = _flag('MCGEN_PAIR_WGRAD', '1') != '0'
 # one-launch multi-round power iteration (mcgen_sn_power_iter_fused): opt-in -- one workgroup per layer streams W through a
 # single CU and measured 0.08 ms / iteration SLOWER than the four row-sliced kernels that fill the chip (tools/ab_bench.sh)
-_SN_FUSED = __import__('os').environ.get('MCGEN_SN_FUSED', '0') == '1'
-_BUCKETS = __import__('os').environ.get('MCGEN_BUCKETS', '1') != '0'        # two gradient buckets per network (callers ask for them only when world > 1)
+_SN_FUSED = _flag('MCGEN_SN_FUSED', '0') == '1'
+_BUCKETS = _flag('MCGEN_BUCKETS', '1') != '0'        # two gradient buckets per network (callers ask for them only when world > 1)
 # mode-compacted forward convolutions (bf16, maps >= 16x16, conv_a launches): opt-in -- measured x1.10 on those launches
 # (tools/bench_mc.py), about 0.5 % of the step after the map / K-major image launches are paid: see DESIGN.md section 4.6
-_MC = __import__('os').environ.get('MCGEN_MC', '0') == '1'
+_MC = _flag('MCGEN_MC', '0') == '1'
 # compacted activations between the launches of the FORWARD-ONLY grouped generator pass (producer-side compacted store +
 # gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
-_GK = __import__('os').environ.get('MCGEN_GK', '1') != '0'
-_LOWRES_SC_BWD = __import__('os').environ.get('MCGEN_LOWRES_SC_BWD', '1') != '0'
+_GK = _flag('MCGEN_GK', '1') != '0'
+_LOWRES_SC_BWD = _flag('MCGEN_LOWRES_SC_BWD', '1') != '0'
 class Nhwc:
     """An image batch in the engines' own layout ([N, H, W, C padded to 8] of the compute dtype, padding channels zero) with
     its true channel count: what the trainer hands from one engine to the other, instead of converting to the module
@@ -112,9 +113,9 @@ class Nhwc:
         return torch.Size((n, self.c, h, w))
 
 
-_SN_SNAP = __import__('os').environ.get('MCGEN_SN_SNAP', '1') != '0'    # the power iteration's kernels write the forward's u/v copy (0: clone afterwards)
+_SN_SNAP = _flag('MCGEN_SN_SNAP', '1') != '0'    # the power iteration's kernels write the forward's u/v copy (0: clone afterwards)
 # FirstDisResBlock: the 1x1 shortcut as a second K segment of conv2's launch (0: its own launch + a residual read)
-_D0_FUSE = __import__('os').environ.get('MCGEN_D0_FUSE', '1') != '0'
+_D0_FUSE = _flag('MCGEN_D0_FUSE', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
 
 
@@ -317,11 +318,14 @@ class GeneratorEngine:
         shapes.append((side, head_conv.out_channels))
         return all(gn % ops.tile_images(n_total, sd, sd, co, self.dtype) == 0 for sd, co in shapes)
 
-    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1, nhwc: bool = False):
+    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1, nhwc: bool = False, one_hot: bool = False):
         """`groups` > 1 (training mode, forward only): z / indicator hold `groups` batches back to back, each normalised
         with its OWN BatchNorm batch statistics -- `groups` successive generator forwards on unchanged weights
         (the five discriminator updates of train_gan.py:139-158) as one pass over groups * N images.
-        `nhwc`: return the images as `Nhwc` (for the discriminator engine) instead of NCHW fp32."""
+        `nhwc`: return the images as `Nhwc` (for the discriminator engine) instead of NCHW fp32.
+        `one_hot`: the caller guarantees `indicator` rows are one-hot (the trainer builds them with F.one_hot); only then
+        may a grouped pass keep its activations compacted -- the compacted pitch is the largest active-channel count of a
+        single codebook row (`_cap`), which a soft or multi-hot indicator could exceed."""
         self.flat_p.ensure()
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype
@@ -344,7 +348,7 @@ class GeneratorEngine:
         codes = self._codes.run(indicator)
         # Forward-only grouped pass: activations between the launches stay COMPACTED -- the producer stores, per image, only
         # the channels the consumer's MultimodalController keeps (ycmap), the consumer gathers the matching weight rows.
-        gk = groups > 1 and self._gk_enabled()
+        gk = groups > 1 and one_hot and self._gk_enabled()
         x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
         caps_h = [self._cap(b.mc_2) if (gk and self._gk_block(i)) else None for i, b in enumerate(res)]
         for i, b in enumerate(res):
@@ -767,8 +771,9 @@ class DiscriminatorEngine:
     def bucket_cut(self) -> int:
         """First residual block of the LATE gradient bucket: the backward pass finishes blocks cut .. last and the tail
         first, so gflat[offset(block cut) :] is final while blocks cut-1 .. 0 are still running -- a data-parallel run
-        starts that bucket's all-reduce there (GANTrainer), under the rest of the backward."""
-        return max(1, len(self.res) // 2)
+        starts that bucket's all-reduce there (GANTrainer), under the rest of the backward.
+        (0: a discriminator with a single residual block has nothing to split -- one bucket, as the generator's rule.)"""
+        return max(1, len(self.res) // 2) if len(self.res) > 1 else 0
 
     def _bucket_tables(self):
         """Spectral-norm fix-up tables of the two buckets: SN layers with index >= the cut block's first layer + the plain
@@ -787,7 +792,7 @@ class DiscriminatorEngine:
                 rows = [(self.flat_p.offset_of(sn.m.weight_orig), self.flat_uv.offset_of(sn.m.weight_u),
                          self.flat_uv.offset_of(sn.m.weight_v), sn.m.weight_orig.shape[0], sn.m.weight_orig[0].numel()) for sn in sns]
                 rows += [(self.flat_p.offset_of(p), 0, 0, 0, p.numel()) for p in plains]
-                return ops.sn_layers_tensor(rows, fp.device), len(rows)
+                return (ops.sn_layers_tensor(rows, fp.device) if rows else None), len(rows)
             hi = table(sn_hi, [p for p in self.plain if self.flat_p.offset_of(p) >= off_cut])
             lo = table([sn for sn in self.sn if sn.idx < i_cut], [p for p in self.plain if self.flat_p.offset_of(p) < off_cut])
             self._bk = {'off_cut': off_cut, 'i_cut': i_cut, 'hi': hi, 'lo': lo}
@@ -848,6 +853,7 @@ class DiscriminatorEngine:
 
         bk = self._bucket_tables() if want_w else None
         cut = self.bucket_cut()
+        split = split and cut > 0                      # (a single residual block: one bucket)
         self._ensure_preps()
         self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
         I = self.img

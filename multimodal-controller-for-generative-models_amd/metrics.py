@@ -49,3 +49,44 @@ def fid_from_features(real: torch.Tensor, generated: torch.Tensor) -> float:
     tr_covmean = torch.linalg.eigvalsh((m + m.t()) * 0.5).clamp_min(0).sqrt().sum()
     diff = mu1 - mu2
     return float(diff @ diff + torch.trace(s1) + torch.trace(s2) - 2 * tr_covmean)
+
+
+# ---- the callers' entry points (metrics.py:44-81 InceptionScore, :84-161 FID) --------------------------------------
+_NO_INCEPTION = ('{} on {} needs torchvision\'s pre-trained inception_v3 (metrics.py:64,116), whose weights cannot be '
+                 'downloaded here; pass features to inception_score_from_probs / fid_from_features instead')
+
+
+def feature_network(data_name: str, checkpoint: str | None = None, device=None):
+    """The feature network the reference evaluates `data_name` with: its own `models.classifier()` for COIL100 /
+    Omniglot (metrics.py:49-53,89-94; weights from `checkpoint`, a reference-format `*_best.pt`), on the fused
+    convolution path.  Other datasets use inception_v3: ValueError."""
+    if data_name not in ('COIL100', 'Omniglot'):
+        raise ValueError(_NO_INCEPTION.format('IS / FID', data_name))
+    from .models.classifier import classifier
+    from .checkpoint import load
+    model = classifier()
+    if checkpoint is not None:
+        model.load_state_dict(load(checkpoint)['model_dict'])
+    if device is not None:
+        model = model.to(device)
+    model.train(False)
+    return model
+
+
+def inception_score(img: torch.Tensor, data_name: str, splits: int = 1, model=None, batch_size: int = 512) -> float:
+    """metrics.py:44-81 with the class probabilities kept on the device: img [N, C, H, W] in (-1, 1)."""
+    model = model if model is not None else feature_network(data_name, device=img.device)
+    with torch.no_grad():
+        pred = torch.cat([torch.softmax(model({'img': x, 'label': x.new_zeros(x.shape[0]).long()})['label'].float(), -1)
+                          for x in img.split(batch_size)])
+    return inception_score_from_probs(pred, splits)
+
+
+def fid(img: torch.Tensor, data_name: str, real: torch.Tensor | None = None, model=None, batch_size: int = 512) -> float:
+    """metrics.py:84-161: features of `real` (the training images, [N, C, H, W] in (-1, 1)) against those of `img`."""
+    if real is None:
+        raise ValueError('Not valid input: fid needs the real images (the reference re-reads its training set, metrics.py:88)')
+    model = model if model is not None else feature_network(data_name, device=img.device)
+    with torch.no_grad():
+        f = lambda t: torch.cat([model.feature({'img': x}).float() for x in t.split(batch_size)])      # noqa: E731
+        return fid_from_features(f(real), f(img))

@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import check
+from ._tuning import flag as _flag
 
 Tensor = torch.Tensor
 
@@ -50,20 +51,23 @@ def _f32(t: Optional[Tensor]) -> Optional[int]:
 
 # ---- per-launch profiling (bench.py roofline): HIP events on the launch stream -------------------------
 _PROF = None
+_PROF_SHAPES = _flag('MCGEN_PROF_SHAPES', '') != ''      # per-shape kernel names in the profile (tools/shape_table.py)
 TILE_LOG = None        # tests set this to a list: every conv_fused launch appends the (BM, BN) tile the policy picked
 FORM_LOG = None        # tests set this to a list: every conv_fused launch appends its weight layout (0 dense, 1 mc, 2 gk)
 
 
-def _timed(name_fn, flops: float, launch, nbytes_fn=None):
+def _timed(name_fn, flops: float, launch, nbytes_fn=None, extra_fn=None):
     """Run `launch()`; when profiling is on, bracket it with events on the current stream.  `nbytes_fn()` = the
-    launch's algorithmic HBM bytes (operands read once + results written once)."""
+    launch's ALGORITHMIC HBM bytes (operands read once + results written once); `extra_fn()` = bytes the implementation
+    moves on top of that (the split-K slabs of a weight-gradient launch), reported apart."""
     if _PROF is None:
         return launch()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = launch()
     e.record()
-    _PROF.append((name_fn(), flops, s, e, float(nbytes_fn()) if nbytes_fn is not None else 0.0))
+    _PROF.append((name_fn(), flops, s, e, float(nbytes_fn()) if nbytes_fn is not None else 0.0,
+                  float(extra_fn()) if extra_fn is not None else 0.0))
     return r
 
 
@@ -74,20 +78,26 @@ def _nbytes(*ts) -> int:
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
-def profile_step(fn, peak_tflops: float):
-    """Run `fn` once untimed and once with every conv/wgrad launch bracketed by HIP events; returns
-    the `roofline` object for the kernel instantiation with the largest total time: algorithmic
-    FLOPs of its launches / sum of their measured durations."""
+def profile_step(fn, peak_tflops: float, iters: int = 5):
+    """Run `fn` once untimed, then `iters` times with every conv / wgrad / slab-reduce launch bracketed by HIP events on
+    the launch stream; returns the `roofline` object for the kernel instantiation with the largest total time:
+    algorithmic FLOPs of its launches / sum of their measured durations, averaged over all `iters` passes, with the
+    per-pass fractions' min / median beside it (`fn(i)` is called with the pass index if it takes an argument)."""
     global _PROF
-    fn()
+    import inspect
+    takes_i = len(inspect.signature(fn).parameters) >= 1
+    call = (lambda i: fn(i)) if takes_i else (lambda i: fn())
+    call(-1)
     torch.cuda.synchronize()
-    _PROF = []
-    try:
-        fn()
-        torch.cuda.synchronize()
-        rec = _PROF
-    finally:
-        _PROF = None
+    recs = []
+    for i in range(max(1, iters)):
+        _PROF = []
+        try:
+            call(i)
+            torch.cuda.synchronize()
+            recs.append(_PROF)
+        finally:
+            _PROF = None
     # An event pair with nothing between its records already reads ~4.8 us on this stack (the second event's own
     # completion); measured live and taken off every bracket, otherwise short launches look 10-15 % slower than rocprofv3's
     # kernel durations (checked: 55.2 -> 50.4 us against 48.2 us for the 128x128 tile, 163.3 -> 158.5 against 159.3).
@@ -97,29 +107,45 @@ def profile_step(fn, peak_tflops: float):
         s.record(); e.record(); pairs.append((s, e))
     torch.cuda.synchronize()
     over_ms = sorted(s.elapsed_time(e) for s, e in pairs)[len(pairs) // 2]
+
+    def aggregate(rec):
+        agg = {}
+        for name, flops, s, e, nbytes, extra in rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+            raw = s.elapsed_time(e)
+            a[0] += 1; a[1] += max(raw - over_ms, 0.1 * raw) * 1e-3; a[2] += flops; a[3] += raw * 1e-3; a[4] += nbytes; a[5] += extra
+        return agg
+    per_pass = [aggregate(r) for r in recs]
     agg = {}
-    for name, flops, s, e, nbytes in rec:
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
-        raw = s.elapsed_time(e)
-        a[0] += 1; a[1] += max(raw - over_ms, 0.1 * raw) * 1e-3; a[2] += flops; a[3] += raw * 1e-3; a[4] += nbytes
+    for pa in per_pass:
+        for k, v in pa.items():
+            a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+            for j in range(6):
+                a[j] += v[j]
     if not agg:
         return None
+    np_ = len(per_pass)
     top = max(agg, key=lambda k: agg[k][1])
-    cnt, secs, flops, raw_secs, nbytes = agg[top]
+    cnt, secs, flops, raw_secs, nbytes, extra = agg[top]
     ach = flops / secs / 1e12
     # which roof bounds the kernel: its algorithmic intensity against the machine balance (MFMA peak / HBM peak)
     intensity = flops / nbytes if nbytes > 0 else float('inf')
     balance = peak_tflops * 1e12 / HBM_PEAK_BYTES_PER_S
-    out = {'bound': 'mfma' if intensity >= balance else 'hbm', 'kernel': top, 'achieved': ach, 'peak': peak_tflops,
-           'unit': 'TFLOP/s', 'frac': ach / peak_tflops, 'traffic': None, 'launches_per_step': cnt,
+    hbm = intensity < balance
+    # the same figure per pass: how reproducible one eager iteration's reading is
+    fr = sorted(((pa[top][4] / pa[top][1] / HBM_PEAK_BYTES_PER_S) if hbm else (pa[top][2] / pa[top][1] / 1e12 / peak_tflops))
+                for pa in per_pass if top in pa and pa[top][1] > 0)
+    out = {'bound': 'hbm' if hbm else 'mfma', 'kernel': top, 'achieved': ach, 'peak': peak_tflops,
+           'unit': 'TFLOP/s', 'frac': ach / peak_tflops, 'traffic': None, 'launches_per_step': cnt / np_,
+           'passes': np_, 'frac_min': fr[0], 'frac_median': fr[len(fr) // 2], 'frac_max': fr[-1],
            'avg_launch_us': secs / cnt * 1e6, 'avg_launch_us_uncorrected': raw_secs / cnt * 1e6,
            'event_pair_overhead_us': over_ms * 1e3, 'flops_per_launch': flops / cnt,
-           'algorithmic_bytes_per_launch': nbytes / cnt, 'intensity_flop_per_byte': intensity,
-           'machine_balance_flop_per_byte': balance,
-           'by_kernel': {k: {'launches': v[0], 'total_ms': v[1] * 1e3, 'tflops': v[2] / v[1] / 1e12,
-                             'gbytes_per_s': v[4] / v[1] / 1e9}
+           'algorithmic_bytes_per_launch': nbytes / cnt, 'split_k_bytes_per_launch': extra / cnt,
+           'intensity_flop_per_byte': intensity, 'machine_balance_flop_per_byte': balance,
+           'by_kernel': {k: {'launches': v[0] / np_, 'total_ms': v[1] * 1e3 / np_, 'tflops': v[2] / v[1] / 1e12,
+                             'gbytes_per_s': v[4] / v[1] / 1e9, **({'split_k_gbytes_per_s': v[5] / v[1] / 1e9} if v[5] else {})}
                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
-    if out['bound'] == 'hbm':                      # an HBM-bound dominant kernel is priced in bytes
+    if hbm:                                        # an HBM-bound dominant kernel is priced in bytes
         out.update(achieved=nbytes / secs / 1e9, peak=HBM_PEAK_BYTES_PER_S / 1e9, unit='GB/s',
                    frac=nbytes / secs / HBM_PEAK_BYTES_PER_S)
     return out
@@ -352,7 +378,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         bm, bn = C.c_int(), C.c_int()
         lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
         base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{(",mc", ",gk")[kmajor - 1] if kmajor else ""}>'
-        if _os.environ.get('MCGEN_PROF_SHAPES'):
+        if _PROF_SHAPES:
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')
         return base
@@ -425,10 +451,12 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
             bias_slabs = torch.empty((splits * 4, pad16(cout)), dtype=torch.float32, device=dy.device)
         p.bias_slabs = _p(bias_slabs)
         _timed(lambda: f'wgrad<{"bf16" if dtype == torch.bfloat16 else "f32"},{seg.ksize}>' + (
-            f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _os.environ.get('MCGEN_PROF_SHAPES') else ''),
+            f' N{n} {h}x{w} {seg.x.shape[-1]}->{cout} s{splits}' if _PROF_SHAPES else ''),
                2.0 * n * h * w * cout * seg.x.shape[-1] * seg.ksize ** 2,
                lambda: check(lib.mcgen_wgrad(C.byref(p), _dt(dtype), _stream()), 'wgrad'),
-               lambda: _nbytes(seg.x, dy, slabs))
+               # algorithmic bytes: x + dy read once, dW (+ db) written once; the split-K slabs are the implementation's
+               lambda: _nbytes(seg.x, dy) + 4 * (cout * cin * seg.ksize ** 2 + (cout if bias_grad is not None else 0)) * (2 if second is not None else 1),
+               lambda: _nbytes(slabs, bias_slabs))
     if grad.numel() != cout * cin * seg.ksize * seg.ksize:
         raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     if second is None:
@@ -444,13 +472,15 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
             _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha),
                               row_scale, seg.x.shape[-1]))
         else:
-            check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
-                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _f32(row_scale),
-                                         seg.x.shape[-1], _stream()), 'wgrad_reduce')
+            _timed(lambda: 'wgrad_reduce', 0.0,
+                   lambda: check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
+                                                        float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _f32(row_scale),
+                                                        seg.x.shape[-1], _stream()), 'wgrad_reduce'),
+                   lambda: _nbytes(gr), lambda: _nbytes(sl, bs))
 
 
 _deferred = None
-_SIDE = _os.environ.get('MCGEN_SIDE_STREAM', '0') == '1'     # measured slower on MI355X (16.7 vs 15.7 ms/step): opt-in only
+_SIDE = _flag('MCGEN_SIDE_STREAM', '0') == '1'     # measured slower on MI355X (16.7 vs 15.7 ms/step): opt-in only
 _side_streams = {}
 _side_keep = []
 
@@ -470,11 +500,11 @@ class _nullctx:
         return False
 
 
-_WG_GROUP_MIN = 1 << 30 if _os.environ.get('MCGEN_WGRAD_GROUP', '1') == '0' else 4      # chunks from which a 1x1 gradient runs as chunk groups
-_WG_MAX_SPLITS = int(_os.environ.get('MCGEN_WGRAD_MAX_SPLITS', '128'))   # (64 left the thin image layers -- 2 blocks -- on half the chip)
-_WG_TARGET = int(_os.environ.get('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
-_WG_TARGET_SMALL = int(_os.environ.get('MCGEN_WGRAD_TARGET_SMALL', '256'))
-_WG_BIG_TILES = int(_os.environ.get('MCGEN_WGRAD_BIG_TILES', '256'))
+_WG_GROUP_MIN = 1 << 30 if _flag('MCGEN_WGRAD_GROUP', '1') == '0' else 4      # chunks from which a 1x1 gradient runs as chunk groups
+_WG_MAX_SPLITS = int(_flag('MCGEN_WGRAD_MAX_SPLITS', '128'))   # (64 left the thin image layers -- 2 blocks -- on half the chip)
+_WG_TARGET = int(_flag('MCGEN_WGRAD_TARGET', '256'))   # workgroups a weight-gradient launch aims for
+_WG_TARGET_SMALL = int(_flag('MCGEN_WGRAD_TARGET_SMALL', '256'))
+_WG_BIG_TILES = int(_flag('MCGEN_WGRAD_BIG_TILES', '256'))
 
 
 class deferred_reduces:
@@ -503,7 +533,9 @@ class deferred_reduces:
                 a.splits, a.Cout, a.Cin, a.ksize, a.Cout_w = splits, cout, cin, ks, cout_w
                 a.row_perm, a.accumulate, a.alpha = row_perm, acc, alpha
                 a.row_scale, a.cin_slab = _f32(rscale), cin_slab
-            check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch')
+            _timed(lambda: 'wgrad_reduce', 0.0,
+                   lambda: check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch'),
+                   lambda: sum(_nbytes(j[1]) for j in jobs), lambda: sum(_nbytes(j[0], j[2]) for j in jobs))
         return False
 
 

@@ -28,10 +28,10 @@ from .gan_engine import FlatState, Nhwc, _bump
 # making HIP calls while this thread captures; only this thread's illegal calls abort the capture.
 _CAPTURE_MODE = 'thread_local'
 
-import os as _os
-_NHWC_PAIR = _os.environ.get('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images stay NHWC (0: through NCHW fp32, as round 1)
-_PAIR_D = _os.environ.get('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
-_GROUP_G = _os.environ.get('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
+from ._tuning import flag as _flag
+_NHWC_PAIR = _flag('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images stay NHWC (0: through NCHW fp32, as round 1)
+_PAIR_D = _flag('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
+_GROUP_G = _flag('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
 
 
 class FusedAdam:
@@ -44,6 +44,14 @@ class FusedAdam:
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+
+    def hyper(self):
+        """The hyper-parameters a launch bakes in as kernel arguments (a captured HIP graph replays the values it was
+        captured with: the graphed trainers compare this key on every iteration and re-capture when it moved)."""
+        return (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps), float(self.wd))
+
+    def set_lr(self, lr: float):
+        self.lr = float(lr)
 
     def step(self, gflat: torch.Tensor):
         flat = self.fs.ensure()
@@ -159,7 +167,7 @@ class GANTrainer:
     def g_fakes(self, ind_rep, z_cat, groups: int, nhwc: bool = False):
         """Training-mode generator forward(s) for `groups` discriminator updates: [groups * N, C, H, W], detached
         (`nhwc`: as the engines' own `Nhwc`, for `pair_buffer`)."""
-        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups, nhwc=nhwc)
+        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups, nhwc=nhwc, one_hot=True)   # ind_rep comes from F.one_hot
         return fake
 
     # The real batch is the same for the d_iters updates of an iteration and the generated batches come out of the generator
@@ -306,6 +314,33 @@ class GraphedGANTrainer(GANTrainer):
         self.geng.refresh_images(force=True)
         self.geng.warm_caps()                       # (load_state_dict bumped the codebooks' versions)
 
+    # ---- device-side snapshot: every tensor a train iteration writes, restored by a handful of flat copies ----------
+    # (bench.py re-loads the initial training state every few iterations so that the discriminator never saturates on
+    # the synthetic data: a saturated hinge loss makes every discriminator backward pass multiply all-zero gradients.)
+    def _state_tensors(self):
+        ts = [self.geng.flat_p.ensure(), self.opt_g.m, self.opt_g.v, self.opt_g.step_count,
+              self.opt_d.m, self.opt_d.v, self.opt_d.step_count]
+        ts += list(self.deng._ensure_flat())
+        ts += [b for b in self.model.generator.buffers() if b.dtype != torch.int64 or b.dim() == 0]
+        seen, out = set(), []
+        for t in ts:                                  # (codebooks are buffers too: constant, copied all the same; aliases once)
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                out.append(t)
+        return out
+
+    def device_snapshot(self):
+        live = self._state_tensors()
+        return live, [t.detach().clone() for t in live]
+
+    def device_restore(self, snap):
+        live, saved = snap
+        with torch.no_grad():
+            torch._foreach_copy_(live, saved)
+        for t in live:
+            _bump(t)
+        self.geng.refresh_images(force=True)          # G's weight images follow its parameters (D's are rebuilt per pass)
+
     def capture(self, img: torch.Tensor, label: torch.Tensor, warmup: int = 1):
         n = img.shape[0]
         dev = img.device
@@ -371,6 +406,7 @@ class GraphedGANTrainer(GANTrainer):
         with torch.cuda.graph(self.g_ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.g_apply()
         self._graphs = True
+        self._hyper_key = (self.opt_g.hyper(), self.opt_d.hyper())
 
     def eager_iteration(self, img, label):
         return GANTrainer.train_iteration(self, img, label)
@@ -379,6 +415,10 @@ class GraphedGANTrainer(GANTrainer):
         """Replays the captured step; `zs` (d_iters + g_iters latent batches) replaces the in-graph latent draws."""
         if self._graphs is None:
             return super().train_iteration(img, label, zs)
+        if self._hyper_key != (self.opt_g.hyper(), self.opt_d.hyper()):
+            # lr / betas / eps changed since the capture (a scheduler step, a resumed optimizer state): the apply graphs
+            # hold the old values as kernel arguments -- capture again (state is snapshotted and restored around it)
+            self.capture(img, label)
         self.s_img.copy_(img, non_blocking=True)
         oh = F.one_hot(label, self.classes).float()
         n, fg = oh.shape[0], self._fg
@@ -490,9 +530,13 @@ class _FlatTrainer:
             with torch.cuda.graph(self.g_a, pool=self.g_c.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._apply()
         self._graphs = True
+        self._hyper_key = self.opt.hyper()
 
     def _replay(self, *inputs, rand=None):
         """`inputs` fill the leading statics; `rand` (optional) replaces the in-graph redraw of the last one."""
+        if self._hyper_key != self.opt.hyper():
+            raise RuntimeError('optimizer hyper-parameters changed after capture(): the captured Adam launch holds the old '
+                               'values -- call capture() again')
         for s, v in zip(self.statics, inputs):
             s.copy_(v, non_blocking=True)
         if self._has_refresh:

@@ -119,6 +119,135 @@ print('SHIMS-OK')
     assert r.returncode == 0 and 'SHIMS-OK' in r.stdout, r.stderr[-3000:]
 
 
+def test_logger_data_metrics_shims_and_the_reference_import_block():
+    """train_gan.py:3,10-14 in full -- models / config / data / metrics / utils / logger -- binds against compat/;
+    `Logger` keeps the reference's bookkeeping (logger.py:34-50: sample-weighted running means per '<tag>/<name>',
+    history on safe(False)), `Metric.evaluate` its name -> function table (metrics.py:178-195), and the loaders the
+    collated-batch protocol of train_gan.py:134-137."""
+    code = r'''
+import sys, os, pickle
+sys.path.insert(0, os.path.join(ROOT, 'compat'))
+import torch
+import models
+from config import cfg
+from data import fetch_dataset, make_data_loader
+from metrics import Metric
+from utils import save, load, to_device, process_control, process_dataset, collate, save_img
+from logger import Logger
+cfg.update(data_name='CIFAR10', model_name='mcgan', device='cpu'); cfg.pop('classes_size', None)
+process_control()
+ds = fetch_dataset(cfg['data_name'], cfg['subset'], verbose=False)
+process_dataset(ds['train'])
+assert cfg['classes_size'] == 10 and ds['train'].synthetic
+cfg['batch_size'] = {'train': 64, 'test': 32}
+dl = make_data_loader(ds)
+b = next(iter(dl['train']))
+assert b['img'].shape == (64, 3, 32, 32) and b['img'].dtype == torch.float32 and b['label'].dtype == torch.int64
+assert float(b['img'].min()) >= -1 and float(b['img'].max()) <= 1 and len(dl['test']) == 512 // 32
+lg = Logger('/nonexistent/runs/x')
+lg.safe(True)
+lg.append({'Loss': 1.0, 'Pair': [1.0, 3.0]}, 'train', n=10)
+lg.append({'Loss': 4.0, 'Pair': [3.0, 5.0]}, 'train', n=30)
+assert abs(lg.mean['train/Loss'] - 3.25) < 1e-12 and lg.counter['train/Loss'] == 40 and lg.tracker['train/Loss'] == 4.0
+assert [round(v, 12) for v in lg.mean['train/Pair']] == [2.5, 4.5]
+lg.append({'info': ['Model: m', 'Train Epoch: 1(100%)']}, 'train', mean=False)
+lg.write('train', ['Loss', 'Pair'])
+lg.safe(False)
+assert lg.history['train/Loss'] == [3.25] and lg.writer is None
+lg2 = pickle.loads(pickle.dumps(lg, protocol=2))
+assert type(lg2).__module__ == 'logger' and lg2.history['train/Loss'] == [3.25] and lg2.mean['train/Loss'] == 3.25
+lg2.reset()
+assert lg2.mean['train/Loss'] == 0 and lg2.history['train/Loss'] == [3.25]
+out = {'loss': torch.tensor(2.0), 'loss_G': torch.tensor(0.5), 'loss_D': torch.tensor(1.5), 'label': torch.tensor([[0.1, 0.9], [0.8, 0.2]])}
+ev = Metric().evaluate(['Loss', 'Loss_G', 'Loss_D', 'Accuracy'], {'label': torch.tensor([1, 1])}, out)
+assert ev == {'Loss': 2.0, 'Loss_G': 0.5, 'Loss_D': 1.5, 'Accuracy': 50.0}, ev
+try:
+    Metric().evaluate(['InceptionScore'], None, {'img': torch.zeros(4, 3, 32, 32)})
+    raise SystemExit('IS on CIFAR-10 must say that inception_v3 is unavailable')
+except ValueError as e:
+    assert 'inception_v3' in str(e)
+print('SHIMS2-OK')
+'''.replace('ROOT', repr(ROOT))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'SHIMS2-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_reference_checkpoint_with_pickled_logger_resumes(tmp_path):
+    """A reference `*_checkpoint.pt` pickles a `logger.Logger` INSTANCE and the scheduler states (train_gan.py:112-118).
+    (1) A file whose logger was pickled by a class laid out like the reference's own (module `logger`, plain attribute
+    dict, no __getstate__) loads through checkpoint.load once compat/ is importable, and resumes with
+    train_gan.py:264-275's steps: optimizer AND scheduler state, then logger.safe(True).
+    (2) The file the driver counterpart's code path writes (make_checkpoint with FusedSchedule-style scheduler states
+    and a compat Logger) goes through the same steps."""
+    m, _ = _small_model()
+    opt = {'generator': torch.optim.Adam(m.generator.parameters(), lr=2e-4, betas=(0.5, 0.999)),
+           'discriminator': torch.optim.Adam(m.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999))}
+    sch = {k: torch.optim.lr_scheduler.MultiStepLR(o, milestones=[65535]) for k, o in opt.items()}
+    for o in opt.values():
+        o.step()
+    for s in sch.values():
+        s.step()
+    from mcgen_amd import checkpoint as ck
+    base = ck.make_checkpoint(m, opt, 3, None, scheduler=sch, logger=None)
+    base['cfg'] = {'model_name': 'mcgan'}
+    torch.save(base, str(tmp_path / 'base.pt'), pickle_protocol=2)
+    ref_dir = tmp_path / 'refsrc'
+    ref_dir.mkdir()
+    # a stand-in laid out like the reference's class (NOT its source): same module / class name, same attribute names
+    (ref_dir / 'logger.py').write_text(
+        'from collections import defaultdict\n'
+        'class Logger:\n'
+        '    def __init__(self, p):\n'
+        '        self.log_path = p; self.writer = None\n'
+        '        self.tracker = defaultdict(int); self.counter = defaultdict(int); self.mean = defaultdict(int)\n'
+        '        self.history = defaultdict(list); self.iterator = defaultdict(int)\n')
+    write = ('import sys, torch; sys.path.insert(0, %r)\n'
+             'from logger import Logger\n'
+             'lg = Logger("output/runs/train_x"); lg.mean["test/InceptionScore"] = 7.5; lg.history["test/InceptionScore"].append(7.25)\n'
+             'lg.iterator["test/InceptionScore"] = 2\n'
+             'd = torch.load(%r, weights_only=False); d["logger"] = lg\n'
+             'torch.save(d, %r, pickle_protocol=2)\n') % (str(ref_dir), str(tmp_path / 'base.pt'), str(tmp_path / 'ref_checkpoint.pt'))
+    r = subprocess.run([sys.executable, '-c', write], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    read = r'''
+import sys, os
+sys.path.insert(0, os.path.join(ROOT, 'compat')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+import test_checkpoint_compat as T
+from mcgen_amd import checkpoint as ck
+from logger import Logger
+from train_gan import FusedSchedule, make_scheduler
+from config import cfg
+m, _ = T._small_model()
+opt = {'generator': torch.optim.Adam(m.generator.parameters()), 'discriminator': torch.optim.Adam(m.discriminator.parameters())}
+cfg['scheduler_name'] = 'None'
+sch = {k: make_scheduler(o) for k, o in opt.items()}
+raw = ck.load(PATH)
+assert type(raw['logger']) is Logger and set(raw['scheduler_dict']) == {'generator', 'discriminator'}
+epoch, lg = ck.resume(PATH, m, opt, sch)                      # train_gan.py:264-273
+assert epoch == 3 and lg.mean['test/InceptionScore'] == 7.5 and lg.history['test/InceptionScore'] == [7.25]
+assert sch['generator'].last_epoch == 1 and opt['generator'].param_groups[0]['lr'] == 2e-4
+lg.safe(True); lg.append({'InceptionScore': 8.0}, 'test'); lg.safe(False)          # train_gan.py:99-107 on the resumed object
+assert lg.history['test/InceptionScore'][-1] == 8.0 and lg.iterator['test/InceptionScore'] == 2
+# (2) what the driver counterpart writes: scheduler_dict and logger are never None, and load back the same way
+class _F:                                                     # the part of FusedAdam a FusedSchedule touches
+    lr = 2e-4
+    def set_lr(self, v): self.lr = v
+fs = {k: FusedSchedule(_F()) for k in opt}
+for s in fs.values(): s.step()
+out = ck.make_checkpoint(m, opt, 4, dict(cfg), scheduler=fs, logger=lg)
+ck.save(out, PATH + '.driver')
+raw2 = ck.load(PATH + '.driver')
+assert raw2['scheduler_dict']['generator']['last_epoch'] == 1 and type(raw2['logger']) is Logger
+sch2 = {k: make_scheduler(o) for k, o in opt.items()}
+e2, lg2 = ck.resume(PATH + '.driver', m, opt, sch2)
+assert e2 == 4 and sch2['discriminator'].last_epoch == 1 and lg2.history['test/InceptionScore'][-1] == 8.0
+print('RESUME-OK')
+'''.replace('ROOT', repr(ROOT)).replace('PATH', repr(str(tmp_path / 'ref_checkpoint.pt')))
+    r = subprocess.run([sys.executable, '-c', read], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'RESUME-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_device_loader_matches_totensor_normalize():
     """mcgen_amd.data: uint8 NHWC -> (x/255 - 0.5)/0.5 NCHW fp32 (data.py:31-33), every sample exactly once per epoch."""
     from mcgen_amd.data import DeviceLoader, normalize_uint8, synthetic_uint8_dataset

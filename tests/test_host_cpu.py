@@ -4,6 +4,8 @@ and the product path refuses CPU tensors instead of falling back."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -237,3 +239,39 @@ def test_library_loader_imports_torch_first():
             "L.load(); assert 'torch' in sys.modules; print('ok')" % ROOT)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_shipped_library_reads_no_environment():
+    """DESIGN 4.1 'no environment-dependent dispatch': every getenv() in csrc/ sits in the first branch of an
+    `#ifdef MCGEN_TUNING` (tuning builds only); the shipped build never compiles one."""
+    csrc = os.path.join(ROOT, 'multimodal-controller-for-generative-models_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(('.hip', '.h')):
+            continue
+        stack = []                                   # per open #if: True while inside `#ifdef MCGEN_TUNING`'s first branch
+        for ln, line in enumerate(open(os.path.join(csrc, f)), 1):
+            t = line.strip()
+            if t.startswith(('#ifdef', '#ifndef', '#if ')):
+                stack.append(t.split()[:2] == ['#ifdef', 'MCGEN_TUNING'])
+            elif t.startswith(('#else', '#elif')) and stack:
+                stack[-1] = False
+            elif t.startswith('#endif') and stack:
+                stack.pop()
+            elif 'getenv' in t and not t.startswith('//'):
+                assert any(stack), f'{f}:{ln}: getenv outside #ifdef MCGEN_TUNING: {t}'
+
+
+def test_tuning_switches_need_opt_in():
+    """The Python-side MCGEN_* A/B switches are honoured only under MCGEN_TUNING=1 (mcgen_amd/_tuning.py): a variable left
+    in the driver's environment cannot change what bench.py times, and an honoured one shows up in `tuning_switches`."""
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from mcgen_amd import gan_engine as GE, trainer as T, ops, _tuning\n'
+            'print(GE._GK, T._PAIR_D, ops._WG_MAX_SPLITS, sorted(_tuning.ACTIVE.items()))\n') % ROOT
+    env = dict(os.environ, MCGEN_GK='0', MCGEN_PAIR_D='0', MCGEN_WGRAD_MAX_SPLITS='7')
+    env.pop('MCGEN_TUNING', None)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split('\n')[-2] == 'True True 128 []', r.stdout
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(env, MCGEN_TUNING='1'), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split('\n')[-2] == "False False 7 [('MCGEN_GK', '0'), ('MCGEN_PAIR_D', '0'), ('MCGEN_WGRAD_MAX_SPLITS', '7')]", r.stdout
