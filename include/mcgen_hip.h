@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap (4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -147,6 +147,16 @@ typedef struct {
 
 int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p);          /* floats per split */
 int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
+/* The weight gradients of up to MCGEN_WGRAD_MULTI_MAX 3x3 layers of ONE backward pass in one launch (wgrad_multi.hip:
+ * 128 co x 64 ci x 9 tap workgroup tiles, one accumulator set per workgroup): same operands, slab layout and `splits` /
+ * `halves` meaning as mcgen_wgrad per layer, so mcgen_wgrad_reduce(_batch) finishes either.  The caller gives each layer
+ * `splits` in proportion to its share of the pass's FLOPs (every workgroup then walks about the same number of 128-pixel
+ * steps).  Replaces, per backward pass, the autograd weight gradients of the block convolutions of mcgan.py:19,23,77,80,
+ * 103-113.  Eligible (mcgen_wgrad_multi_ok != 0): bf16, ksize 3, square maps of side 8 / 16 / 32, Cout a multiple of 128,
+ * seg.C a multiple of 64, N*H*W a multiple of 128, no statistics groups / compaction map. */
+#define MCGEN_WGRAD_MULTI_MAX 8
+int mcgen_wgrad_multi_ok(const mcgen_wgrad_t* p, int dtype);
+int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, void* stream);
 /* grad[master layout] (+)= alpha * sum_s slabs[s]; master layout = [Cout][Cin][k][k] with
  * row co stored at (co % rows_inner) * row_perm + co / rows_inner when row_perm > 1
  * (the generator's Linear(128 -> C*4*4) viewed as NHWC, mcgan.py:51,67).

@@ -36,6 +36,9 @@ class Wgrad(C.Structure):
                 ('bias_slabs', C.c_void_p)]
 
 
+WGRAD_MULTI_MAX = 8        # MCGEN_WGRAD_MULTI_MAX (include/mcgen_hip.h)
+
+
 class WReduce(C.Structure):
     _fields_ = [('slabs', C.c_void_p), ('grad', C.c_void_p), ('bias_slabs', C.c_void_p), ('bias_grad', C.c_void_p),
                 ('bias_grad2', C.c_void_p),
@@ -77,6 +80,8 @@ SYMBOLS = {
     'mcgen_conv_fused': (_i, [C.POINTER(Conv), _i, _vp]),
     'mcgen_wgrad_slab_elems': (_i64, [C.POINTER(Wgrad)]),
     'mcgen_wgrad': (_i, [C.POINTER(Wgrad), _i, _vp]),
+    'mcgen_wgrad_multi_ok': (_i, [C.POINTER(Wgrad), _i]),
+    'mcgen_wgrad_multi': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
     'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),

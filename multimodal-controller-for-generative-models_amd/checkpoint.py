@@ -36,11 +36,34 @@ def save(input, path, protocol=2, mode='torch'):
 def load(path, mode='torch'):
     """utils.py:38-45.  (weights_only=False: the reference pickles its cfg dict and Logger object into the file.)"""
     if mode == 'torch':
-        return torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+        try:
+            return torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+        except ModuleNotFoundError as e:
+            # A reference checkpoint pickles its `logger.Logger` instance (train_gan.py:112-118): the class must be
+            # importable under that module name.  When the caller has not put a `logger` module on the path (the
+            # reference's own, or compat/logger.py), bind the shim and read the file again.
+            if e.name != 'logger' or not _bind_logger_shim():
+                raise
+            return torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
     elif mode == 'numpy':
         import numpy as np
         return np.load(path, allow_pickle=True)
     raise ValueError('Not valid save mode')
+
+
+def _bind_logger_shim() -> bool:
+    """sys.modules['logger'] = compat/logger.py (the drop-in for src/logger.py); False when it cannot be found."""
+    import importlib.util
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(here), 'compat', 'logger.py')
+    if 'logger' in sys.modules or not os.path.exists(path):
+        return False
+    spec = importlib.util.spec_from_file_location('logger', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules['logger'] = mod
+    return True
 
 
 def _opt_state(opt):

@@ -1,0 +1,352 @@
+// Weight gradients of the 3x3 convolutions of one backward pass in ONE launch (gfx950 MFMA, bf16).
+//
+//   dW[co][tap][ci] = sum over pixels  dy[pixel][co] * prologue(x)[pixel + tap][ci]          (mcgen_wgrad, wgrad.hip)
+//
+// What bounded the per-layer kernels of wgrad.hip on the big layers: a 64 co x 32 ci workgroup tile does
+// 72 MFMAs per SIMD per 128-pixel step -- 0.48 us of matrix pipe against ~0.9 us of fixed per-step cost (barrier, DMA wait,
+// the window's prologue pass, re-done by every output-channel block) -- and the small layers (8x8 maps, 20 launches per
+// iteration) are all pipeline fill.  Here:
+//   * the workgroup tile is 128 co x 64 ci x 9 taps (8 waves, 144 accumulator registers each: 64 co x 16 ci x 9 taps):
+//     288 MFMAs per SIMD per step, the window prologue runs once per 128 output channels, operand bytes per FLOP halve;
+//   * up to MCGEN_WGRAD_MULTI_MAX layers share the launch: the host sizes each layer's pixel splits by its share of the
+//     FLOPs, so every workgroup walks about the same number of steps, the chip is filled once per PASS, and the split-K
+//     slabs (one accumulator set per workgroup, whatever the tile) are paid once per pass instead of once per layer;
+//   * dy tiles travel by LDS-DMA (unpadded 256-byte rows, 16-byte units XOR-swizzled by (row & 7) << 1 on the SOURCE
+//     address: the transposing fragment reads are conflict-free); the x window goes through registers -- loaded two steps
+//     ahead, prologue (BatchNorm affine, ReLU, MultimodalController code: modules.py:71-76) + ds_write one step ahead,
+//     right after the barrier, where the other waves' MFMAs cover it (cdna_hip_programming.md T14);
+//   * every LDS address of the step is one per-lane base + an instruction immediate (LGW, LGH are template parameters).
+// Slabs keep wgrad.hip's layout [split][chunk of 32 ci][tap][Cout_w][32], so mcgen_wgrad_reduce(_batch) serves both.
+#include "conv_tile.h"
+
+namespace {
+
+constexpr int WB_BM = 128;                 // pixels per step
+constexpr int WB_CO = 128, WB_CI = 64;     // workgroup tile
+constexpr int WB_NT = 512;
+constexpr int WB_XPITCH = WB_CI * 2 + 32;  // 160 B per window pixel: 8 consecutive pixels fall on 8 distinct 32-byte bank groups
+constexpr int WB_DROW = WB_CO * 2;         // 256 B per dy row
+constexpr int WB_ABUF = 32768, WB_DBUF = WB_BM * WB_DROW;    // one window buffer (<= 204 pixels x 160 B), one dy tile
+constexpr int WB_AFF = 2 * WB_ABUF + 2 * WB_DBUF;            // BatchNorm scale | shift of the tile's 64 channels: 2 x 256 B
+constexpr int WB_CODE = WB_AFF + 512;                        // code rows: 2 slots x 2 images x 256 B
+constexpr int WB_LDS = WB_CODE + 1024;                       // A0 A1 D0 D1 affine codes
+
+static __device__ __forceinline__ s16x4 wb_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<uintptr_t>(p)));
+}
+static __device__ __forceinline__ bf16x8 wb_frag(const char* p0, const char* p1) {
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = wb_tr16(p0); u.h[1] = wb_tr16(p1);
+    return u.v;
+}
+
+struct WgMulti {
+    mcgen_wgrad_t l[MCGEN_WGRAD_MULTI_MAX];
+    int first[MCGEN_WGRAD_MULTI_MAX + 1];      // first workgroup of each layer (first[n] = grid size)
+    int n;
+};
+
+// Geometry of a 128-pixel step on a (1 << LGH) x (1 << LGW) map: TH whole rows of one image, or TI whole images.
+template <int LGW, int LGH>
+struct WbGeo {
+    static constexpr int W = 1 << LGW, H = 1 << LGH, HW = W * H;
+    static constexpr int TI = HW >= WB_BM ? 1 : WB_BM / HW;
+    static constexpr int TH = HW >= WB_BM ? WB_BM / W : H;
+    static constexpr int LGTHW = (HW >= WB_BM) ? 7 : LGW + LGH;        // log2(TH * W)
+    static constexpr int PR = TH + 2, PC = W + 2, PP = TI * PR * PC;
+    static constexpr int NIX = (PP * 8 + WB_NT - 1) / WB_NT;            // 16-byte window units per thread
+    static_assert(PP * WB_XPITCH <= WB_ABUF - 128 && TI <= 2 && PR + 1 < 32, "window buffer");
+    static_assert(TH >= 2 || TI > 1, "tiles of a single row are not built (upsampled operands need even first rows)");
+    // window position (pixel index) of tile pixel m, halo included
+    static constexpr int winpos(int m) {
+        return ((m >> LGTHW) * PR + ((m & ((1 << LGTHW) - 1)) >> LGW) + 1) * PC + (m & (W - 1)) + 1;
+    }
+};
+
+template <int LGW, int LGH>
+static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, const int bx, const int by, const int bz,
+                                                      const int splits, char* smem) {
+    using G = WbGeo<LGW, LGH>;
+    constexpr int W = G::W, H = G::H, HW = G::HW, PR = G::PR, PC = G::PC, PP = G::PP, NIX = G::NIX, TI = G::TI;
+    char* const ldsA = smem;
+    char* const ldsD = smem + 2 * WB_ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 2, wb = wave & 3;             // output-channel half (64), input-channel quarter (16)
+    const int l15 = lane & 15, lg = lane >> 4, q4 = l15 >> 2, p4 = l15 & 3;
+    const mcgen_seg_t sg = p.seg;
+    const int co0 = bx * WB_CO, c0 = by * WB_CI;
+    const long Mtot = (long)p.N * HW;
+    const int m_tiles = (int)(Mtot / WB_BM);
+    // step walk of this split: all steps with stride `splits`, or (halves) one half of them with stride splits / 2
+    const int zs = p.halves ? (splits >> 1) : splits;
+    const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
+    const int t_first = (p.halves ? (bz / zs) * mt : 0) + bz % zs;
+    const int cnt = (mt - bz % zs + zs - 1) / zs;
+    const bool do_bias = (p.bias_slabs != nullptr) && (by == 0);
+
+    // ---- x window items of this thread: unit (window pixel pp, 8-channel group u); everything step-independent is a constant
+    const int u8 = tid & 7;                                        // (WB_NT % 8 == 0: every item of a thread has the same u)
+    const int cx = c0 + u8 * 8;
+    const bool cok = cx < sg.C;
+    // x_pk = LDS byte offset | (window row + 1) << 16 (0: the item never passes the row test) ; x_off = source element offset
+    int x_pk[NIX], x_off[NIX];
+#pragma unroll
+    for (int k = 0; k < NIX; ++k) {
+        const int pp = (tid + k * WB_NT) >> 3;
+        const int ti = pp / (PR * PC), rem = pp - ti * (PR * PC);
+        const int pr = rem / PC, pc = rem - pr * PC;
+        const int dh = pr - 1, w = pc - 1;
+        const bool item = pp < PP;
+        const bool colok = item && cok && w >= 0 && w < W;
+        // (threads past the window's last unit store zeros into the buffer's spare 128 bytes: no branch around an item)
+        x_pk[k] = (item ? pp * WB_XPITCH + u8 * 16 : WB_ABUF - 128 + u8 * 16) | ((colok ? pr + 1 : 0) << 16);
+        // element offset from the step's first source pixel; through the x2 upsample the source pixel of (h, w) is (h >> 1, w >> 1)
+        // (steps start on even rows, so the halving splits into a step part and this constant part; dh = -1 -> row h0/2 - 1)
+        x_off[k] = (sg.ups ? (ti * (HW >> 2) + (dh >> 1) * (W >> 1) + (w >> 1)) : (ti * HW + dh * W + w)) * sg.C + cx;
+    }
+    // the tile's BatchNorm affine: once per workgroup, kept in LDS (the registers are the accumulators')
+    float* const ldsAff = reinterpret_cast<float*>(smem + WB_AFF);
+    if (tid < 2 * WB_CI) {
+        const int c = c0 + (tid & (WB_CI - 1));
+        float v = (tid < WB_CI) ? 1.f : 0.f;
+        if (sg.scale && c < sg.C) v = (tid < WB_CI) ? sg.scale[c] : sg.shift[c];
+        ldsAff[tid] = v;
+    }
+    const float relu_lo = sg.relu ? 0.f : -__builtin_inff();
+    const char* xs = reinterpret_cast<const char*>(sg.x);
+    const char* dyb = reinterpret_cast<const char*>(p.dy);
+    const size_t dpix = (size_t)p.Cdy * 2;
+
+    // ---- dy units of this lane: DMA instruction d = wave * 4 + k covers rows 4 d .. 4 d + 3, 16 units of 16 bytes each
+    int d_src[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = (wave * 4 + k) * 4 + (lane >> 4);
+        int u = (lane & 15) ^ ((m & 7) << 1);
+        if (co0 + u * 8 + 8 > p.Cdy) u = 0;                       // beyond the dy pitch: any in-bounds unit (those rows are dropped)
+        const int ti = m >> G::LGTHW, rem = m & ((1 << G::LGTHW) - 1);
+        const int r = rem >> LGW, c = rem & (W - 1);
+        const int mp = p.dy_ups ? (ti * (HW >> 2) + (r >> 1) * (W >> 1) + (c >> 1)) : m;
+        d_src[k] = mp * (int)dpix + co0 * 2 + u * 16;
+    }
+    // first source pixel of step `tile` for an operand stored at the map's resolution or at half of it
+    auto first_pixel = [&](int tile, bool up) -> size_t {
+        const int pix0 = tile * WB_BM;
+        if (!up) return (size_t)pix0;
+        const int n0 = pix0 >> (LGW + LGH), h0 = (pix0 & (HW - 1)) >> LGW;
+        return ((size_t)n0 * (H >> 1) + (h0 >> 1)) * (W >> 1);
+    };
+    auto tile_of = [&](int i) { return t_first + (i < cnt ? i : cnt - 1) * zs; };
+
+    // ---- register stage of the x window: raw units; the step's code row(s) travel by LDS-DMA (64 floats per image)
+    u32x4 raw[NIX];
+    char* const ldsCode = smem + WB_CODE;
+    auto load_x = [&](int i) {
+        const int tile = tile_of(i);
+        const int pix0 = tile * WB_BM;
+        const int n0 = pix0 >> (LGW + LGH), h0 = (TI == 1) ? ((pix0 & (HW - 1)) >> LGW) : 0;
+        const char* xb = xs + first_pixel(tile, sg.ups != 0) * sg.C * 2;
+#pragma unroll
+        for (int k = 0; k < NIX; ++k) {
+            const int row = (x_pk[k] >> 16) & 31;                                      // window row + 1, 0 = never
+            const bool ok = row != 0 && (unsigned)(h0 + row - 2) < (unsigned)H;
+            const char* src = ok ? xb + (ptrdiff_t)x_off[k] * 2 : xs;                   // outside: any in-bounds address
+            raw[k] = *reinterpret_cast<const u32x4*>(src);
+        }
+        if (sg.code && wave < TI) {                                                    // wave t: the code row of image n0 + t
+            const int c = c0 + lane;
+            const float* src = sg.code + (size_t)(n0 + wave) * sg.C + (c < sg.C ? c : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ldsCode + ((i & 1) * 2 + wave) * 256), 4, 0, 0);
+        }
+    };
+    // prologue + LDS store of the staged window: v -> max(v * sc + sh, relu ? 0 : -inf) * code, zeros outside the image
+    auto write_x = [&](int i) {
+        const int pix0 = tile_of(i) * WB_BM;
+        const int h0 = (TI == 1) ? ((pix0 & (HW - 1)) >> LGW) : 0;
+        char* dst = ldsA + (i & 1) * WB_ABUF;
+        float sc[8], sh[8], cd[TI][8];
+        load8f(ldsAff + u8 * 8, sc); load8f(ldsAff + WB_CI + u8 * 8, sh);
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cd[t][e] = 1.f;
+            if (sg.code) load8f(reinterpret_cast<const float*>(ldsCode + ((i & 1) * 2 + t) * 256) + u8 * 8, cd[t]);
+        }
+#pragma unroll
+        for (int k = 0; k < NIX; ++k) {
+            const int row = (x_pk[k] >> 16) & 31, lo = x_pk[k] & 0xffff;
+            const bool ok = row != 0 && (unsigned)(h0 + row - 2) < (unsigned)H;
+            const bool second = TI > 1 && lo >= PR * PC * WB_XPITCH;                   // (TI <= 2: the window's second image)
+            union { bf16x8 h; u32x4 w; } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c0v = second ? cd[TI - 1][2 * e] : cd[0][2 * e], c1v = second ? cd[TI - 1][2 * e + 1] : cd[0][2 * e + 1];
+                const float v0 = fmaxf(fmaf(__uint_as_float(raw[k][e] << 16), sc[2 * e], sh[2 * e]), relu_lo) * c0v;
+                const float v1 = fmaxf(fmaf(__uint_as_float(raw[k][e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), relu_lo) * c1v;
+                o.h[2 * e] = (bf16_t)v0; o.h[2 * e + 1] = (bf16_t)v1;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.w[e] = ok ? o.w[e] : 0u;
+            *reinterpret_cast<u32x4*>(dst + lo) = o.w;
+            __builtin_amdgcn_sched_barrier(0);             // one item at a time: the accumulators leave ~100 registers for all of this
+        }
+    };
+    auto dma_dy = [&](int i) {
+        const char* db = dyb + first_pixel(tile_of(i), p.dy_ups != 0) * dpix;
+        char* ds = ldsD + (i & 1) * WB_DBUF + wave * 4096;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + d_src[k]),
+                                             (__attribute__((address_space(3))) void*)(ds + k * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addresses: one per-lane base per operand (four for dy: the swizzle moves the co fragment), steps and taps by immediates
+    const int m0 = 4 * lg + q4;                                    // the lane's pixel row inside a 16-pixel group
+    int aoff;                                                      // window: pixel m0 of the tile, tap (0, 0) -> halo origin
+    {
+        const int ti = 0, r = m0 >> LGW, c = m0 & (W - 1);         // (m0 < 16 <= TH * W: never leaves the first image)
+        aoff = ((ti * PR + r) * PC + c) * WB_XPITCH + wb * 32 + p4 * 8;
+    }
+    int doff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        doff[c] = m0 * WB_DROW + 32 * ((wa * 4 + c) ^ (m0 & 7)) + 8 * p4;
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    // ---- pipeline: x of step i + 2 in registers, x of step i + 1 written and dy of step i + 1 in flight while step i multiplies
+    load_x(0);
+    dma_dy(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // the affine rows and step 0's code row(s) are in LDS
+    write_x(0);
+    if (cnt > 1) load_x(1);
+    for (int i = 0; i < cnt; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dy of step i has landed (and this thread's x of step i + 1)
+        __syncthreads();                                               // step i published; the buffers of step i - 1 are free
+        if (i + 1 < cnt) {
+            write_x(i + 1);
+            dma_dy(i + 1);
+            if (i + 2 < cnt) load_x(i + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // (the staging block's temporaries die before the fragments come alive)
+        const char* A = ldsA + (i & 1) * WB_ABUF + aoff;
+        const char* D = ldsD + (i & 1) * WB_DBUF;
+        if (do_bias) {
+            // column sums of the dy tile: thread = (column tid & 127, row quarter tid >> 7)
+            const int col = tid & 127, part = tid >> 7;
+#pragma unroll 8
+            for (int r = 0; r < WB_BM / 4; ++r) {
+                const int row = part * (WB_BM / 4) + r;
+                bsum += (float)*reinterpret_cast<const bf16_t*>(D + row * WB_DROW + 16 * ((col >> 3) ^ ((row & 7) << 1)) + 2 * (col & 7));
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < WB_BM / 32; ++ks) {
+            bf16x8 df[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                df[c] = wb_frag(D + doff[c] + (32 * ks) * WB_DROW, D + doff[c] + (32 * ks + 16) * WB_DROW);
+            // window offsets of the step's two 16-pixel groups (pixel 0 of each group: compile-time)
+            constexpr int HALO0 = PC + 1;
+            const int g0 = (G::winpos(32 * ks) - HALO0) * WB_XPITCH, g1 = (G::winpos(32 * ks + 16) - HALO0) * WB_XPITCH;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int tap = ((j / 3) * PC + (j % 3)) * WB_XPITCH;
+                const bf16x8 af = wb_frag(A + g0 + tap, A + g1 + tap);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[c], af, acc[j][c], 0, 0, 0);
+                if (j % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // fragment reads at most three taps ahead (register budget)
+            }
+        }
+    }
+    // ---- slab[z][chunk][tap][co][32]: lane holds D[co = 4 lg + r][ci = l15] of (tap j, co fragment c)
+    const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * 9 * p.Cout_w * MCGEN_CK;
+    float* out = p.slabs + (size_t)bz * slab_elems;
+    const int qc = by * 2 + (wb >> 1), col = (wb & 1) * 16 + l15;
+    if (qc < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + (wa * 4 + c) * 16 + lg * 4 + r;
+                    if (co < p.Cout_w) out[(((size_t)qc * 9 + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][c][r];
+                }
+    }
+    if (do_bias) {
+        const int colb = tid & 127, part = tid >> 7;
+        if (co0 + colb < p.Cout_w) p.bias_slabs[((size_t)bz * 4 + part) * p.Cout_w + co0 + colb] = bsum;
+    }
+}
+
+__global__ __launch_bounds__(WB_NT, 1)
+void wgrad_multi_kernel(const WgMulti a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < MCGEN_WGRAD_MULTI_MAX; ++k) l += (k < a.n && (int)blockIdx.x >= a.first[k]) ? 1 : 0;
+    const mcgen_wgrad_t& p = a.l[l];
+    const int local = (int)blockIdx.x - a.first[l];
+    const int gx = p.Cout_w / WB_CO, gy = p.seg.C / WB_CI;
+    const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+    const int lgw = 31 - __builtin_clz(p.W);
+    switch (lgw) {
+        case 5: wgrad_big_body<5, 5>(p, bx, by, bz, p.splits, smem); break;
+        case 4: wgrad_big_body<4, 4>(p, bx, by, bz, p.splits, smem); break;
+        default: wgrad_big_body<3, 3>(p, bx, by, bz, p.splits, smem); break;
+    }
+}
+
+}  // namespace
+
+extern "C" int mcgen_wgrad_multi_ok(const mcgen_wgrad_t* p, int dtype) {
+    if (!p || dtype != MCGEN_BF16) return 0;
+    if (p->seg.ksize != 3 || p->H != p->W || (p->W != 8 && p->W != 16 && p->W != 32)) return 0;
+    if (p->Cout_w % WB_CO || p->seg.C % WB_CI || p->Cout != p->Cout_w || p->Cdy < p->Cout_w) return 0;
+    if (((long)p->N * p->H * p->W) % WB_BM) return 0;
+    if (p->seg.group_n || p->seg.cmap) return 0;
+    return 1;
+}
+
+extern "C" int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, void* stream) {
+    MCGEN_CHECK(layers && n >= 1 && n <= MCGEN_WGRAD_MULTI_MAX, "wgrad_multi: 1 .. %d layers per launch", MCGEN_WGRAD_MULTI_MAX);
+    WgMulti a;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const mcgen_wgrad_t& p = layers[i];
+        MCGEN_CHECK(p.seg.x && p.dy && p.slabs, "wgrad_multi: null pointer (layer %d)", i);
+        MCGEN_CHECK(mcgen_wgrad_multi_ok(&p, dtype), "wgrad_multi: layer %d is not eligible (bf16, 3x3, square 8/16/32 maps, Cout %% 128 == 0, "
+                    "C %% 64 == 0, whole 128-pixel steps)", i);
+        const long m_tiles = (long)p.N * p.H * p.W / WB_BM;
+        MCGEN_CHECK(p.splits >= 1 && p.splits <= m_tiles, "wgrad_multi: layer %d: bad splits", i);
+        MCGEN_CHECK(!p.halves || (p.splits % 2 == 0 && m_tiles % 2 == 0 && p.splits / 2 <= m_tiles / 2), "wgrad_multi: layer %d: halves needs even splits and steps", i);
+        MCGEN_CHECK(!(p.seg.ups || p.dy_ups) || p.H >= 4, "wgrad_multi: layer %d: upsampled operands need maps of at least 4 rows", i);
+        a.l[i] = p;
+        a.first[i] = total;
+        total += (p.Cout_w / WB_CO) * (p.seg.C / WB_CI) * p.splits;
+    }
+    for (int i = n; i < MCGEN_WGRAD_MULTI_MAX; ++i) { a.l[i] = layers[0]; a.first[i] = total; }
+    a.first[MCGEN_WGRAD_MULTI_MAX] = total;
+    a.n = n;
+    static bool raised = false;
+    if (!raised) {
+        raised = true;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WB_LDS);
+        if (e != hipSuccess) return mcgen_fail("wgrad_multi: cannot raise LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(total), dim3(WB_NT), WB_LDS, reinterpret_cast<hipStream_t>(stream), a);
+    MCGEN_LAUNCH_CHECK("wgrad_multi");
+    return 0;
+}

@@ -418,6 +418,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         raise _lib.McgenError(f'dy must be {exp}+[C] {dtype}, got {tuple(dy.shape)} {dy.dtype}')
     m_tiles = (n * h * w + 127) // 128
     nchunk = (seg.x.shape[-1] + 31) // 32
+    explicit_splits = splits
     if splits is None:
         # 1x1 gradients with >= 4 chunks run as chunk groups of 4 (wgrad.hip): a quarter of the workgroups per split
         # (wgrad.hip: the ring form -- bf16, tiles inside one image -- comes first; chunk groups are for the small maps)
@@ -435,6 +436,17 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     p.splits = splits
     p.halves = int(second is not None)
     lib = _lib.load()
+    if grad.numel() != cout * cin * seg.ksize * seg.ksize:
+        raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
+    if (_deferred is not None and _MULTI and explicit_splits is None and dtype == torch.bfloat16
+            and lib.mcgen_wgrad_multi_ok(C.byref(p), _dt(dtype))):
+        # The 3x3 layers of a backward pass share ONE launch (mcgen_wgrad_multi): queued here, launched when the pass's
+        # deferred_reduces context closes -- its pixel splits are sized by the layer's share of the pass's FLOPs.
+        if not grad.is_contiguous():
+            raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
+        _deferred.append(_PendingMulti(p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm,
+                                       row_scale, m_tiles, (pad16(cout) // 128) * (seg.x.shape[-1] // 64)))
+        return
     elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
     # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
     # already exist, and nothing reads its slabs before the pass's batched reduce, so it overlaps the
@@ -457,8 +469,6 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
                # algorithmic bytes: x + dy read once, dW (+ db) written once; the split-K slabs are the implementation's
                lambda: _nbytes(seg.x, dy) + 4 * (cout * cin * seg.ksize ** 2 + (cout if bias_grad is not None else 0)) * (2 if second is not None else 1),
                lambda: _nbytes(slabs, bias_slabs))
-    if grad.numel() != cout * cin * seg.ksize * seg.ksize:
-        raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
     if second is None:
         parts = [(slabs, bias_slabs, grad, bias_grad, bias_grad2, splits)]
     else:
@@ -480,6 +490,88 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
 
 
 _deferred = None
+_MULTI = _flag('MCGEN_WGRAD_MULTI', '1') != '0'        # eligible 3x3 weight gradients of a pass as one mcgen_wgrad_multi launch
+_CU_COUNT = {}
+
+
+def _cu_count(device) -> int:
+    n = _CU_COUNT.get(device)
+    if n is None:
+        n = _CU_COUNT[device] = torch.cuda.get_device_properties(device).multi_processor_count
+    return n
+
+
+class _PendingMulti:
+    """One queued layer of a mcgen_wgrad_multi launch (see ops.wgrad)."""
+    __slots__ = ('p', 'seg', 'dy', 'cout', 'cin', 'grad', 'bias_grad', 'bias_grad2', 'second', 'alpha', 'accumulate', 'row_perm',
+                 'row_scale', 'm_tiles', 'blocks', 'splits', 'slabs', 'bias_slabs')
+
+    def __init__(self, p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm, row_scale, m_tiles, blocks):
+        self.p, self.seg, self.dy, self.cout, self.cin = p, seg, dy, cout, cin
+        self.grad, self.bias_grad, self.bias_grad2, self.second = grad, bias_grad, bias_grad2, second
+        self.alpha, self.accumulate, self.row_perm, self.row_scale = alpha, accumulate, row_perm, row_scale
+        self.m_tiles, self.blocks = m_tiles, blocks
+
+    def jobs(self):
+        """The slab-reduce job(s) of the layer, in deferred_reduces' tuple form."""
+        cw, ks, cs = pad16(self.cout), self.seg.ksize, self.seg.x.shape[-1]
+        tail = (self.cout, self.cin, ks, cw, self.row_perm, int(self.accumulate), float(self.alpha), self.row_scale, cs)
+        if self.second is None:
+            return [(self.slabs, self.grad, self.bias_slabs, self.bias_grad, self.bias_grad2, self.splits) + tail]
+        hs = self.splits // 2
+        b0 = self.bias_slabs[:hs * 4] if self.bias_slabs is not None else None
+        b1 = self.bias_slabs[hs * 4:] if self.bias_slabs is not None else None
+        return [(self.slabs[:hs], self.grad, b0, self.bias_grad, self.bias_grad2, hs) + tail,
+                (self.slabs[hs:], self.second[0], b1, self.second[1], self.second[2], hs) + tail]
+
+
+def _launch_multi(pend):
+    """Size the queued layers' pixel splits by their share of the pass's work (128-pixel steps x workgroup tiles), one
+    workgroup per CU over the whole launch, allocate the slabs and launch mcgen_wgrad_multi (<= MCGEN_WGRAD_MULTI_MAX layers each)."""
+    lib = _lib.load()
+    dev = pend[0].dy.device
+    for base in range(0, len(pend), _lib.WGRAD_MULTI_MAX):
+        grp = pend[base:base + _lib.WGRAD_MULTI_MAX]
+        budget = _cu_count(dev)
+        work = [q.m_tiles * q.blocks for q in grp]
+        tot = float(sum(work))
+        for q, wk in zip(grp, work):
+            unit = 2 if q.second is not None else 1                     # a two-half launch needs even splits
+            cap = q.m_tiles // unit * unit
+            sp = int(budget * wk / tot / q.blocks) // unit * unit
+            q.splits = max(unit, min(cap, sp))
+        # hand the workgroups the floors left over to the layers with the most steps per workgroup
+        used = sum(q.splits * q.blocks for q in grp)
+        while True:
+            best = None
+            for q in grp:
+                unit = 2 if q.second is not None else 1
+                if q.splits + unit <= q.m_tiles // unit * unit and used + unit * q.blocks <= budget:
+                    load = q.m_tiles / q.splits
+                    if best is None or load > best[0]:
+                        best = (load, q, unit)
+            if best is None:
+                break
+            best[1].splits += best[2]
+            used += best[2] * best[1].blocks
+        arr = (_lib.Wgrad * len(grp))()
+        flops = nbytes = extra = 0.0
+        for a, q in zip(arr, grp):
+            elems = int(lib.mcgen_wgrad_slab_elems(C.byref(q.p)))
+            q.slabs = torch.empty((q.splits, elems), dtype=torch.float32, device=dev)
+            q.bias_slabs = (torch.empty((q.splits * 4, pad16(q.cout)), dtype=torch.float32, device=dev)
+                            if q.bias_grad is not None else None)
+            q.p.splits, q.p.slabs, q.p.bias_slabs = q.splits, _p(q.slabs), _p(q.bias_slabs)
+            C.memmove(C.byref(a), C.byref(q.p), C.sizeof(_lib.Wgrad))
+            n, hh, ww = q.p.N, q.p.H, q.p.W
+            flops += 2.0 * n * hh * ww * q.cout * q.seg.x.shape[-1] * 9
+            nbytes += _nbytes(q.seg.x, q.dy) + 4 * (q.cout * q.cin * 9 + (q.cout if q.bias_grad is not None else 0)) * (2 if q.second is not None else 1)
+            extra += _nbytes(q.slabs, q.bias_slabs)
+        _timed(lambda: 'wgrad_multi<bf16,3>', flops,
+               lambda: check(lib.mcgen_wgrad_multi(arr, len(grp), _lib.BF16, _stream()), 'wgrad_multi'),
+               lambda: nbytes, lambda: extra)
+
+
 _SIDE = _flag('MCGEN_SIDE_STREAM', '0') == '1'     # measured slower on MI355X (16.7 vs 15.7 ms/step): opt-in only
 _side_streams = {}
 _side_keep = []
@@ -520,6 +612,12 @@ class deferred_reduces:
     def __exit__(self, et, ev, tb):
         global _deferred
         jobs, _deferred = _deferred, self._outer
+        pend = [j for j in jobs if isinstance(j, _PendingMulti)]
+        if et is None and pend:
+            _launch_multi(pend)
+            jobs = [t for j in jobs for t in (j.jobs() if isinstance(j, _PendingMulti) else [j])]
+        elif pend:
+            jobs = [j for j in jobs if not isinstance(j, _PendingMulti)]
         if _SIDE and _side_keep:
             for s in _side_streams.values():                 # join: the slabs are complete before they are reduced
                 torch.cuda.current_stream().wait_stream(s)

@@ -312,8 +312,13 @@ def test_driver_counterpart_runs_and_resumes(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'Train Epoch: 1' in r.stdout
     path = os.path.join(out, 'model', '0_CIFAR10_label_mcgan_0.5_checkpoint.pt')
-    raw = ck.load(path)
+    raw = ck.load(path)                       # (the file pickles a logger.Logger: checkpoint.load binds compat/logger.py itself)
     assert raw['epoch'] == 2 and set(raw['optimizer_dict']) == {'generator', 'discriminator'}
+    # what the reference's resume_mode 1 touches (train_gan.py:264-275): scheduler state per network, a usable Logger
+    assert set(raw['scheduler_dict']) == {'generator', 'discriminator'} and raw['scheduler_dict']['generator']['last_epoch'] == 1
+    assert type(raw['logger']).__name__ == 'Logger' and type(raw['logger']).__module__ == 'logger'
+    assert 'train/Loss_D' in raw['logger'].history and 'test/GeneratedMean' in raw['logger'].history
+    assert 'stand-in' in r.stdout                 # test() says that its metric is not IS / FID
     assert int(raw['optimizer_dict']['discriminator']['state'][0]['step']) == 10     # 2 batches x 5 D updates
     r = subprocess.run(base + ['--num_epochs', '2', '--resume_mode', '1'], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]

@@ -779,6 +779,108 @@ def test_big_wgrad_two_halves_bf16():
     _assert_close(b2, dyf[n // 2:].sum((0, 2, 3)), dtype, 'second half bias')
 
 
+MULTI_PASSES = {
+    # one backward pass = the layers whose weight gradients share ONE mcgen_wgrad_multi launch:
+    # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves)
+    'generator': [(128, 32, 256, 256, False, False, True, False),     # G block 2 conv_b
+                  (128, 32, 256, 256, True, False, True, False),      # G block 2 conv_a (x through the upsample)
+                  (128, 16, 256, 256, False, False, True, False),
+                  (128, 16, 256, 256, True, False, True, False),
+                  (128, 8, 256, 256, False, False, True, False),      # 8x8 maps: two images per 128-pixel step
+                  (128, 8, 256, 256, True, False, True, False)],      # x at 4x4 through the upsample
+    'discriminator': [(256, 32, 128, 128, False, True, False, True),  # D block 0 conv2: pooled gradient, one slab set per half
+                      (256, 16, 128, 128, False, False, False, True),
+                      (256, 16, 128, 128, False, True, False, True),
+                      (256, 8, 128, 128, False, False, False, True),
+                      (256, 8, 128, 128, False, False, False, True)],
+    'small': [(4, 16, 64, 128, False, False, True, False),           # few steps per layer: more workgroups than steps must not happen
+              (2, 8, 128, 128, True, False, False, False),
+              (8, 32, 64, 128, False, True, True, True)],
+}
+
+
+@pytest.mark.parametrize('name', list(MULTI_PASSES))
+def test_wgrad_multi_pass_bf16(name):
+    """mcgen_wgrad_multi (wgrad_multi.hip): the 3x3 weight gradients of one backward pass queued inside a deferred_reduces
+    context run as ONE launch with FLOP-proportional pixel splits; every layer against the CPU reference
+    (torch.nn.grad.conv2d_weight on the prologue-applied, bf16-rounded operands), bias gradients and the per-half
+    gradients of a paired pass included -- and bit-identical when the same pass is run twice (fixed-order reduction)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    layers = MULTI_PASSES[name]
+    g = torch.Generator().manual_seed(811 + len(layers))
+    prob, refs = [], []
+    for (n, h, ci, co, ups, dy_ups, affine, halves) in layers:
+        hs = h // 2 if ups else h
+        x = _rnd(g, n, ci, hs, hs)
+        scale, shift = (_rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3) if affine else (None, None)
+        code = (torch.rand(n, ci, generator=g) < 0.5).float()
+        hd = h // 2 if dy_ups else h
+        dy = _rnd(g, n, co, hd, hd) * 0.1
+        a = _q(ref_prologue(_q(x, dtype), scale, shift, True, code, ups), dtype)
+        dyf = _q(dy, dtype)
+        if dy_ups:
+            dyf = dyf.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        parts = (slice(0, n // 2), slice(n // 2, n)) if halves else (slice(None),)
+        refs.append([(torch.nn.grad.conv2d_weight(a[sl], (co, ci, 3, 3), dyf[sl], padding=1), dyf[sl].sum((0, 2, 3))) for sl in parts])
+        seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda() if affine else None, shift=shift.cuda() if affine else None,
+                      code=code.cuda(), ups=ups, relu=True)
+        prob.append((seg, _nhwc(ops, dy, dtype), co, ci, dy_ups, halves))
+
+    def run():
+        outs = []
+        ops._PROF = []                                   # record the launches of the pass
+        try:
+            with ops.deferred_reduces():
+                for seg, dyt, co, ci, dy_ups, halves in prob:
+                    gs = [torch.zeros((co, ci, 3, 3), device='cuda') for _ in range(2 if halves else 1)]
+                    bs = [torch.zeros((co,), device='cuda') for _ in range(2 if halves else 1)]
+                    ops.wgrad(seg, dyt, co, ci, gs[0], dy_ups=dy_ups, bias_grad=bs[0], second=(gs[1], bs[1], None) if halves else None)
+                    outs.append((gs, bs))
+            names = [r[0] for r in ops._PROF]
+        finally:
+            ops._PROF = None
+        return outs, names
+    outs, names = run()
+    assert names.count('wgrad_multi<bf16,3>') == 1 and not any(nm.startswith('wgrad<') for nm in names), names
+    for li, ((gs, bs), ref) in enumerate(zip(outs, refs)):
+        for hi, ((gr, br), gt, bt) in enumerate(zip(ref, gs, bs)):
+            _assert_close(gt, gr, dtype, f'{name} layer {li} half {hi}')
+            _assert_close(bt, br, dtype, f'{name} layer {li} half {hi} bias')
+    outs2, _ = run()
+    for (gs, bs), (gs2, bs2) in zip(outs, outs2):
+        for a_, b_ in zip(gs + bs, gs2 + bs2):
+            assert torch.equal(a_, b_)
+
+
+def test_wgrad_multi_matches_the_per_layer_kernels():
+    """Same operands through mcgen_wgrad_multi and through the per-layer kernels of wgrad.hip (the queue switched off):
+    the two split the pixels differently, so they agree to fp32 summation order, not bitwise."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(877)
+    n, h, c = 64, 16, 128
+    x, dy = _rnd(g, n, c, h, h), _rnd(g, n, c, h, h) * 0.1
+    scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), relu=True)
+    dyt = _nhwc(ops, dy, dtype)
+    res = []
+    for multi in (True, False):
+        old = ops._MULTI
+        ops._MULTI = multi
+        try:
+            gr, bg = torch.zeros((c, c, 3, 3), device='cuda'), torch.zeros((c,), device='cuda')
+            with ops.deferred_reduces():
+                ops.wgrad(seg, dyt, c, c, gr, bias_grad=bg, alpha=0.5)
+            res.append((gr.cpu(), bg.cpu()))
+        finally:
+            ops._MULTI = old
+    scale_g = float(res[1][0].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * scale_g + 1e-6
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_grouped_batchnorm_pass_equals_separate_passes(dtype):
     """mcgen_seg_t.group_n + mcgen_bn_finalize_groups: two training-mode BatchNorm batches pushed through
