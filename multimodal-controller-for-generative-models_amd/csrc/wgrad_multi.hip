@@ -250,22 +250,30 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
                 bsum += (float)*reinterpret_cast<const bf16_t*>(D + row * WB_DROW + 16 * ((col >> 3) ^ ((row & 7) << 1)) + 2 * (col & 7));
             }
         }
+        // fragment reads one tap ahead of their MFMAs (two window fragments in registers: the register budget allows no more);
+        // the dy fragments of a 32-pixel group are read with its first tap
+        constexpr int HALO0 = PC + 1;
+        auto rd_a = [&](int ks, int j) {
+            const int g0 = (G::winpos(32 * ks) - HALO0) * WB_XPITCH, g1 = (G::winpos(32 * ks + 16) - HALO0) * WB_XPITCH;
+            const int tap = ((j / 3) * PC + (j % 3)) * WB_XPITCH;
+            return wb_frag(A + g0 + tap, A + g1 + tap);
+        };
+        bf16x8 af = rd_a(0, 0);
 #pragma unroll
         for (int ks = 0; ks < WB_BM / 32; ++ks) {
             bf16x8 df[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 df[c] = wb_frag(D + doff[c] + (32 * ks) * WB_DROW, D + doff[c] + (32 * ks + 16) * WB_DROW);
-            // window offsets of the step's two 16-pixel groups (pixel 0 of each group: compile-time)
-            constexpr int HALO0 = PC + 1;
-            const int g0 = (G::winpos(32 * ks) - HALO0) * WB_XPITCH, g1 = (G::winpos(32 * ks + 16) - HALO0) * WB_XPITCH;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const int tap = ((j / 3) * PC + (j % 3)) * WB_XPITCH;
-                const bf16x8 af = wb_frag(A + g0 + tap, A + g1 + tap);
+                const bool last = (ks == WB_BM / 32 - 1) && (j == 8);
+                bf16x8 an = af;
+                if (!last) an = (j == 8) ? rd_a(ks + 1, 0) : rd_a(ks, j + 1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[c], af, acc[j][c], 0, 0, 0);
-                if (j % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // fragment reads at most three taps ahead (register budget)
+                af = an;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
