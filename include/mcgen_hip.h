@@ -338,9 +338,20 @@ int mcgen_hinge_g(const float* fake, int N, float* loss, float* dfake, void* str
 int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, void* stream);
 
 /* Adam over one flat fp32 buffer (torch.optim.Adam as configured at train_gan.py:43-47,231):
- * step is a device counter incremented by the call. */
+ * step = int64[2] on the device: step[0] is the counter the call increments (by the last workgroup to finish: no
+ * follow-up launch), step[1] a ticket word that is 0 between calls. */
 int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int64_t* step, void* stream);
+/* mcgen_sn_grad_fix_pair with Adam's update in place of the store (a single-rank discriminator update, train_gan.py:154-158:
+ * d/d(weight_orig) is never materialised): for the layers of the table, g = fix(g_src0; uv0, sigma0) + fix(g_src1; uv1, sigma1)
+ * goes straight into m, v, p (p doubles as w_base: the dot <g, W> is taken before any element moves).  A step that covers
+ * its parameters with several tables (the two gradient buckets) passes the layer count of ALL of them as `ticket_layers`:
+ * the last launch's last workgroup increments step[0].  workspace: 2 * 32 * nlayers floats; step as in mcgen_adam. */
+int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, float* p, float* m, float* v,
+                           const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                           const float* sigma0, const float* sigma1, float* workspace,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
+                           int ticket_layers, void* stream);
 
 /* ---- MCGlow-specific kernels (reference: models/mcglow.py) ------------------------------------------------- */
 /* Block squeeze / unsqueeze (mcglow.py:221-223, 262-265): [N,H,W,C] <-> [N,H/2,W/2,4C], channel c*4 + 2*dh + dw.

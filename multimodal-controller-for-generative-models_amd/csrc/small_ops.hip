@@ -433,7 +433,8 @@ __global__ void sn_k1_wtu(const float* __restrict__ wb, const float* __restrict_
     float* part = ws + (size_t)blockIdx.x * ws_stride + (size_t)blockIdx.y * L.cols;
     for (int j = threadIdx.x; j < L.cols; j += blockDim.x) {
         float s = 0.f;
-        for (int i = r0; i < r1; ++i) s = fmaf(W[(size_t)i * L.cols + j], u[i], s);
+#pragma unroll 4
+        for (int i = r0; i < r1; ++i) s = fmaf(W[(size_t)i * L.cols + j], u[i], s);        // (same order; the loads of a column go out together)
         part[j] = s;
     }
 }
@@ -444,8 +445,12 @@ __global__ void sn_k2_v(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
     const float* part = ws + (size_t)blockIdx.x * ws_stride;
     float nrm = 0.f;
     for (int j = threadIdx.x; j < L.cols; j += blockDim.x) {
+        float pv[SN_RS];
+#pragma unroll
+        for (int k = 0; k < SN_RS; ++k) pv[k] = part[(size_t)k * L.cols + j];           // 32 independent loads, then the sum in slice order
         float s = 0.f;
-        for (int k = 0; k < SN_RS; ++k) s += part[(size_t)k * L.cols + j];
+#pragma unroll
+        for (int k = 0; k < SN_RS; ++k) s += pv[k];
         sv[j] = s; nrm += s * s;
     }
     nrm = sqrtf(block_sum(nrm, red));
@@ -467,6 +472,7 @@ __global__ void sn_k3_wv(const float* __restrict__ wb, const float* __restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int i = r0 + wave; i < r1; i += nw) {
         float s = 0.f;
+#pragma unroll 6
         for (int j = lane; j < L.cols; j += 64) s = fmaf(W[(size_t)i * L.cols + j], v[j], s);
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
         if (lane == 0) t[i] = s;
@@ -785,22 +791,85 @@ __global__ void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
 // ---- Adam -----------------------------------------------------------------------------------------------
 // torch.optim.Adam (no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// The step counter is bumped by the LAST block to finish (ticket in step[1]): every block has read step[0] before it
+// takes its ticket, so the bump cannot race a reader, and the launch needs no one-thread follow-up kernel.
+__device__ __forceinline__ void adam_step_ticket(int64_t* step, unsigned total_blocks) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
+        const unsigned prev = atomicAdd(ticket, 1u);
+        if (prev == total_blocks - 1) { *ticket = 0u; step[0] += 1; }
+    }
+}
+__device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t i, float gi,
+                                          float b1, float b2, float eps, float wd, float step_size, float bc2s) {
+    if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr, float b1, float b2, float eps, float wd, const int64_t* step) {
+                            size_t n, float lr, float b1, float b2, float eps, float wd, int64_t* step) {
     const double t = (double)(step[0] + 1);
     const float bc1 = (float)(1.0 - pow((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
     const float step_size = lr / bc1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float gi = g[i];
-        if (wd != 0.f) gi = fmaf(wd, p[i], gi);
-        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-        m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        adam_elem(p, m, v, i, g[i], b1, b2, eps, wd, step_size, bc2s);
+    adam_step_ticket(step, gridDim.x);
+}
+
+constexpr int SNA_CHUNKS = 128;      // blocks per layer of the fused fix + Adam launch (the dot pass keeps SNF_CHUNKS partials per layer)
+// sn_grad_apply2_kernel with torch.optim.Adam's update in place of the store: the discriminator update of a single-rank
+// run never materialises d/d(weight_orig) -- g = fix(g0; uv0, sigma0) + fix(g1; uv1, sigma1) goes straight into m, v, p
+// (train_gan.py:154-158: backward, optimizer['discriminator'].step()).  `ticket_total` = blocks of ALL launches of the
+// step (the layer tables of the two gradient buckets): the last of them bumps the step counter.
+__global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const float* __restrict__ g1, float* __restrict__ pw,
+                                        float* __restrict__ mo, float* __restrict__ vo,
+                                        const float* __restrict__ uv0, const float* __restrict__ uv1,
+                                        const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma0,
+                                        const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
+                                        float lr, float b1, float b2, float eps, float wd, int64_t* step, unsigned ticket_total) {
+    const double t = (double)(step[0] + 1);
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* A = g0 + L.w_off; const float* B = g1 + L.w_off;
+    float* P = pw + L.w_off; float* M = mo + L.w_off; float* V = vo + L.w_off;
+    if (L.rows == 0) {
+        const int per = (L.cols + SNA_CHUNKS - 1) / SNA_CHUNKS;
+        const int i0 = blockIdx.y * per, i1 = (i0 + per < L.cols) ? i0 + per : L.cols;
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) adam_elem(P, M, V, i, A[i] + B[i], b1, b2, eps, wd, step_size, bc2s);
+    } else {
+        const float* ua = uv0 + L.u_off; const float* va = uv0 + L.v_off;
+        const float* ub = uv1 + L.u_off; const float* vb = uv1 + L.v_off;
+        const float sa = sigma0[blockIdx.x], sb = sigma1[blockIdx.x];
+        float da = 0.f, db = 0.f;
+        for (int k = 0; k < SNF_CHUNKS; ++k) {
+            da += partial[(size_t)blockIdx.x * SNF_CHUNKS + k];
+            db += partial[((size_t)nlayers + blockIdx.x) * SNF_CHUNKS + k];
+        }
+        da /= sa; db /= sb;
+        const float ia = 1.f / sa, ib = 1.f / sb;
+        const size_t n = (size_t)L.rows * L.cols;
+        const size_t per = (n + SNA_CHUNKS - 1) / SNA_CHUNKS;
+        const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
+        for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            const int r = (int)(i / L.cols), c = (int)(i - (size_t)r * L.cols);
+            const float oa = (A[i] - da * ua[r] * va[c]) * ia;
+            const float ob = (B[i] - db * ub[r] * vb[c]) * ib;
+            adam_elem(P, M, V, i, oa + ob, b1, b2, eps, wd, step_size, bc2s);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
+        const unsigned prev = atomicAdd(ticket, 1u);
+        if (prev == ticket_total - 1) { *ticket = 0u; step[0] += 1; }
     }
 }
-__global__ void step_inc_kernel(int64_t* step) { step[0] += 1; }
 
 }  // namespace
 
@@ -1021,8 +1090,9 @@ static int sn_power_iter_impl(const float* w_base, float* uv_base, const mcgen_s
     MCGEN_CHECK(max_cols * 4 <= 60 * 1024, "sn_power_iter: layers wider than 15360 columns are not supported");
     const int t_off = SN_RS * max_cols, ws_stride = t_off + max_rows;
     if (do_iter) {
-        hipLaunchKernelGGL(sn_k1_wtu, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride);
-        hipLaunchKernelGGL(sn_k2_v, dim3(nlayers), dim3(256), max_cols * 4, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, uv_snap);
+        // (wide blocks: these kernels are chains of dependent L2 round trips, a column per thread keeps each chain at one trip)
+        hipLaunchKernelGGL(sn_k1_wtu, dim3(nlayers, SN_RS), dim3(512), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride);
+        hipLaunchKernelGGL(sn_k2_v, dim3(nlayers), dim3(1024), max_cols * 4, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, uv_snap);
     }
     hipLaunchKernelGGL(sn_k3_wv, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride, t_off);
     hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, do_iter, sigma, uv_snap);
@@ -1159,8 +1229,22 @@ extern "C" int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype
 
 extern "C" int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int64_t* step, void* stream) {
-    MCGEN_CHECK(p && g && m && v && step && n > 0, "adam: bad arguments");
+    MCGEN_CHECK(p && g && m && v && step && n > 0, "adam: bad arguments (step: int64[2] = {counter, ticket = 0})");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step);
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, STREAM(stream), step);
     MCGEN_LAUNCH_CHECK("adam"); return 0;
+}
+extern "C" int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, float* p, float* m, float* v,
+                                      const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                      const float* sigma0, const float* sigma1, float* workspace,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
+                                      int ticket_layers, void* stream) {
+    MCGEN_CHECK(g_src0 && g_src1 && p && m && v && uv0 && uv1 && layers_dev && sigma0 && sigma1 && workspace && step && nlayers > 0,
+                "sn_fix_pair_adam: bad arguments (workspace: 2 * 32 * nlayers floats; step: int64[2] = {counter, ticket})");
+    MCGEN_CHECK(ticket_layers >= nlayers, "sn_fix_pair_adam: ticket_layers counts the layers of ALL launches of the step");
+    hipLaunchKernelGGL(sn_grad_dot2_kernel, dim3(nlayers, SNF_CHUNKS, 2), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, layers_dev,
+                       workspace, nlayers);
+    hipLaunchKernelGGL(sn_fix_pair_adam_kernel, dim3(nlayers, SNA_CHUNKS), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, m, v, uv0, uv1,
+                       layers_dev, sigma0, sigma1, workspace, nlayers, lr, beta1, beta2, eps, weight_decay, step,
+                       (unsigned)ticket_layers * SNA_CHUNKS);
+    MCGEN_LAUNCH_CHECK("sn_fix_pair_adam"); return 0;
 }

@@ -610,6 +610,10 @@ class DiscriminatorEngine:
             bwd += [(W(c2m), img(f'{i}.c2t', c2m, True), True, 1, c2m.idx, a),
                     (W(c1m), img(f'{i}.c1t', c1m, True), True, 1, c1m.idx, 1.0)]
         self._prep_fwd, self._prep_bwd = ops.PrepBatch(fwd, dt), ops.PrepBatch(bwd, dt)
+        # training passes build both sets in ONE launch at the start of the forward (same sigma): the backward pass that
+        # follows finds its transposed images ready (`_bwd_sigma` remembers whose they are)
+        self._prep_all = ops.PrepBatch(fwd + bwd, dt)
+        self._bwd_sigma = None
 
     def _ensure_preps(self):
         if self._prep_fwd is None or self._prep_fwd.dtype != self.dtype or not self._prep_fwd.valid():
@@ -647,7 +651,7 @@ class DiscriminatorEngine:
     def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
         sigma, uv = self._power_iter(train)
         codes = self._codes.run(indicator)
-        ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None}
+        ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None, 'train': train}
         return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
 
     def pair_codes(self, ind2: Tensor):
@@ -710,7 +714,11 @@ class DiscriminatorEngine:
         n = x_nchw.shape[0]
         sigma = ctx['sigma']
         self._ensure_preps()
-        self._prep_fwd.run(sigma)                 # every W / sigma image of this pass in one launch
+        if ctx.get('train', True):
+            self._prep_all.run(sigma)             # every W / sigma image of this pass, forward and transposed, in one launch
+            self._bwd_sigma = sigma
+        else:
+            self._prep_fwd.run(sigma)
         I = self.img
         img = x_nchw.t if isinstance(x_nchw, Nhwc) else ops.to_nhwc(x_nchw.detach().contiguous(), dt)
         if img.dtype != dt:
@@ -800,7 +808,7 @@ class DiscriminatorEngine:
         return self._bk
 
     def backward_iter(self, ctx, dlogit: Tensor, gflat: Optional[Tensor], accumulate: bool, need_input_grad: bool,
-                      split: bool = True):
+                      split: bool = True, defer_fix: bool = False):
         """dlogit [N] fp32.  (`split` False: one gradient bucket, handed out at the end.)  Parameter gradients (w.r.t. weight_orig and the biases) are written or
         added into `gflat` (flat, laid out like ``flat_p``; None skips them, e.g. in the generator
         step).  A generator: yields (lo, hi) each time gflat[lo:hi] is final -- the late bucket (tail + blocks
@@ -855,7 +863,9 @@ class DiscriminatorEngine:
         cut = self.bucket_cut()
         split = split and cut > 0                      # (a single residual block: one bucket)
         self._ensure_preps()
-        self._prep_bwd.run(sigma)                 # transposed W / sigma images of THIS pass's sigma
+        if self._bwd_sigma is not sigma:          # (another forward rebuilt the images since this pass's own)
+            self._prep_bwd.run(sigma)             # transposed W / sigma images of THIS pass's sigma
+            self._bwd_sigma = sigma
         I = self.img
         tl = self.sn_of[self.tail_lin]
         sg_t = sigma[tl.idx:tl.idx + 1]
@@ -927,8 +937,14 @@ class DiscriminatorEngine:
             raise
         red.__exit__(None, None, None)
         if want_w:
-            if not (_BUCKETS and split):
-                fix(bk['hi'], bk['i_cut'])          # single bucket: the late layers were not fixed up mid-pass
-            fix(bk['lo'], 0)
+            if defer_fix and pair is not None and not (_BUCKETS and split) and not accumulate:
+                # the caller finishes the update itself (FusedAdam.step_fused_sn_pair: fix-up + Adam in one launch per table):
+                # hand it the raw per-half gradients and the spectral-norm state of the two forwards; gflat stays unwritten
+                self.pending_fix = {'g0': passes[0][1], 'g1': passes[1][1], 'uv0': uv, 'uv1': pair['uv2'], 'sigma0': sigma,
+                                    'sigma1': pair['sigma2'], 'tables': [(bk['hi'], bk['i_cut']), (bk['lo'], 0)]}
+            else:
+                if not (_BUCKETS and split):
+                    fix(bk['hi'], bk['i_cut'])      # single bucket: the late layers were not fixed up mid-pass
+                fix(bk['lo'], 0)
             yield ((0, bk['off_cut'], True) if (_BUCKETS and split) else (0, fp.numel(), True))
         return dimg

@@ -32,6 +32,7 @@ from ._tuning import flag as _flag
 _NHWC_PAIR = _flag('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images stay NHWC (0: through NCHW fp32, as round 1)
 _PAIR_D = _flag('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
 _GROUP_G = _flag('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
+_FUSE_D_ADAM = _flag('MCGEN_FUSE_D_ADAM', '1') != '0'     # single rank: spectral-norm gradient fix + Adam of a paired D update in one launch
 
 
 class FusedAdam:
@@ -43,7 +44,8 @@ class FusedAdam:
         flat = self.fs.ensure()
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+        self._step_buf = torch.zeros(2, dtype=torch.int64, device=flat.device)     # {step counter, launch ticket} (ops.adam)
+        self.step_count = self._step_buf[:1]
 
     def hyper(self):
         """The hyper-parameters a launch bakes in as kernel arguments (a captured HIP graph replays the values it was
@@ -55,7 +57,20 @@ class FusedAdam:
 
     def step(self, gflat: torch.Tensor):
         flat = self.fs.ensure()
-        ops.adam(flat, gflat, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)
+        ops.adam(flat, gflat, self.m, self.v, self._step_buf, self.lr, self.betas, self.eps, self.wd)
+        for p in self.fs.tensors:
+            _bump(p)
+
+    def step_fused_sn_pair(self, pending):
+        """The discriminator's update straight from the raw per-half gradients of a paired pass (DiscriminatorEngine.
+        backward_iter(defer_fix=True)): spectral-norm fix + Adam in one launch per layer table (ops.sn_fix_pair_adam)."""
+        flat = self.fs.ensure()
+        tables = [t for t in pending['tables'] if t[0][1] > 0]
+        total = sum(t[0][1] for t in tables)
+        for (table, nl), sg_off in tables:
+            ops.sn_fix_pair_adam(pending['g0'], pending['g1'], flat, self.m, self.v, pending['uv0'], pending['uv1'], table, nl,
+                                 pending['sigma0'][sg_off:], pending['sigma1'][sg_off:], self._step_buf, self.lr, self.betas,
+                                 self.eps, self.wd, total)
         for p in self.fs.tensors:
             _bump(p)
 
@@ -191,7 +206,7 @@ class GANTrainer:
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
-    def d_compute_iter(self, img, ind, fake, ind2=None, x2=None, codes=None):
+    def d_compute_iter(self, img, ind, fake, ind2=None, x2=None, codes=None, fuse=False):
         """`fake`: this update's generated batch (NCHW fp32, detached).  `ind2` (optional): the indicator twice,
         [2N, modes] -- constant over the D updates of an iteration, so the caller builds it once.  `x2` (optional, instead
         of img / fake): real (+) fake as `pair_buffer` / `pair_set_fake` left them."""
@@ -205,7 +220,10 @@ class GANTrainer:
             n = ind.shape[0]
             lg = logits.view(-1)
             self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
-            yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False, split=self.world > 1)
+            # `fuse` (single rank): the raw per-half gradients stay as they are -- d_apply turns them into the update in one
+            # fused launch per layer table (spectral-norm fix + Adam) and self.grad_d is not written
+            yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False, split=self.world > 1,
+                                               defer_fix=fuse and self.world == 1)
             return
         d_real, ctx_r = self.deng.forward(img, ind, True)
         d_fake, ctx_f = self.deng.forward(fake, ind, True)
@@ -219,7 +237,12 @@ class GANTrainer:
         return self.loss_d
 
     def d_apply(self):
-        self.opt_d.step(self.grad_d)
+        pending = getattr(self.deng, 'pending_fix', None)
+        if pending is not None:
+            self.deng.pending_fix = None
+            self.opt_d.step_fused_sn_pair(pending)
+        else:
+            self.opt_d.step(self.grad_d)
 
     def g_compute_iter(self, ind, z):
         fake, gctx = self.geng.forward(z, ind, True, nhwc=_NHWC_PAIR)  # (engine to engine: images and their gradient stay NHWC)
@@ -238,7 +261,7 @@ class GANTrainer:
         self.geng.refresh_images(force=True)
 
     def d_update(self, img, ind, fake, ind2=None, x2=None, codes=None):
-        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2, x2, codes):
+        for lo, hi, _last in self.d_compute_iter(img, ind, fake, ind2, x2, codes, fuse=_FUSE_D_ADAM):
             self._reduce_bucket(self.grad_d, lo, hi)
         self._join_comm()
         self.d_apply()
@@ -394,8 +417,8 @@ class GraphedGANTrainer(GANTrainer):
                     lo, hi, last = next(gen)
                 graphs.append((gk, (lo, hi)))
             return graphs
-        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2, codes=self.s_codes) if _NHWC_PAIR else
-                                    self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2))
+        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2, codes=self.s_codes, fuse=_FUSE_D_ADAM)
+                                    if _NHWC_PAIR else self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2, fuse=_FUSE_D_ADAM))
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_zd.normal_()
         with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):

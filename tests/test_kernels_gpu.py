@@ -463,12 +463,12 @@ def test_dtail_hinge_tanh_adam():
     p = _rnd(g, 1000).requires_grad_(True)
     opt = torch.optim.Adam([p], lr=2e-4, betas=(0.5, 0.999))
     pg, m, v = p.detach().clone().cuda(), torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
-    step = torch.zeros(1, dtype=torch.int64, device='cuda')
+    step = torch.zeros(2, dtype=torch.int64, device='cuda')          # {step counter, launch ticket}
     for _ in range(3):
         gr = _rnd(g, 1000)
         p.grad = gr.clone(); opt.step()
         ops.adam(pg, gr.cuda(), m, v, step, 2e-4, (0.5, 0.999))
-    assert int(step) == 3
+    assert step.tolist() == [3, 0]                                    # the last workgroup of each launch bumps the counter
     np.testing.assert_allclose(pg.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
 
 

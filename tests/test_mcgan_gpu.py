@@ -555,6 +555,47 @@ def test_compacted_grouped_pass_matches_dense(cfg_name):
         np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_discriminator_update_equals_fix_then_adam(dtype):
+    """trainer._FUSE_D_ADAM: on a single rank the paired discriminator update goes from the raw per-half gradients to the
+    parameters in one fused launch per layer table (spectral-norm fix-up + Adam, mcgen_sn_fix_pair_adam) instead of
+    fix-up -> gradient buffer -> Adam.  Same arithmetic per element: one train iteration either way leaves the same
+    losses, parameters and Adam moments to an fp32 rounding step, and the same step counters (small model, injected latents)."""
+    from mcgen_amd import trainer as T
+    gh, dh, modes = [32, 32, 32, 32], [32, 32, 32, 32], 10
+    sd = gu.procedural_state(gu.mcgan_shapes(gh, dh, modes), seed=78, num_mode=modes)
+    img, lab = gu.synthetic_batch(16, modes, seed=5)
+    img, lab = img.cuda(), lab.cuda()
+    zs = [z.cuda() for z in gu.latent_batches(6, 16, 128, seed=6)]
+
+    def run(flag):
+        old = T._FUSE_D_ADAM
+        T._FUSE_D_ADAM = flag
+        try:
+            m = _build(gh, dh, modes, 'CIFAR10', sd, dtype)
+            m.train(True)
+            tr = T.GANTrainer(m, modes)
+            d, g = tr.train_iteration(img, lab, zs)
+            return (float(d), float(g), {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()},
+                    tr.opt_d.m.cpu().clone(), tr.opt_d.v.cpu().clone(), tr.opt_d._step_buf.tolist())
+        finally:
+            T._FUSE_D_ADAM = old
+    d1, g1, s1, m1, v1, st1 = run(True)
+    d0, g0, s0, m0, v0, st0 = run(False)
+    assert st1 == st0 == [5, 0]
+    # (the two kernels contract the same expressions into different FMAs: equal to an fp32 rounding step, not bitwise)
+    # bf16: a last-bit difference in a parameter can flip the bf16 rounding of its weight image in the NEXT update
+    rel = 2e-6 if dtype == torch.float32 else 2e-3
+    np.testing.assert_allclose([d1, g1], [d0, g0], rtol=rel, atol=rel)
+    for a_, b_ in ((m1, m0), (v1, v0)):
+        assert float((a_ - b_).abs().max()) <= rel * float(b_.abs().max()) + 1e-12
+    for k in s1:
+        # (generator: a conv bias in front of a BatchNorm has an exact-zero gradient, so Adam turns the SIGN of its rounding
+        # residue into a step of ~0.6 lr -- DESIGN.md section 2; the discriminator, whose update this test is about, is tight)
+        tol = rel * (1 + float(s0[k].abs().max())) if k.startswith('discriminator.') else 3e-4
+        assert float((s1[k] - s0[k]).abs().max()) <= tol, k
+
+
 def test_graphed_trainer_full_width_bf16_matches_eager():
     """The path bench.py times, at its real size: GraphedGANTrainer at full width, bf16, B = 128 (grouped 5 N generator pass
     with compacted activations, pipelined tiles) captures into HIP graphs -- the compacted pitches are read on the host

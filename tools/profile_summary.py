@@ -32,6 +32,8 @@ def bench_name(k: str):
         return f'conv_fused<bf16,{m.group(2)},{m.group(3)},{m.group(1)}>'
     if 'wgrad_reduce' in k:
         return None
+    if 'wgrad_multi_kernel' in k:                               # several 3x3 layers of a pass in one launch (bf16 only)
+        return 'wgrad_multi<bf16,3>'
     m = re.search(r'wgrad_ring_kernel(?:ILi|<)(\d+)', k)        # bf16-only LDS-DMA ring form
     if m:
         return f'wgrad<bf16,{m.group(1)}>'
