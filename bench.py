@@ -382,6 +382,7 @@ def main():
                     help='re-load the initial training state every this many iterations (0 = never, the default: with the '
                          "generator-drawn pool the discriminator loss stays in 0.1-1.2 over 600+ iterations); the copies run "
                          'inside the timed region')
+    ap.add_argument('--grad-bf16', action='store_true', help='N > 1: gradient buckets cross the links as bf16 (off: fp32, as the reference sums them)')
     ap.add_argument('--roofline-passes', type=int, default=5, help='instrumented eager iterations the roofline object averages')
     a = ap.parse_args()
 
@@ -444,7 +445,8 @@ def main():
     torch.manual_seed(100 + rank)
 
     log('model built')
-    tr = GraphedGANTrainer(model, classes, dist_group=group, world_size=world)
+    tr = GraphedGANTrainer(model, classes, dist_group=group, world_size=world,
+                           grad_wire_dtype=torch.bfloat16 if a.grad_bf16 else None)
     graphed = False
     if not a.no_graph:
         graphed = try_capture(lambda: tr.capture(img, lab, warmup=1), world, dev)
@@ -464,7 +466,7 @@ def main():
     # losses of EVERY iteration are kept (`loss_trace`) to show that the step never degenerates into all-zero hinge
     # gradients (measured with the default pool: D_loss 0.1-1.2 over 625 iterations without any reset).
     snap = tr.device_snapshot()
-    total_its = a.warmup + a.steps + max(0, a.sustain_steps)
+    total_its = a.warmup + a.steps + max(0, a.sustain_steps) + (5 if world > 1 else 0)
     trace = torch.zeros(total_its + 1, 2, device=dev)
     it = 0
 
@@ -505,6 +507,16 @@ def main():
         barrier()
         sustained = 1e3 * (time.perf_counter() - t1) / a.sustain_steps
         log(f'sustained check: {sustained:.3f} ms/step over {a.sustain_steps} steps')
+    # N > 1: how much of the gradient all-reduce time hides under the backward pass (a few extra, untimed iterations)
+    overlap = None
+    if world > 1:
+        barrier()
+        tr.overlap_begin()
+        n_ov = 5
+        for _ in range(n_ov):
+            step()
+        overlap = {k: v / n_ov for k, v in tr.overlap_end().items()}
+        barrier()
     tr_host = trace[:it].cpu()
     timed_tr = tr_host[a.warmup:a.warmup + a.steps]
     loss_trace = {
@@ -551,6 +563,10 @@ def main():
             'step_mfma_frac': value / world * FLOP_PER_IMAGE[a.workload] / (PEAK_TFLOPS[a.dtype] * 1e12),
             'last_losses': losses, 'loss_trace': loss_trace, 'sustained_ms_per_step': sustained, 'sustain_steps': a.sustain_steps,
             'data_pool': {'batches': pool, 'reset_every': a.reset_every, 'real_data': a.real_data},
+            # rank 0's view, per iteration: comm_us = time its gradient all-reduces ran, overlap_us = the part hidden under
+            # the backward pass, exposed_us = the part the optimizer step waited for (None on one GPU)
+            'overlap_us': overlap['overlap_us'] if overlap else None, 'comm': overlap,
+            'grad_wire_dtype': 'bf16' if a.grad_bf16 else 'f32',
             'tuning_switches': dict(_tuning_active()),
             'roofline': attach_traffic(roofline, a.workload, a.batch, a.dtype), 'cpu_baseline': cpu,
         }

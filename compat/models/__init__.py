@@ -18,3 +18,4 @@ from mcgen_amd.models.mcglow import mcglow  # noqa: F401,E402
 from mcgen_amd.models.mcpixelcnn import mcpixelcnn  # noqa: F401,E402
 from mcgen_amd.models.mcvae import mcvae  # noqa: F401,E402
 from mcgen_amd.models.vqvae import vqvae  # noqa: F401,E402
+from mcgen_amd.models.classifier import classifier, Classifier  # noqa: F401,E402

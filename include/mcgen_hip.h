@@ -449,6 +449,11 @@ int mcgen_gated_bwd_apply(void* ds, const void* s, const float* sums, const floa
  * (mcpixelcnn.py:37-40,57-60 horiz_resid; mcvae.py:17-35 ResBlock; mcvae.py:40-48,86-92 stage activations) */
 int mcgen_affine_code_res(const void* x, const float* scale, const float* shift, const float* code, const void* res,
                           void* y, int dtype, int N, int HW, int C, int pre_relu, int post_relu, void* stream);
+/* y[n, ho, wo, c] = max over the 2x2 window of relu(x * scale[c] + shift[c]): Conv -> BatchNorm2d (eval) -> ReLU -> MaxPool2d(2)
+ * of the COIL100 / Omniglot feature network behind IS / FID (models/classifier.py:17-29, metrics/metrics.py:49-62,89-113);
+ * x is [N, 2 Ho, 2 Wo, C], C a multiple of 8 (padding channels: scale = shift = 0). */
+int mcgen_affine_relu_maxpool2(const void* x, const float* scale, const float* shift, void* y, int dtype,
+                               int N, int Ho, int Wo, int C, void* stream);
 /* backward of such a tail, pass 1: g' = g * [y_post > 0] (if y_post; also written to g_gated = the residual's gradient),
  * dz = g' * code * [x*scale + shift > 0 if pre_relu], and the BatchNorm-backward partial sums of dz over x */
 int mcgen_code_bn_stats(const void* g, const float* code, const void* x, const float* mean, const float* rstd,

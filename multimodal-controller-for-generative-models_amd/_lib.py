@@ -110,6 +110,7 @@ SYMBOLS = {
     'mcgen_gated_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_gated_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i64, _i, _vp]),
     'mcgen_affine_code_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_affine_relu_maxpool2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_code_bn_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'mcgen_cross_entropy': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i64, _i, _i, _vp]),
     'mcgen_wgrad_reduce_batch': (_i, [_vp, _i, _vp]),

@@ -205,6 +205,31 @@ __global__ void affine_code_res_kernel(const T* __restrict__ x, const float* __r
         Elem<T>::store8(y + p * C + c, v);
     }
 }
+// ---- classifier block tail (models/classifier.py:17-29): y = MaxPool2d(2)(relu(x * sc + sh)), eval-mode BatchNorm as an affine --------
+template <typename T>
+__global__ void affine_relu_maxpool2_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                            T* __restrict__ y, int N, int Ho, int Wo, int C) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    const int W = 2 * Wo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8; size_t t = i / cv;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho); const size_t n = t / Ho;
+        float a[8], b[8], o[8];
+        load8f(sc + c, a); load8f(sh + c, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;                           // max over relu(.) >= 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[8];
+            Elem<T>::load8(x + (((n * 2 * Ho + 2 * ho + (q >> 1)) * W) + 2 * wo + (q & 1)) * C + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], fmaf(v[j], a[j], b[j]));
+        }
+        Elem<T>::store8(y + i * 8, o);
+    }
+}
 // its backward, pass 1: dz = g * code (written out) and the BN-backward partial sums over x
 // gates: y_post != NULL -> g *= [y_post > 0] (the tail ended in a ReLU; the gated g is also the residual's gradient,
 // written to g_gated when given); pre_relu -> dz *= [x * sc + sh > 0]
@@ -397,6 +422,15 @@ extern "C" int mcgen_affine_code_res(const void* x, const float* scale, const fl
         hipLaunchKernelGGL(affine_code_res_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, scale, shift, code, (const float*)res, (float*)y, pixels, HW, C, pre_relu, post_relu),
         hipLaunchKernelGGL(affine_code_res_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, scale, shift, code, (const bf16_t*)res, (bf16_t*)y, pixels, HW, C, pre_relu, post_relu));
     MCGEN_LAUNCH_CHECK("affine_code_res"); return 0;
+}
+extern "C" int mcgen_affine_relu_maxpool2(const void* x, const float* scale, const float* shift, void* y, int dtype,
+                                          int N, int Ho, int Wo, int C, void* stream) {
+    MCGEN_CHECK(x && scale && shift && y && N > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "affine_relu_maxpool2: bad arguments (C a multiple of 8)");
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(affine_relu_maxpool2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)x, scale, shift, (float*)y, N, Ho, Wo, C),
+        hipLaunchKernelGGL(affine_relu_maxpool2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, scale, shift, (bf16_t*)y, N, Ho, Wo, C));
+    MCGEN_LAUNCH_CHECK("affine_relu_maxpool2"); return 0;
 }
 extern "C" int mcgen_code_bn_stats(const void* g, const float* code, const void* x, const float* mean, const float* rstd,
                                    void* dz, float* partials, int blocks, int dtype, int N, int HW, int C,

@@ -31,11 +31,20 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local
 
 
-def allreduce_mean_(flat: torch.Tensor, world: int, group=None) -> torch.Tensor:
-    """In-place average of one flat gradient bucket over the ranks (no-op for world == 1)."""
+def allreduce_mean_(flat: torch.Tensor, world: int, group=None, wire_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """In-place average of one flat gradient bucket over the ranks (no-op for world == 1).
+    `wire_dtype` = torch.bfloat16 (SURVEY 8(e) "optional bf16 gradient compression"): the bucket crosses the links as
+    bf16 -- half the bytes per xGMI link of the ring -- scaled by 1 / world BEFORE the cast so that the sum stays in
+    range; the averaged gradient carries bf16's 8 significant bits, so this is opt-in (default: fp32 on the wire, the
+    reference's nn.DataParallel sums fp32 gradients, train_gan.py:96-98)."""
     if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.mul_(1.0 / world)
+        if wire_dtype is not None and wire_dtype != flat.dtype:
+            wire = (flat * (1.0 / world)).to(wire_dtype)
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(wire)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.mul_(1.0 / world)
     return flat
 
 

@@ -1121,6 +1121,17 @@ def affine_code_res(x: Tensor, scale, shift, code: Optional[Tensor], res: Option
     return y
 
 
+def affine_relu_maxpool2(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
+    """MaxPool2d(2)(relu(x * scale + shift)) on [N, H, W, C] (mcgen_affine_relu_maxpool2)."""
+    n, h, w, c = x.shape
+    if h % 2 or w % 2 or scale.numel() != c or shift.numel() != c:
+        raise _lib.McgenError(f'affine_relu_maxpool2: even H, W and [C] affine vectors, got {tuple(x.shape)} / {scale.numel()}')
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    check(_lib.load().mcgen_affine_relu_maxpool2(_p(x), _f32(scale), _f32(shift), _p(y), _dt(x.dtype), n, h // 2, w // 2, c, _stream()),
+          'affine_relu_maxpool2')
+    return y
+
+
 def code_bn_bwd(g: Tensor, code: Optional[Tensor], x: Tensor, scale, mean, rstd, dgamma: Tensor, dbeta: Tensor,
                 shift=None, pre_relu: bool = False, y_post: Optional[Tensor] = None, want_gated: bool = False):
     """Backward of y = post_relu?( pre_relu?(BN(x)) * code + res ) w.r.t. x (training-mode BatchNorm); fills

@@ -122,8 +122,10 @@ class FusedAdam:
 
 class GANTrainer:
     def __init__(self, model, classes: int, lr=2e-4, betas=(0.5, 0.999), d_iters: int = 5, g_iters: int = 1,
-                 dist_group=None, world_size: int = 1):
+                 dist_group=None, world_size: int = 1, grad_wire_dtype: Optional[torch.dtype] = None):
         self.model = model
+        self.grad_wire_dtype = grad_wire_dtype            # torch.bfloat16: gradient buckets cross the links as bf16 (dist.allreduce_mean_)
+        self._ov = None                                   # overlap bookkeeping (overlap_begin / overlap_end)
         self.classes = classes
         self.d_iters, self.g_iters = d_iters, g_iters
         self.geng = model.generator._engine()
@@ -156,17 +158,46 @@ class GANTrainer:
             cs = self._comm_stream()
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                allreduce_mean_(g[lo:hi], self.world, self.group)
+                if self._ov is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(cs)
+                allreduce_mean_(g[lo:hi], self.world, self.group, self.grad_wire_dtype)
+                if self._ov is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(cs)
+                    self._ov['pending'].append((e0, e1))
 
     def _join_comm(self):
         if self.world > 1:
+            if self._ov is not None:
+                j = torch.cuda.Event(enable_timing=True); j.record(torch.cuda.current_stream())
+                self._ov['joins'].append((j, self._ov['pending'])); self._ov['pending'] = []
             torch.cuda.current_stream().wait_stream(self._comm_stream())
+
+    # ---- how much of the gradient exchange runs under the backward pass ----------------------------------------------
+    def overlap_begin(self):
+        """Start timing every bucket's all-reduce (events on the communication stream) against the moment the compute
+        stream reaches the join in front of the optimizer step."""
+        self._ov = {'pending': [], 'joins': []}
+
+    def overlap_end(self):
+        """-> {'comm_us': time the all-reduces ran, 'overlap_us': the part of it that ran while the compute stream was
+        still busy with the rest of the backward pass (hidden), 'exposed_us': the rest}, summed over the iterations since
+        overlap_begin()."""
+        torch.cuda.synchronize()
+        ov, self._ov = self._ov, None
+        comm = hidden = 0.0
+        for j, pend in (ov['joins'] if ov else []):
+            for e0, e1 in pend:
+                dur = e0.elapsed_time(e1) * 1e3
+                before_join = e0.elapsed_time(j) * 1e3               # < 0: the bucket started after compute reached the join
+                comm += dur
+                hidden += max(0.0, min(dur, before_join))
+        return {'comm_us': comm, 'overlap_us': hidden, 'exposed_us': comm - hidden}
 
     def _allreduce(self, g: torch.Tensor):
         """Whole-buffer exchange on the compute stream (kept for callers that do not bucket)."""
         if self.world > 1:
             from .dist import allreduce_mean_
-            allreduce_mean_(g, self.world, self.group)
+            allreduce_mean_(g, self.world, self.group, self.grad_wire_dtype)
 
     # ---- the generator passes of the discriminator updates -----------------------------------------
     def fake_groups(self, n: int) -> int:

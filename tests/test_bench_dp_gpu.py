@@ -27,6 +27,10 @@ def test_bench_two_ranks_one_card(workload):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
     assert out['config']['global_batch'] == 32 and out['value'] > 0
+    if workload == 'cifar10':
+        # N > 1 line: the gradient exchange's own time per iteration and the part of it hidden under the backward pass
+        assert out['comm'] is not None and out['comm']['comm_us'] > 0
+        assert 0 <= out['overlap_us'] <= out['comm']['comm_us'] + 1e-6 and out['grad_wire_dtype'] == 'f32'
 
 
 @pytest.mark.parametrize('workload', ['cifar10', 'coil100'])

@@ -17,14 +17,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+    dev_idx = rank if backend == 'nccl' else 0            # RCCL: one rank per GPU; gloo: both ranks share cuda:0
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev_idx), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     import torch.nn.functional as F
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(dev_idx)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_idx))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from mcgen_amd import models
         from mcgen_amd.config import cfg, process_control
@@ -93,13 +97,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_card_gradients_and_replay():
+def _run_two_ranks(backend):
     import torch.multiprocessing as mp
     world = 2
-    port = 29700 + (os.getpid() % 200)
+    port = 29700 + (os.getpid() % 200) + (300 if backend == 'nccl' else 0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -119,3 +123,14 @@ def test_two_ranks_one_card_gradients_and_replay():
         assert results[rank]['replicas_identical']
     for k in ref:                                     # every rank ends with the identical averaged bucket
         assert np.array_equal(results[0][k], results[1][k]), k
+
+
+def test_two_ranks_one_card_gradients_and_replay():
+    _run_two_ranks('gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='the RCCL path needs two GPUs (one rank per device); the 1-GPU pool skips it')
+def test_two_ranks_two_cards_nccl():
+    """The same checks over RCCL (backend "nccl", one rank per GPU, xGMI between them): bucketed all-reduce on the
+    communication stream under the backward pass, bit-identical replicas after graph-replayed iterations."""
+    _run_two_ranks('nccl')

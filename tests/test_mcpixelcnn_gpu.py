@@ -216,6 +216,51 @@ def test_pixelcnn_bf16_tracks_fp32():
     assert max(abs(a - b) for a, b in zip(losses, d['losses'])) < 5e-2, (losses, d['losses'])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mcpixelcnn_full_size_digest(dtype):
+    """BASELINE configs[4] as the reference runs it (utils.py:139-143: 15 layers, hidden 128, 512 codes, 10 modes --
+    6,367,616 parameters) on the HIP path against the reference-generated mcpixelcnn_full_digest.npz (procedural weights,
+    B=8): loss, logits digest and sample of the first training forward, then two train_pixelcnn.py steps."""
+    import ast
+    from mcgen_amd import models
+    from mcgen_amd.config import cfg
+    from mcgen_amd.trainer import PixelCNNTrainer
+    d = gu.load_npz('mcpixelcnn_full_digest.npz')
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(d['shape_keys'], d['shape_vals'])}
+    f32 = dtype == torch.float32
+
+    def build():
+        cfg.update(model_name='mcpixelcnn', device='cuda', classes_size=10, controller_rate=0.5)
+        cfg['pixelcnn'] = {'num_layer': 15, 'hidden_size': 128, 'num_embedding': 512}
+        m = models.mcpixelcnn()
+        m.load_state_dict(gu.procedural_state_generic(shapes, seed=4242))
+        return m.cuda().set_compute_dtype(dtype)
+    m = build()
+    assert sum(p.numel() for p in m.parameters()) == 6367616
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
+    m.train(True)
+    with torch.no_grad():
+        out = m({'img': codes, 'label': lab})
+    print('first training-mode loss', float(out['loss']), 'reference', float(d['losses'][0]))
+    assert abs(float(out['loss']) - float(d['losses'][0])) < (2e-4 if f32 else 5e-2)
+    lg = out['logits'].float()
+    assert _rel(lg[:, ::16, ::2, ::2], d['logits0_sample']) < (1e-3 if f32 else 6e-2)
+    got, ref = gu.checksum(lg.cpu()), d['logits0_digest']
+    assert np.abs(got - ref).max() < (1e-3 if f32 else 3e-2) * ref[1], (got, ref)
+    tr = PixelCNNTrainer(build())
+    losses = [float(tr.train_iteration(codes, lab)) for _ in range(2)]
+    print('train losses', losses, 'reference', d['losses'])
+    assert abs(losses[0] - d['losses'][0]) < (2e-4 if f32 else 5e-2)
+    assert abs(losses[1] - d['losses'][1]) < (2e-2 if f32 else 1.5e-1)
+    if f32:
+        fin = tr.model.state_dict()
+        for k in d['final_keys']:
+            name = str(k)[len('final_digest/'):]
+            got, ref = gu.checksum(fin[name].float().cpu()), d[str(k)]
+            assert np.abs(got - ref).max() < 2e-3 * ref[1], (name, got, ref)
+
+
 def test_generate_autoregressive_greedy_vs_oracle():
     """MCGatedPixelCNN.generate (mcpixelcnn.py:103-112): 64 sequential eval-mode forwards through the mask-A im2col
     path.  Decoded greedily (argmax in place of the multinomial draw) the result is a deterministic function of the

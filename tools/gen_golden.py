@@ -582,7 +582,84 @@ def fx_mcglow_full():
     save('mcglow_full_digest.npz', **arrays)
 
 
-FIXTURES.update(mcgan_full_b128=fx_mcgan_full_b128, mcgan_coil_full=fx_mcgan_coil_full, mcglow_full=fx_mcglow_full)
+def fx_mcpixelcnn_full():
+    """BASELINE configs[4] as the reference runs it (utils.py:139-143): MCGatedPixelCNN with 15 layers, hidden 128,
+    512 codes, 10 modes (6,367,616 parameters) on 8x8 code maps; procedural weights (golden_util.
+    procedural_state_generic), B=8: logits digest + loss of the first training forward, two train_pixelcnn.py steps,
+    digests of a few final tensors."""
+    import models
+    cfg['model_name'] = 'mcpixelcnn'; cfg['device'] = 'cpu'; cfg['classes_size'] = 10; cfg['controller_rate'] = 0.5
+    cfg['pixelcnn'] = {'num_layer': 15, 'hidden_size': 128, 'num_embedding': 512}
+    torch.manual_seed(0)
+    model = models.mcpixelcnn(); model.train(True)
+    assert sum(p.numel() for p in model.parameters()) == 6367616
+    ref_sd = model.state_dict()
+    keys = sorted(ref_sd)
+    shapes = {k: tuple(ref_sd[k].shape) for k in keys}
+    model.load_state_dict(gu.procedural_state_generic(shapes, seed=4242))
+    arrays = {'shape_keys': np.array(keys), 'shape_vals': np.array([str(shapes[k]) for k in keys])}
+    g = torch.Generator().manual_seed(43)
+    codes = torch.randint(0, 512, (8, 8, 8), generator=g)
+    lab = torch.randint(0, 10, (8,), generator=g)
+    arrays['codes'] = codes.numpy(); arrays['label'] = lab.numpy()
+    first = _single_opt_steps(model, {'img': codes, 'label': lab}, 300, 2, arrays)
+    arrays['logits0_digest'] = gu.checksum(first['logits'].detach())
+    arrays['logits0_sample'] = first['logits'].detach().numpy()[:, ::16, ::2, ::2].copy()
+    fin = model.state_dict()
+    for k in ['layers.0.vert_stack.weight', 'layers.7.horiz_resid.weight', 'layers.14.gate_h.bn.running_var', 'output_conv.3.weight']:
+        if k in fin:
+            arrays['final_digest/' + k] = gu.checksum(fin[k].float())
+    arrays['final_keys'] = np.array([k for k in arrays if k.startswith('final_digest/')])
+    save('mcpixelcnn_full_digest.npz', **arrays)
+
+
+def fx_classifier():
+    """The feature network of IS / FID on COIL100 / Omniglot (models/classifier.py:14-52; metrics.py:49-62,89-113):
+    hidden [8, 16, 32, 64] (utils.py:185), evaluation mode, on both data shapes ([3,32,32] and Omniglot's [1,32,32]); weights from the reference's own
+    initialisation with non-trivial BatchNorm running statistics.  Outputs: features and logits of a batch, and the
+    Inception Score / FID the reference's formulas (metrics.py:75-82,139-161) give on them."""
+    import models
+    from scipy import linalg
+    arrays = {}
+    for tag, shape, classes in (('coil100', [3, 32, 32], 100), ('gray', [1, 32, 32], 40)):     # (Omniglot's shape; 40 of its 1623 classes keep the file small)
+        cfg['model_name'] = 'classifier'; cfg['device'] = 'cpu'; cfg['classes_size'] = classes; cfg['data_shape'] = shape
+        cfg['classifier'] = {'hidden_size': [8, 16, 32, 64]}
+        torch.manual_seed(5)
+        model = models.classifier()
+        g = torch.Generator().manual_seed(61)
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                    m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+        model.train(False)
+        arrays.update(np_state(model.state_dict(), f'{tag}/sd/'))
+        img = torch.rand(20, *shape, generator=g) * 2 - 1
+        real = torch.rand(24, *shape, generator=g) * 2 - 1
+        arrays[f'{tag}/img'] = img.numpy(); arrays[f'{tag}/real'] = real.numpy()
+        with torch.no_grad():
+            feat = model.feature({'img': img})
+            out = model({'img': img, 'label': torch.zeros(20, dtype=torch.long)})
+            rfeat = model.feature({'img': real})
+        arrays[f'{tag}/feature'] = feat.numpy(); arrays[f'{tag}/logits'] = out['label'].numpy()
+        pred = F.softmax(out['label'], dim=-1)                                    # metrics.py:61-62,75-81
+        py = pred.mean(0)
+        arrays[f'{tag}/inception_score'] = np.array(F.kl_div(py.log().view(1, -1).expand_as(pred), pred, reduction='batchmean').exp().item())
+        a, b = rfeat.numpy().astype(np.float64), feat.numpy().astype(np.float64)  # metrics.py:139-161
+        mu1, mu2 = a.mean(0), b.mean(0)
+        s1, s2 = np.cov(a, rowvar=False), np.cov(b, rowvar=False)
+        covmean, _ = linalg.sqrtm(s1.dot(s2), disp=False)
+        if not np.isfinite(covmean).all():
+            off = np.eye(s1.shape[0]) * 1e-6
+            covmean = linalg.sqrtm((s1 + off).dot(s2 + off))
+        covmean = covmean.real if np.iscomplexobj(covmean) else covmean
+        d = mu1 - mu2
+        arrays[f'{tag}/fid'] = np.array(d.dot(d) + np.trace(s1) + np.trace(s2) - 2 * np.trace(covmean))
+    save('classifier_small.npz', **arrays)
+
+
+FIXTURES.update(mcgan_full_b128=fx_mcgan_full_b128, mcgan_coil_full=fx_mcgan_coil_full, mcglow_full=fx_mcglow_full,
+                mcpixelcnn_full=fx_mcpixelcnn_full, classifier=fx_classifier)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
