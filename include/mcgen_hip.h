@@ -154,7 +154,7 @@ int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
  * steps).  Replaces, per backward pass, the autograd weight gradients of the block convolutions of mcgan.py:19,23,77,80,
  * 103-113.  Eligible (mcgen_wgrad_multi_ok != 0): bf16, ksize 3, square maps of side 8 / 16 / 32, Cout a multiple of 128,
  * seg.C a multiple of 64, N*H*W a multiple of 128, no statistics groups / compaction map. */
-#define MCGEN_WGRAD_MULTI_MAX 8
+#define MCGEN_WGRAD_MULTI_MAX 16
 int mcgen_wgrad_multi_ok(const mcgen_wgrad_t* p, int dtype);
 int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, void* stream);
 /* grad[master layout] (+)= alpha * sum_s slabs[s]; master layout = [Cout][Cin][k][k] with

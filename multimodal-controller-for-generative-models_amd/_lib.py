@@ -36,7 +36,7 @@ class Wgrad(C.Structure):
                 ('bias_slabs', C.c_void_p)]
 
 
-WGRAD_MULTI_MAX = 8        # MCGEN_WGRAD_MULTI_MAX (include/mcgen_hip.h)
+WGRAD_MULTI_MAX = 16       # MCGEN_WGRAD_MULTI_MAX (include/mcgen_hip.h)
 
 
 class WReduce(C.Structure):

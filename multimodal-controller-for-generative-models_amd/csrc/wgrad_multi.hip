@@ -28,8 +28,8 @@ constexpr int WB_XPITCH = WB_CI * 2 + 32;  // 160 B per window pixel: 8 consecut
 constexpr int WB_DROW = WB_CO * 2;         // 256 B per dy row
 constexpr int WB_ABUF = 32768, WB_DBUF = WB_BM * WB_DROW;    // one window buffer (<= 204 pixels x 160 B), one dy tile
 constexpr int WB_AFF = 2 * WB_ABUF + 2 * WB_DBUF;            // BatchNorm scale | shift of the tile's 64 channels: 2 x 256 B
-constexpr int WB_CODE = WB_AFF + 512;                        // code rows: 2 slots x 2 images x 256 B
-constexpr int WB_LDS = WB_CODE + 1024;                       // A0 A1 D0 D1 affine codes
+constexpr int WB_CODE = WB_AFF + 512;                        // code rows: 2 buffers x 8 images x 256 B (wave w brings image w % TI)
+constexpr int WB_LDS = WB_CODE + 2 * 8 * 256;                // A0 A1 D0 D1 affine codes
 
 static __device__ __forceinline__ s16x4 wb_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -47,28 +47,29 @@ struct WgMulti {
     int n;
 };
 
-// Geometry of a 128-pixel step on a (1 << LGH) x (1 << LGW) map: TH whole rows of one image, or TI whole images.
-template <int LGW, int LGH>
+// Geometry of a 128-pixel step on a (1 << LGH) x (1 << LGW) map: TH whole rows of one image, or TI whole images; KS x KS taps.
+template <int LGW, int LGH, int KS>
 struct WbGeo {
-    static constexpr int W = 1 << LGW, H = 1 << LGH, HW = W * H;
+    static constexpr int W = 1 << LGW, H = 1 << LGH, HW = W * H, HALO = KS >> 1, NTAP = KS * KS;
     static constexpr int TI = HW >= WB_BM ? 1 : WB_BM / HW;
     static constexpr int TH = HW >= WB_BM ? WB_BM / W : H;
     static constexpr int LGTHW = (HW >= WB_BM) ? 7 : LGW + LGH;        // log2(TH * W)
-    static constexpr int PR = TH + 2, PC = W + 2, PP = TI * PR * PC;
+    static constexpr int PR = TH + 2 * HALO, PC = W + 2 * HALO, PP = TI * PR * PC;
     static constexpr int NIX = (PP * 8 + WB_NT - 1) / WB_NT;            // 16-byte window units per thread
-    static_assert(PP * WB_XPITCH <= WB_ABUF - 128 && TI <= 2 && PR + 1 < 32, "window buffer");
+    static_assert(PP * WB_XPITCH <= WB_ABUF - 128 && TI <= 8 && PR + 1 < 32, "window buffer");
     static_assert(TH >= 2 || TI > 1, "tiles of a single row are not built (upsampled operands need even first rows)");
     // window position (pixel index) of tile pixel m, halo included
     static constexpr int winpos(int m) {
-        return ((m >> LGTHW) * PR + ((m & ((1 << LGTHW) - 1)) >> LGW) + 1) * PC + (m & (W - 1)) + 1;
+        return ((m >> LGTHW) * PR + ((m & ((1 << LGTHW) - 1)) >> LGW) + HALO) * PC + (m & (W - 1)) + HALO;
     }
 };
 
-template <int LGW, int LGH>
+template <int LGW, int LGH, int KS>
 static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, const int bx, const int by, const int bz,
                                                       const int splits, char* smem) {
-    using G = WbGeo<LGW, LGH>;
+    using G = WbGeo<LGW, LGH, KS>;
     constexpr int W = G::W, H = G::H, HW = G::HW, PR = G::PR, PC = G::PC, PP = G::PP, NIX = G::NIX, TI = G::TI;
+    constexpr int HALO = G::HALO, NTAP = G::NTAP;
     char* const ldsA = smem;
     char* const ldsD = smem + 2 * WB_ABUF;
 
@@ -98,7 +99,7 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
         const int pp = (tid + k * WB_NT) >> 3;
         const int ti = pp / (PR * PC), rem = pp - ti * (PR * PC);
         const int pr = rem / PC, pc = rem - pr * PC;
-        const int dh = pr - 1, w = pc - 1;
+        const int dh = pr - HALO, w = pc - HALO;
         const bool item = pp < PP;
         const bool colok = item && cok && w >= 0 && w < W;
         // (threads past the window's last unit store zeros into the buffer's spare 128 bytes: no branch around an item)
@@ -152,7 +153,7 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
 #pragma unroll
         for (int k = 0; k < NIX; ++k) {
             const int row = (x_pk[k] >> 16) & 31;                                      // window row + 1, 0 = never
-            const bool ok = row != 0 && (unsigned)(h0 + row - 2) < (unsigned)H;
+            const bool ok = row != 0 && (unsigned)(h0 + row - 1 - HALO) < (unsigned)H;
             const char* src = ok ? xb + (ptrdiff_t)x_off[k] * 2 : xs;                   // outside: any in-bounds address
             raw[k] = *reinterpret_cast<const u32x4*>(src);
         }
@@ -160,7 +161,7 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
             const int c = c0 + lane;
             const float* src = sg.code + (size_t)(n0 + wave) * sg.C + (c < sg.C ? c : 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ldsCode + ((i & 1) * 2 + wave) * 256), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ldsCode + ((i & 1) * 8 + wave) * 256), 4, 0, 0);
         }
     };
     // prologue + LDS store of the staged window: v -> max(v * sc + sh, relu ? 0 : -inf) * code, zeros outside the image
@@ -168,25 +169,22 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
         const int pix0 = tile_of(i) * WB_BM;
         const int h0 = (TI == 1) ? ((pix0 & (HW - 1)) >> LGW) : 0;
         char* dst = ldsA + (i & 1) * WB_ABUF;
-        float sc[8], sh[8], cd[TI][8];
+        float sc[8], sh[8];
         load8f(ldsAff + u8 * 8, sc); load8f(ldsAff + WB_CI + u8 * 8, sh);
-#pragma unroll
-        for (int t = 0; t < TI; ++t) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cd[t][e] = 1.f;
-            if (sg.code) load8f(reinterpret_cast<const float*>(ldsCode + ((i & 1) * 2 + t) * 256) + u8 * 8, cd[t]);
-        }
 #pragma unroll
         for (int k = 0; k < NIX; ++k) {
             const int row = (x_pk[k] >> 16) & 31, lo = x_pk[k] & 0xffff;
-            const bool ok = row != 0 && (unsigned)(h0 + row - 2) < (unsigned)H;
-            const bool second = TI > 1 && lo >= PR * PC * WB_XPITCH;                   // (TI <= 2: the window's second image)
+            const bool ok = row != 0 && (unsigned)(h0 + row - 1 - HALO) < (unsigned)H;
+            const int img = TI > 1 ? lo / (PR * PC * WB_XPITCH) : 0;                   // image of the window the unit belongs to
+            float cd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cd[e] = 1.f;
+            if (sg.code) load8f(reinterpret_cast<const float*>(ldsCode + ((i & 1) * 8 + (img < TI ? img : 0)) * 256) + u8 * 8, cd);
             union { bf16x8 h; u32x4 w; } o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float c0v = second ? cd[TI - 1][2 * e] : cd[0][2 * e], c1v = second ? cd[TI - 1][2 * e + 1] : cd[0][2 * e + 1];
-                const float v0 = fmaxf(fmaf(__uint_as_float(raw[k][e] << 16), sc[2 * e], sh[2 * e]), relu_lo) * c0v;
-                const float v1 = fmaxf(fmaf(__uint_as_float(raw[k][e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), relu_lo) * c1v;
+                const float v0 = fmaxf(fmaf(__uint_as_float(raw[k][e] << 16), sc[2 * e], sh[2 * e]), relu_lo) * cd[2 * e];
+                const float v1 = fmaxf(fmaf(__uint_as_float(raw[k][e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), relu_lo) * cd[2 * e + 1];
                 o.h[2 * e] = (bf16_t)v0; o.h[2 * e + 1] = (bf16_t)v1;
             }
 #pragma unroll
@@ -216,9 +214,9 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
     for (int c = 0; c < 4; ++c)
         doff[c] = m0 * WB_DROW + 32 * ((wa * 4 + c) ^ (m0 & 7)) + 8 * p4;
 
-    f32x4 acc[9][4];
+    f32x4 acc[NTAP][4];
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < NTAP; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
@@ -252,10 +250,10 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
         }
         // fragment reads one tap ahead of their MFMAs (two window fragments in registers: the register budget allows no more);
         // the dy fragments of a 32-pixel group are read with its first tap
-        constexpr int HALO0 = PC + 1;
+        constexpr int HALO0 = HALO * PC + HALO;
         auto rd_a = [&](int ks, int j) {
             const int g0 = (G::winpos(32 * ks) - HALO0) * WB_XPITCH, g1 = (G::winpos(32 * ks + 16) - HALO0) * WB_XPITCH;
-            const int tap = ((j / 3) * PC + (j % 3)) * WB_XPITCH;
+            const int tap = ((j / KS) * PC + (j % KS)) * WB_XPITCH;
             return wb_frag(A + g0 + tap, A + g1 + tap);
         };
         bf16x8 af = rd_a(0, 0);
@@ -266,10 +264,10 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
             for (int c = 0; c < 4; ++c)
                 df[c] = wb_frag(D + doff[c] + (32 * ks) * WB_DROW, D + doff[c] + (32 * ks + 16) * WB_DROW);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const bool last = (ks == WB_BM / 32 - 1) && (j == 8);
+            for (int j = 0; j < NTAP; ++j) {
+                const bool last = (ks == WB_BM / 32 - 1) && (j == NTAP - 1);
                 bf16x8 an = af;
-                if (!last) an = (j == 8) ? rd_a(ks + 1, 0) : rd_a(ks, j + 1);
+                if (!last) an = (j == NTAP - 1) ? rd_a(ks + 1, 0) : rd_a(ks, j + 1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[c], af, acc[j][c], 0, 0, 0);
                 af = an;
@@ -279,18 +277,18 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
     }
     // ---- slab[z][chunk][tap][co][32]: lane holds D[co = 4 lg + r][ci = l15] of (tap j, co fragment c)
     const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;
-    const size_t slab_elems = (size_t)nchunk * 9 * p.Cout_w * MCGEN_CK;
+    const size_t slab_elems = (size_t)nchunk * NTAP * p.Cout_w * MCGEN_CK;
     float* out = p.slabs + (size_t)bz * slab_elems;
     const int qc = by * 2 + (wb >> 1), col = (wb & 1) * 16 + l15;
     if (qc < nchunk) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
+        for (int j = 0; j < NTAP; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + (wa * 4 + c) * 16 + lg * 4 + r;
-                    if (co < p.Cout_w) out[(((size_t)qc * 9 + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][c][r];
+                    if (co < p.Cout_w) out[(((size_t)qc * NTAP + j) * p.Cout_w + co) * MCGEN_CK + col] = acc[j][c][r];
                 }
     }
     if (do_bias) {
@@ -310,10 +308,19 @@ void wgrad_multi_kernel(const WgMulti a) {
     const int gx = p.Cout_w / WB_CO, gy = p.seg.C / WB_CI;
     const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
     const int lgw = 31 - __builtin_clz(p.W);
-    switch (lgw) {
-        case 5: wgrad_big_body<5, 5>(p, bx, by, bz, p.splits, smem); break;
-        case 4: wgrad_big_body<4, 4>(p, bx, by, bz, p.splits, smem); break;
-        default: wgrad_big_body<3, 3>(p, bx, by, bz, p.splits, smem); break;
+    if (p.seg.ksize == 3) {
+        switch (lgw) {
+            case 5: wgrad_big_body<5, 5, 3>(p, bx, by, bz, p.splits, smem); break;
+            case 4: wgrad_big_body<4, 4, 3>(p, bx, by, bz, p.splits, smem); break;
+            default: wgrad_big_body<3, 3, 3>(p, bx, by, bz, p.splits, smem); break;
+        }
+    } else {
+        switch (lgw) {
+            case 5: wgrad_big_body<5, 5, 1>(p, bx, by, bz, p.splits, smem); break;
+            case 4: wgrad_big_body<4, 4, 1>(p, bx, by, bz, p.splits, smem); break;
+            case 3: wgrad_big_body<3, 3, 1>(p, bx, by, bz, p.splits, smem); break;
+            default: wgrad_big_body<2, 2, 1>(p, bx, by, bz, p.splits, smem); break;
+        }
     }
 }
 
@@ -321,7 +328,8 @@ void wgrad_multi_kernel(const WgMulti a) {
 
 extern "C" int mcgen_wgrad_multi_ok(const mcgen_wgrad_t* p, int dtype) {
     if (!p || dtype != MCGEN_BF16) return 0;
-    if (p->seg.ksize != 3 || p->H != p->W || (p->W != 8 && p->W != 16 && p->W != 32)) return 0;
+    if (p->seg.ksize != 3 && p->seg.ksize != 1) return 0;
+    if (p->H != p->W || (p->W != 8 && p->W != 16 && p->W != 32 && !(p->W == 4 && p->seg.ksize == 1))) return 0;
     if (p->Cout_w % WB_CO || p->seg.C % WB_CI || p->Cout != p->Cout_w || p->Cdy < p->Cout_w) return 0;
     if (((long)p->N * p->H * p->W) % WB_BM) return 0;
     if (p->seg.group_n || p->seg.cmap) return 0;
@@ -335,7 +343,7 @@ extern "C" int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, 
     for (int i = 0; i < n; ++i) {
         const mcgen_wgrad_t& p = layers[i];
         MCGEN_CHECK(p.seg.x && p.dy && p.slabs, "wgrad_multi: null pointer (layer %d)", i);
-        MCGEN_CHECK(mcgen_wgrad_multi_ok(&p, dtype), "wgrad_multi: layer %d is not eligible (bf16, 3x3, square 8/16/32 maps, Cout %% 128 == 0, "
+        MCGEN_CHECK(mcgen_wgrad_multi_ok(&p, dtype), "wgrad_multi: layer %d is not eligible (bf16, 3x3 or 1x1, square 8/16/32 maps -- 1x1 also 4, Cout %% 128 == 0, "
                     "C %% 64 == 0, whole 128-pixel steps)", i);
         const long m_tiles = (long)p.N * p.H * p.W / WB_BM;
         MCGEN_CHECK(p.splits >= 1 && p.splits <= m_tiles, "wgrad_multi: layer %d: bad splits", i);

@@ -533,7 +533,8 @@ def _launch_multi(pend):
     for base in range(0, len(pend), _lib.WGRAD_MULTI_MAX):
         grp = pend[base:base + _lib.WGRAD_MULTI_MAX]
         budget = _cu_count(dev)
-        work = [q.m_tiles * q.blocks for q in grp]
+        # (a 1x1 step moves the same dy tile for a ninth of the MFMAs: memory-bound, about a third of a 3x3 step's time)
+        work = [q.m_tiles * q.blocks * (1.0 if q.seg.ksize == 3 else 0.35) for q in grp]
         tot = float(sum(work))
         for q, wk in zip(grp, work):
             unit = 2 if q.second is not None else 1                     # a two-half launch needs even splits
@@ -547,7 +548,7 @@ def _launch_multi(pend):
             for q in grp:
                 unit = 2 if q.second is not None else 1
                 if q.splits + unit <= q.m_tiles // unit * unit and used + unit * q.blocks <= budget:
-                    load = q.m_tiles / q.splits
+                    load = q.m_tiles / q.splits * (1.0 if q.seg.ksize == 3 else 0.35)
                     if best is None or load > best[0]:
                         best = (load, q, unit)
             if best is None:
@@ -564,10 +565,10 @@ def _launch_multi(pend):
             q.p.splits, q.p.slabs, q.p.bias_slabs = q.splits, _p(q.slabs), _p(q.bias_slabs)
             C.memmove(C.byref(a), C.byref(q.p), C.sizeof(_lib.Wgrad))
             n, hh, ww = q.p.N, q.p.H, q.p.W
-            flops += 2.0 * n * hh * ww * q.cout * q.seg.x.shape[-1] * 9
-            nbytes += _nbytes(q.seg.x, q.dy) + 4 * (q.cout * q.cin * 9 + (q.cout if q.bias_grad is not None else 0)) * (2 if q.second is not None else 1)
+            flops += 2.0 * n * hh * ww * q.cout * q.seg.x.shape[-1] * q.seg.ksize ** 2
+            nbytes += _nbytes(q.seg.x, q.dy) + 4 * (q.cout * q.cin * q.seg.ksize ** 2 + (q.cout if q.bias_grad is not None else 0)) * (2 if q.second is not None else 1)
             extra += _nbytes(q.slabs, q.bias_slabs)
-        _timed(lambda: 'wgrad_multi<bf16,3>', flops,
+        _timed(lambda: 'wgrad_multi<bf16>', flops,
                lambda: check(lib.mcgen_wgrad_multi(arr, len(grp), _lib.BF16, _stream()), 'wgrad_multi'),
                lambda: nbytes, lambda: extra)
 

@@ -781,7 +781,7 @@ def test_big_wgrad_two_halves_bf16():
 
 MULTI_PASSES = {
     # one backward pass = the layers whose weight gradients share ONE mcgen_wgrad_multi launch:
-    # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves)
+    # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves[, ksize])
     'generator': [(128, 32, 256, 256, False, False, True, False),     # G block 2 conv_b
                   (128, 32, 256, 256, True, False, True, False),      # G block 2 conv_a (x through the upsample)
                   (128, 16, 256, 256, False, False, True, False),
@@ -796,6 +796,14 @@ MULTI_PASSES = {
     'small': [(4, 16, 64, 128, False, False, True, False),           # few steps per layer: more workgroups than steps must not happen
               (2, 8, 128, 128, True, False, False, False),
               (8, 32, 64, 128, False, True, True, True)],
+    # 1x1 layers ride in the same launch: the generator's low-resolution shortcut, the discriminator's pooled shortcut,
+    # MCGlow's 512 -> 512 coupling convolution on 16x16 / 8x8 / 4x4 maps (eight images per 128-pixel step)
+    'with 1x1': [(128, 16, 256, 256, False, False, False, False, 1),
+                 (256, 16, 128, 128, False, True, False, True, 1),
+                 (128, 16, 512, 512, False, False, True, False, 1),
+                 (128, 8, 512, 512, False, False, True, False, 1),
+                 (128, 4, 512, 512, False, False, True, False, 1),
+                 (128, 16, 256, 256, False, False, True, False)],
 }
 
 
@@ -810,7 +818,9 @@ def test_wgrad_multi_pass_bf16(name):
     layers = MULTI_PASSES[name]
     g = torch.Generator().manual_seed(811 + len(layers))
     prob, refs = [], []
-    for (n, h, ci, co, ups, dy_ups, affine, halves) in layers:
+    for layer in layers:
+        n, h, ci, co, ups, dy_ups, affine, halves = layer[:8]
+        ks = layer[8] if len(layer) > 8 else 3
         hs = h // 2 if ups else h
         x = _rnd(g, n, ci, hs, hs)
         scale, shift = (_rnd(g, ci) * 0.5 + 1, _rnd(g, ci) * 0.3) if affine else (None, None)
@@ -822,18 +832,18 @@ def test_wgrad_multi_pass_bf16(name):
         if dy_ups:
             dyf = dyf.repeat_interleave(2, 2).repeat_interleave(2, 3)
         parts = (slice(0, n // 2), slice(n // 2, n)) if halves else (slice(None),)
-        refs.append([(torch.nn.grad.conv2d_weight(a[sl], (co, ci, 3, 3), dyf[sl], padding=1), dyf[sl].sum((0, 2, 3))) for sl in parts])
-        seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda() if affine else None, shift=shift.cuda() if affine else None,
+        refs.append([(torch.nn.grad.conv2d_weight(a[sl], (co, ci, ks, ks), dyf[sl], padding=ks // 2), dyf[sl].sum((0, 2, 3))) for sl in parts])
+        seg = ops.Seg(_nhwc(ops, x, dtype), ksize=ks, scale=scale.cuda() if affine else None, shift=shift.cuda() if affine else None,
                       code=code.cuda(), ups=ups, relu=True)
-        prob.append((seg, _nhwc(ops, dy, dtype), co, ci, dy_ups, halves))
+        prob.append((seg, _nhwc(ops, dy, dtype), co, ci, dy_ups, halves, ks))
 
     def run():
         outs = []
         ops._PROF = []                                   # record the launches of the pass
         try:
             with ops.deferred_reduces():
-                for seg, dyt, co, ci, dy_ups, halves in prob:
-                    gs = [torch.zeros((co, ci, 3, 3), device='cuda') for _ in range(2 if halves else 1)]
+                for seg, dyt, co, ci, dy_ups, halves, ks in prob:
+                    gs = [torch.zeros((co, ci, ks, ks), device='cuda') for _ in range(2 if halves else 1)]
                     bs = [torch.zeros((co,), device='cuda') for _ in range(2 if halves else 1)]
                     ops.wgrad(seg, dyt, co, ci, gs[0], dy_ups=dy_ups, bias_grad=bs[0], second=(gs[1], bs[1], None) if halves else None)
                     outs.append((gs, bs))
@@ -842,7 +852,7 @@ def test_wgrad_multi_pass_bf16(name):
             ops._PROF = None
         return outs, names
     outs, names = run()
-    assert names.count('wgrad_multi<bf16,3>') == 1 and not any(nm.startswith('wgrad<') for nm in names), names
+    assert names.count('wgrad_multi<bf16>') == 1 and not any(nm.startswith('wgrad<') for nm in names), names
     for li, ((gs, bs), ref) in enumerate(zip(outs, refs)):
         for hi, ((gr, br), gt, bt) in enumerate(zip(ref, gs, bs)):
             _assert_close(gt, gr, dtype, f'{name} layer {li} half {hi}')

@@ -50,7 +50,7 @@ def main():
             run()
         torch.cuda.synchronize()
         rec, ops._PROF = ops._PROF, None
-        for key in ('wgrad_multi<bf16,3>', 'wgrad_reduce'):
+        for key in ('wgrad_multi<bf16>', 'wgrad_reduce'):
             ts = sorted(s.elapsed_time(e) * 1e3 for nm, _, s, e, *_ in rec if nm == key)
             if ts:
                 med = ts[len(ts) // 2]

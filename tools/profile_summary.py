@@ -33,7 +33,7 @@ def bench_name(k: str):
     if 'wgrad_reduce' in k:
         return None
     if 'wgrad_multi_kernel' in k:                               # several 3x3 layers of a pass in one launch (bf16 only)
-        return 'wgrad_multi<bf16,3>'
+        return 'wgrad_multi<bf16>'
     m = re.search(r'wgrad_ring_kernel(?:ILi|<)(\d+)', k)        # bf16-only LDS-DMA ring form
     if m:
         return f'wgrad<bf16,{m.group(1)}>'
