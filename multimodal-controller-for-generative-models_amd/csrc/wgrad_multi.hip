@@ -256,7 +256,10 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
             const int tap = ((j / KS) * PC + (j % KS)) * WB_XPITCH;
             return wb_frag(A + g0 + tap, A + g1 + tap);
         };
-        bf16x8 af = rd_a(0, 0);
+        // (two named buffers picked by the compile-time parity of the tap counter: a rotating `next -> current` copy costs
+        // four v_mov per tap -- measured 3.1 VALU per MFMA with it)
+        bf16x8 afb[2];
+        afb[0] = rd_a(0, 0);
 #pragma unroll
         for (int ks = 0; ks < WB_BM / 32; ++ks) {
             bf16x8 df[4];
@@ -265,12 +268,11 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
                 df[c] = wb_frag(D + doff[c] + (32 * ks) * WB_DROW, D + doff[c] + (32 * ks + 16) * WB_DROW);
 #pragma unroll
             for (int j = 0; j < NTAP; ++j) {
+                const int t = ks * NTAP + j;                           // compile-time: the loops are fully unrolled
                 const bool last = (ks == WB_BM / 32 - 1) && (j == NTAP - 1);
-                bf16x8 an = af;
-                if (!last) an = (j == NTAP - 1) ? rd_a(ks + 1, 0) : rd_a(ks, j + 1);
+                if (!last) afb[(t + 1) & 1] = (j == NTAP - 1) ? rd_a(ks + 1, 0) : rd_a(ks, j + 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[c], af, acc[j][c], 0, 0, 0);
-                af = an;
+                for (int c = 0; c < 4; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[c], afb[t & 1], acc[j][c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

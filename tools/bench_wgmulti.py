@@ -21,6 +21,8 @@ PASSES = {
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    nobias = 'nobias' in sys.argv[2:]
+    noaff = 'noaffine' in sys.argv[2:]
     dev = torch.device('cuda')
     g = torch.Generator(device=dev).manual_seed(0)
     for name, layers in PASSES.items():
@@ -30,9 +32,9 @@ def main():
             x = torch.randn(n, hs, hs, ci, device=dev, generator=g).bfloat16()
             dy = (torch.randn(n, hd, hd, co, device=dev, generator=g) * 0.1).bfloat16()
             code = (torch.rand(n, ci, device=dev, generator=g) < 0.5).float()
-            sc = torch.rand(ci, device=dev, generator=g) + 0.5 if affine else None
-            sh = torch.randn(ci, device=dev, generator=g) * 0.3 if affine else None
-            seg = ops.Seg(x, scale=sc, shift=sh, code=code, ups=ups, relu=True)
+            sc = torch.rand(ci, device=dev, generator=g) + 0.5 if (affine and not noaff) else None
+            sh = torch.randn(ci, device=dev, generator=g) * 0.3 if (affine and not noaff) else None
+            seg = ops.Seg(x, scale=sc, shift=sh, code=None if noaff else code, ups=ups, relu=not noaff)
             gs = [torch.zeros(co, ci, 3, 3, device=dev) for _ in range(2 if halves else 1)]
             bs = [torch.zeros(co, device=dev) for _ in range(2 if halves else 1)]
             prob.append((seg, dy, co, ci, dy_ups, halves, gs, bs))
@@ -41,7 +43,8 @@ def main():
         def run():
             with ops.deferred_reduces():
                 for seg, dy, co, ci, dy_ups, halves, gs, bs in prob:
-                    ops.wgrad(seg, dy, co, ci, gs[0], dy_ups=dy_ups, bias_grad=bs[0], second=(gs[1], bs[1], None) if halves else None)
+                    ops.wgrad(seg, dy, co, ci, gs[0], dy_ups=dy_ups, bias_grad=None if nobias else bs[0],
+                              second=(gs[1], None if nobias else bs[1], None) if halves else None)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
