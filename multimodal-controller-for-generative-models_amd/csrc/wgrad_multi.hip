@@ -219,7 +219,11 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
     for (int j = 0; j < NTAP; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    // bias gradient = column sums of dy: thread (16-byte unit tid & 15, row group tid >> 4) adds rows rg, rg + 32, rg + 64, rg + 96 of
+    // every tile (four 16-byte LDS reads per step; the row groups meet in LDS once, after the last step)
+    float bsum8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum8[e] = 0.f;
 
     // ---- pipeline: x of step i + 2 in registers, x of step i + 1 written and dy of step i + 1 in flight while step i multiplies
     load_x(0);
@@ -240,12 +244,14 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
         const char* A = ldsA + (i & 1) * WB_ABUF + aoff;
         const char* D = ldsD + (i & 1) * WB_DBUF;
         if (do_bias) {
-            // column sums of the dy tile: thread = (column tid & 127, row quarter tid >> 7)
-            const int col = tid & 127, part = tid >> 7;
-#pragma unroll 8
-            for (int r = 0; r < WB_BM / 4; ++r) {
-                const int row = part * (WB_BM / 4) + r;
-                bsum += (float)*reinterpret_cast<const bf16_t*>(D + row * WB_DROW + 16 * ((col >> 3) ^ ((row & 7) << 1)) + 2 * (col & 7));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(D + ((tid >> 4) + 32 * k) * WB_DROW + (tid & 15) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum8[2 * e] += __uint_as_float(r[e] << 16);
+                    bsum8[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                }
             }
         }
         // fragment reads one tap ahead of their MFMAs (two window fragments in registers: the register budget allows no more);
@@ -294,8 +300,19 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
                 }
     }
     if (do_bias) {
+        // (workgroup-uniform branch) the 32 row groups of a column meet in LDS; rows [split * 4 + 1 .. + 3] of bias_slabs stay
+        // zero -- mcgen_wgrad_reduce adds all splits * 4 rows
+        __syncthreads();                                               // the last step's fragment reads are done: LDS is free
+        float* red = reinterpret_cast<float*>(smem);
+        const int rg = tid >> 4, lu = (tid & 15) ^ ((rg & 7) << 1);    // the unit's logical position (rows rg + 32 k share rg & 7)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rg * WB_CO + lu * 8 + e] = bsum8[e];
+        __syncthreads();
         const int colb = tid & 127, part = tid >> 7;
-        if (co0 + colb < p.Cout_w) p.bias_slabs[((size_t)bz * 4 + part) * p.Cout_w + co0 + colb] = bsum;
+        float s = 0.f;
+        if (part == 0)
+            for (int r = 0; r < 32; ++r) s += red[r * WB_CO + colb];
+        if (co0 + colb < p.Cout_w) p.bias_slabs[((size_t)bz * 4 + part) * p.Cout_w + co0 + colb] = s;
     }
 }
 
