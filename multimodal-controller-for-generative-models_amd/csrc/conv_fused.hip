@@ -2080,7 +2080,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 
     // ---- further (1x1) segments: synchronous, window buffer 0, ring slots 0 / 1 ---------------------------------------
     if (p.nseg > 1) {
-        int blk = T0, tg = 0;
+        int tg = 0;
         int nrest = 0;
         // (GK: one further segment; its chunks are the image's active ones)
         const int16_t* cidx1 = nullptr; int cw1 = 8, cnt1 = 0;
@@ -2121,7 +2121,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
                 for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
                     for (int fm = 0; fm < FM; ++fm) M::run(yf[fn], xf[fm], acc[fn][fm]);
-                ++tg; ++blk;
+                ++tg;
             }
         }
     }
@@ -2595,6 +2595,7 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (p->w_layout == 1) return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
     if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
+    if (mcgen_conv_skinny_ok(p, dtype)) return mcgen_conv_skinny(p, reinterpret_cast<hipStream_t>(stream));
     const TilePick t = pick_tile(p, dtype);
     if (p->ycmap) MCGEN_CHECK(dtype == MCGEN_BF16 && t.BM <= p->H * p->W && p->Cout_w <= t.BN,
                               "conv_fused: compacted output: the %dx%d tile must lie inside one image and hold all %d channels", t.BM, t.BN, p->Cout_w);

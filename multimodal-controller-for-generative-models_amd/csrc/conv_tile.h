@@ -3,6 +3,10 @@
 #pragma once
 #include "mcgen_common.h"
 
+// conv_skinny.hip: Cout <= 16 over a deep K on 4x4 / 8x8 / 16x16 maps, K split over the waves of a workgroup
+int mcgen_conv_skinny_ok(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_skinny(const mcgen_conv_t* p, hipStream_t st);
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     typedef bf16x8 frag;

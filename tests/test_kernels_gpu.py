@@ -779,6 +779,33 @@ def test_big_wgrad_two_halves_bf16():
     _assert_close(b2, dyf[n // 2:].sum((0, 2, 3)), dtype, 'second half bias')
 
 
+@pytest.mark.parametrize('n,h,c,co,res,prol', [(128, 16, 512, 4, False, True), (128, 8, 512, 8, True, False), (128, 4, 512, 16, False, True),
+                                               (16, 4, 256, 16, True, True), (8, 8, 160, 12, False, True)])
+def test_skinny_split_k_conv_bf16(n, h, c, co, res, prol):
+    """conv_skinny.hip: 3x3, Cout <= 16 over a deep K on 16x16 / 8x8 / 4x4 maps (MCGlow's ZeroConv2d forward, mcglow.py:119-130,
+    and the coupling nets' input gradients): K split over the 16 waves of a workgroup, partial sums combined in LDS --
+    with and without the prologue (ActNorm affine, ReLU, code) and the residual add, against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(911 + h + co)
+    x = _rnd(g, n, c, h, h)
+    wt, b = _rnd(g, co, c, 3, 3) * 0.03, _rnd(g, co)
+    scale, shift = (_rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3) if prol else (None, None)
+    code = (torch.rand(n, c, generator=g) < 0.5).float() if prol else None
+    r = _rnd(g, n, co, h, h) if res else None
+    a = _q(ref_prologue(_q(x, dtype), scale, shift, prol, code, False), dtype) if prol else _q(x, dtype)
+    ref = F.conv2d(a, _q(wt, dtype), b, padding=1) * 1.0
+    if res:
+        ref = ref + _q(r, dtype)
+    seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda() if prol else None, shift=shift.cuda() if prol else None,
+                  code=code.cuda() if prol else None, relu=prol)
+    y, _ = ops.conv_fused([seg], ops.prep_weight(wt.cuda(), dtype), co, bias=b.cuda(), res=_nhwc(ops, r, dtype) if res else None)
+    assert y.shape[-1] == ops.pad8(co)
+    if ops.pad8(co) > co:
+        assert float(y[..., co:].float().abs().max()) == 0.0          # padded channels stay exactly zero
+    _assert_close(ops.to_nchw(y, co), ref, dtype, 'skinny conv')
+
+
 MULTI_PASSES = {
     # one backward pass = the layers whose weight gradients share ONE mcgen_wgrad_multi launch:
     # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves[, ksize])
