@@ -526,6 +526,8 @@ def main():
         'first_iterations_d_g': [[round(float(x), 4) for x in r] for r in tr_host[:min(it, max(8, 2 * a.reset_every))]],
         'every_32nd_iteration_d_g': [[round(float(x), 4) for x in r] for r in tr_host[31::32]],
         'iterations': it,
+        # share of ALL iterations whose discriminator hinge loss is (nearly) saturated: their D backward passes see mostly zeros
+        'd_loss_below_0.05_fraction': float((tr_host[:, 0] < 0.05).float().mean()),
     }
 
     roofline = None

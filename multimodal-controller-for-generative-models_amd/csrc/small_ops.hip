@@ -804,6 +804,14 @@ __device__ __forceinline__ void adam_step_ticket(int64_t* step, unsigned total_b
         if (prev == total_blocks - 1) { *ticket = 0u; step[0] += 1; }
     }
 }
+// beta^t for an integer step count by repeated squaring (<= 2 log2 t double multiplies).  The library pow() is several
+// hundred instructions per lane, and every wave of an Adam launch used to run it twice: the fused discriminator update,
+// whose grid is thousands of small blocks, spent most of its 21 us there.
+__device__ __forceinline__ double adam_powi(double b, long t) {
+    double r = 1.0;
+    while (t > 0) { if (t & 1) r *= b; b *= b; t >>= 1; }
+    return r;
+}
 __device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t i, float gi,
                                           float b1, float b2, float eps, float wd, float step_size, float bc2s) {
     if (wd != 0.f) gi = fmaf(wd, p[i], gi);
@@ -814,9 +822,9 @@ __device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restri
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t n, float lr, float b1, float b2, float eps, float wd, int64_t* step) {
-    const double t = (double)(step[0] + 1);
-    const float bc1 = (float)(1.0 - pow((double)b1, t));
-    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const long t = (long)step[0] + 1;
+    const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
     const float step_size = lr / bc1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         adam_elem(p, m, v, i, g[i], b1, b2, eps, wd, step_size, bc2s);
@@ -834,9 +842,9 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
                                         const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma0,
                                         const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
                                         float lr, float b1, float b2, float eps, float wd, int64_t* step, unsigned ticket_total) {
-    const double t = (double)(step[0] + 1);
-    const float bc1 = (float)(1.0 - pow((double)b1, t));
-    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const long t = (long)step[0] + 1;
+    const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
     const float step_size = lr / bc1;
     const mcgen_sn_layer_t L = layers[blockIdx.x];
     const float* A = g0 + L.w_off; const float* B = g1 + L.w_off;
