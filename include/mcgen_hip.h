@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -124,6 +124,9 @@ typedef struct {
 int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype);
 /* the (pixels x channels) output tile the launcher will pick for `p` (names the kernel instantiation) */
 int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn);
+/* which kernel family mcgen_conv_fused hands `p` to: 0 the tiled forms named by mcgen_conv_tile, 1 the split-K skinny
+ * kernel (Cout <= 16, deep K, maps up to 16x16), 2 the one-image-per-workgroup kernel (3x3, 128 -> 128, 8x8 maps) */
+int mcgen_conv_form(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream);
 
 /* Weight gradient of the same fused convolution for ONE segment:
@@ -344,14 +347,15 @@ int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float eps, float weight_decay, int64_t* step, void* stream);
 /* mcgen_sn_grad_fix_pair with Adam's update in place of the store (a single-rank discriminator update, train_gan.py:154-158:
  * d/d(weight_orig) is never materialised): for the layers of the table, g = fix(g_src0; uv0, sigma0) + fix(g_src1; uv1, sigma1)
- * goes straight into m, v, p (p doubles as w_base: the dot <g, W> is taken before any element moves).  A step that covers
- * its parameters with several tables (the two gradient buckets) passes the layer count of ALL of them as `ticket_layers`:
- * the last launch's last workgroup increments step[0].  workspace: 2 * 32 * nlayers floats; step as in mcgen_adam. */
+ * goes straight into m, v, p (p doubles as w_base: the dot <g, W> is taken before any element moves).  `advance_step` = 1:
+ * the call's dot launch increments step[0] and the update launch behind it reads the new count -- a step that covers its
+ * parameters with several tables passes 1 for the first table and 0 for the rest.  workspace: 2 * 32 * nlayers floats;
+ * step as in mcgen_adam (the ticket word is not used). */
 int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, float* p, float* m, float* v,
                            const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
                            const float* sigma0, const float* sigma1, float* workspace,
                            float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
-                           int ticket_layers, void* stream);
+                           int advance_step, void* stream);
 
 /* ---- MCGlow-specific kernels (reference: models/mcglow.py) ------------------------------------------------- */
 /* Block squeeze / unsqueeze (mcglow.py:221-223, 262-265): [N,H,W,C] <-> [N,H/2,W/2,4C], channel c*4 + 2*dh + dw.

@@ -77,6 +77,7 @@ SYMBOLS = {
     'mcgen_abi_version': (_i, []),
     'mcgen_conv_m_tiles': (_i, [C.POINTER(Conv), _i]),
     'mcgen_conv_tile': (_i, [C.POINTER(Conv), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'mcgen_conv_form': (_i, [C.POINTER(Conv), _i]),
     'mcgen_conv_fused': (_i, [C.POINTER(Conv), _i, _vp]),
     'mcgen_wgrad_slab_elems': (_i64, [C.POINTER(Wgrad)]),
     'mcgen_wgrad': (_i, [C.POINTER(Wgrad), _i, _vp]),

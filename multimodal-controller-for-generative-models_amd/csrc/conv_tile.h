@@ -6,6 +6,9 @@
 // conv_skinny.hip: Cout <= 16 over a deep K on 4x4 / 8x8 / 16x16 maps, K split over the waves of a workgroup
 int mcgen_conv_skinny_ok(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_skinny(const mcgen_conv_t* p, hipStream_t st);
+// conv_smap.hip: 3x3 128 -> 128 on 8x8 maps, one image per workgroup, weight fragments straight from L2
+int mcgen_conv_smap_ok(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_smap(const mcgen_conv_t* p, hipStream_t st);
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 6; }
+extern "C" int mcgen_abi_version(void) { return 7; }
 
 namespace {
 
@@ -618,8 +618,11 @@ __global__ void sn_grad_apply_kernel(const float* __restrict__ gsrc, float* gdst
 // Two halves of a paired pass (DiscriminatorEngine.forward_pair: the same weights, each half with the u, v, sigma of its own
 // forward) in one launch each: blockIdx.z = half in the dot pass; the apply pass adds both halves' terms and writes once.
 __global__ void sn_grad_dot2_kernel(const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ wb,
-                                    const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ partial, int nlayers) {
+                                    const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ partial, int nlayers,
+                                    int64_t* bump) {
     __shared__ float red[32];
+    // (the fused fix + Adam launch that follows reads the step counter this launch advances: one writer, no ticket)
+    if (bump && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) bump[0] += 1;
     const mcgen_sn_layer_t L = layers[blockIdx.x];
     if (L.rows == 0) return;
     const float* G = (blockIdx.z ? g1 : g0) + L.w_off; const float* W = wb + L.w_off;
@@ -834,15 +837,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 constexpr int SNA_CHUNKS = 128;      // blocks per layer of the fused fix + Adam launch (the dot pass keeps SNF_CHUNKS partials per layer)
 // sn_grad_apply2_kernel with torch.optim.Adam's update in place of the store: the discriminator update of a single-rank
 // run never materialises d/d(weight_orig) -- g = fix(g0; uv0, sigma0) + fix(g1; uv1, sigma1) goes straight into m, v, p
-// (train_gan.py:154-158: backward, optimizer['discriminator'].step()).  `ticket_total` = blocks of ALL launches of the
-// step (the layer tables of the two gradient buckets): the last of them bumps the step counter.
+// (train_gan.py:154-158: backward, optimizer['discriminator'].step()).  The step counter was advanced by the dot launch
+// in front of this one (the first table's, when a step covers its parameters with several): step[0] IS this step's t.
 __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const float* __restrict__ g1, float* __restrict__ pw,
                                         float* __restrict__ mo, float* __restrict__ vo,
                                         const float* __restrict__ uv0, const float* __restrict__ uv1,
                                         const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma0,
                                         const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
-                                        float lr, float b1, float b2, float eps, float wd, int64_t* step, unsigned ticket_total) {
-    const long t = (long)step[0] + 1;
+                                        float lr, float b1, float b2, float eps, float wd, const int64_t* __restrict__ step) {
+    const long t = (long)step[0];
     const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
     const float step_size = lr / bc1;
@@ -879,12 +882,6 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
             c += dc; r += dr;
             if (c >= cols) { c -= cols; ++r; }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
-        const unsigned prev = atomicAdd(ticket, 1u);
-        if (prev == ticket_total - 1) { *ticket = 0u; step[0] += 1; }
     }
 }
 
@@ -1143,7 +1140,7 @@ extern "C" int mcgen_sn_grad_fix_pair(const float* g_src0, const float* g_src1, 
                 "sn_grad_fix_pair: bad arguments (workspace must hold 2 * 32 * nlayers floats)");
     MCGEN_CHECK(g_src0 != g_dst && g_src1 != g_dst, "sn_grad_fix_pair: the destination must not alias a source");
     hipLaunchKernelGGL(sn_grad_dot2_kernel, dim3(nlayers, SNF_CHUNKS, 2), dim3(256), 0, STREAM(stream), g_src0, g_src1, w_base, layers_dev,
-                       workspace, nlayers);
+                       workspace, nlayers, (int64_t*)nullptr);
     hipLaunchKernelGGL(sn_grad_apply2_kernel, dim3(nlayers, SNF_CHUNKS), dim3(256), 0, STREAM(stream), g_src0, g_src1, g_dst, uv0, uv1,
                        layers_dev, sigma0, sigma1, workspace, nlayers, accumulate);
     MCGEN_LAUNCH_CHECK("sn_grad_fix_pair"); return 0;
@@ -1254,14 +1251,12 @@ extern "C" int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, 
                                       const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                       const float* sigma0, const float* sigma1, float* workspace,
                                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
-                                      int ticket_layers, void* stream) {
+                                      int advance_step, void* stream) {
     MCGEN_CHECK(g_src0 && g_src1 && p && m && v && uv0 && uv1 && layers_dev && sigma0 && sigma1 && workspace && step && nlayers > 0,
                 "sn_fix_pair_adam: bad arguments (workspace: 2 * 32 * nlayers floats; step: int64[2] = {counter, ticket})");
-    MCGEN_CHECK(ticket_layers >= nlayers, "sn_fix_pair_adam: ticket_layers counts the layers of ALL launches of the step");
     hipLaunchKernelGGL(sn_grad_dot2_kernel, dim3(nlayers, SNF_CHUNKS, 2), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, layers_dev,
-                       workspace, nlayers);
+                       workspace, nlayers, advance_step ? step : (int64_t*)nullptr);
     hipLaunchKernelGGL(sn_fix_pair_adam_kernel, dim3(nlayers, SNA_CHUNKS), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, m, v, uv0, uv1,
-                       layers_dev, sigma0, sigma1, workspace, nlayers, lr, beta1, beta2, eps, weight_decay, step,
-                       (unsigned)ticket_layers * SNA_CHUNKS);
+                       layers_dev, sigma0, sigma1, workspace, nlayers, lr, beta1, beta2, eps, weight_decay, step);
     MCGEN_LAUNCH_CHECK("sn_fix_pair_adam"); return 0;
 }

@@ -803,7 +803,9 @@ class DiscriminatorEngine:
                 return (ops.sn_layers_tensor(rows, fp.device) if rows else None), len(rows)
             hi = table(sn_hi, [p for p in self.plain if self.flat_p.offset_of(p) >= off_cut])
             lo = table([sn for sn in self.sn if sn.idx < i_cut], [p for p in self.plain if self.flat_p.offset_of(p) < off_cut])
-            self._bk = {'off_cut': off_cut, 'i_cut': i_cut, 'hi': hi, 'lo': lo}
+            # (a single-rank update has nothing to overlap with: one table for the fused fix + Adam launch)
+            every = table(sorted(self.sn, key=lambda sn: sn.idx), list(self.plain))
+            self._bk = {'off_cut': off_cut, 'i_cut': i_cut, 'hi': hi, 'lo': lo, 'all': every}
             self._bk_key = key
         return self._bk
 
@@ -941,7 +943,7 @@ class DiscriminatorEngine:
                 # the caller finishes the update itself (FusedAdam.step_fused_sn_pair: fix-up + Adam in one launch per table):
                 # hand it the raw per-half gradients and the spectral-norm state of the two forwards; gflat stays unwritten
                 self.pending_fix = {'g0': passes[0][1], 'g1': passes[1][1], 'uv0': uv, 'uv1': pair['uv2'], 'sigma0': sigma,
-                                    'sigma1': pair['sigma2'], 'tables': [(bk['hi'], bk['i_cut']), (bk['lo'], 0)]}
+                                    'sigma1': pair['sigma2'], 'tables': [(bk['all'], 0)]}
             else:
                 if not (_BUCKETS and split):
                     fix(bk['hi'], bk['i_cut'])      # single bucket: the late layers were not fixed up mid-pass

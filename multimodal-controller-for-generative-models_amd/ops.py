@@ -54,6 +54,7 @@ _PROF = None
 _PROF_SHAPES = _flag('MCGEN_PROF_SHAPES', '') != ''      # per-shape kernel names in the profile (tools/shape_table.py)
 TILE_LOG = None        # tests set this to a list: every conv_fused launch appends the (BM, BN) tile the policy picked
 FORM_LOG = None        # tests set this to a list: every conv_fused launch appends its weight layout (0 dense, 1 mc, 2 gk)
+KERNEL_LOG = None      # tests set this to a list: every conv_fused launch appends mcgen_conv_form (0 tiled, 1 skinny, 2 one image per workgroup)
 
 
 def _timed(name_fn, flops: float, launch, nbytes_fn=None, extra_fn=None):
@@ -377,7 +378,10 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     def _name():
         bm, bn = C.c_int(), C.c_int()
         lib.mcgen_conv_tile(C.byref(p), _dt(dtype), C.byref(bm), C.byref(bn))
+        form = lib.mcgen_conv_form(C.byref(p), _dt(dtype))
         base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{(",mc", ",gk")[kmajor - 1] if kmajor else ""}>'
+        if form:
+            base = ('conv_skinny<bf16>', 'conv_smap<bf16>')[form - 1]
         if _PROF_SHAPES:
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')
@@ -388,6 +392,8 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         TILE_LOG.append((bm.value, bn.value))
     if FORM_LOG is not None:
         FORM_LOG.append(kmajor)
+    if KERNEL_LOG is not None:
+        KERNEL_LOG.append(int(lib.mcgen_conv_form(C.byref(p), _dt(dtype))))
     _timed(_name, kflops, lambda: check(lib.mcgen_conv_fused(C.byref(p), _dt(dtype), _stream()), 'conv_fused'),
            lambda: _nbytes(wimg, y, res, gate_x, *[s.x for s in segs]))
     return y, stats
@@ -799,14 +805,14 @@ def sn_grad_fix_pair(g_src0: Tensor, g_src1: Tensor, g_dst: Tensor, w_base: Tens
 
 def sn_fix_pair_adam(g_src0: Tensor, g_src1: Tensor, p: Tensor, m: Tensor, v: Tensor, uv0: Tensor, uv1: Tensor,
                      layers_dev: Tensor, nlayers: int, sigma0: Tensor, sigma1: Tensor, step: Tensor, lr: float, betas,
-                     eps: float, weight_decay: float, ticket_layers: int):
+                     eps: float, weight_decay: float, advance_step: bool):
     """mcgen_sn_fix_pair_adam: the spectral-norm gradient fix of both halves of a paired discriminator pass fused with
     Adam's update of the same layers (`step`: the int64[2] {counter, ticket} buffer of ops.adam)."""
     assert step.dtype == torch.int64 and step.numel() == 2
     ws = torch.empty(2 * 32 * nlayers, dtype=torch.float32, device=p.device)
     check(_lib.load().mcgen_sn_fix_pair_adam(_f32(g_src0), _f32(g_src1), _f32(p), _f32(m), _f32(v), _f32(uv0), _f32(uv1),
                                              _p(layers_dev), nlayers, _f32(sigma0), _f32(sigma1), _f32(ws), lr, betas[0], betas[1],
-                                             eps, weight_decay, _p(step), ticket_layers, _stream()), 'sn_fix_pair_adam')
+                                             eps, weight_decay, _p(step), int(advance_step), _stream()), 'sn_fix_pair_adam')
 
 
 def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),

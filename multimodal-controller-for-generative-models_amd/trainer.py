@@ -66,11 +66,10 @@ class FusedAdam:
         backward_iter(defer_fix=True)): spectral-norm fix + Adam in one launch per layer table (ops.sn_fix_pair_adam)."""
         flat = self.fs.ensure()
         tables = [t for t in pending['tables'] if t[0][1] > 0]
-        total = sum(t[0][1] for t in tables)
-        for (table, nl), sg_off in tables:
+        for i, ((table, nl), sg_off) in enumerate(tables):
             ops.sn_fix_pair_adam(pending['g0'], pending['g1'], flat, self.m, self.v, pending['uv0'], pending['uv1'], table, nl,
                                  pending['sigma0'][sg_off:], pending['sigma1'][sg_off:], self._step_buf, self.lr, self.betas,
-                                 self.eps, self.wd, total)
+                                 self.eps, self.wd, i == 0)
         for p in self.fs.tensors:
             _bump(p)
 

@@ -806,6 +806,89 @@ def test_skinny_split_k_conv_bf16(n, h, c, co, res, prol):
     _assert_close(ops.to_nchw(y, co), ref, dtype, 'skinny conv')
 
 
+@pytest.mark.parametrize('n,case', [(256, 'forward'), (128, 'forward'), (256, 'input gradient'), (128, 'input gradient'), (3, 'affine')])
+def test_whole_image_conv_bf16(n, case):
+    """conv_smap.hip: 3x3, 128 -> 128 on 8x8 maps (the discriminator's 8x8 residual blocks, mcgan.py:95-138, forward and
+    input-gradient direction): whole images per workgroup (two at N = 256), weight fragments straight from the image, K
+    parts combined in LDS -- prologue (ReLU, code, affine) and epilogue (alpha, bias, bias2, output code, ReLU gate,
+    residual) against F.conv2d on the CPU; the launch must take the new kernel (mcgen_conv_form == 2)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    c = 128
+    g = torch.Generator().manual_seed(1201 + n)
+    x = _rnd(g, n, c, 8, 8)
+    wt, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
+    kw, alpha = {}, 1.0
+    if case == 'forward':
+        code = (torch.rand(n, c, generator=g) < 0.5).float() * 1.25
+        r = _rnd(g, n, c, 8, 8)
+        a = _q(ref_prologue(_q(x, dtype), None, None, True, code, False), dtype)
+        ref = F.conv2d(a, _q(wt, dtype), b, padding=1) + _q(r, dtype)
+        seg = ops.Seg(_nhwc(ops, x, dtype), code=code.cuda(), relu=True)
+        kw = dict(bias=b.cuda(), res=_nhwc(ops, r, dtype))
+    elif case == 'input gradient':
+        oc = (torch.rand(n, c, generator=g) < 0.5).float() * 0.8
+        gx = _rnd(g, n, c, 8, 8)
+        ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, padding=1) * oc[:, :, None, None] * (_q(gx, dtype) > 0).float()
+        seg = ops.Seg(_nhwc(ops, x, dtype))
+        kw = dict(ocode=oc.cuda(), gate_x=_nhwc(ops, gx, dtype))
+    else:
+        scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+        b2 = _rnd(g, c)
+        alpha = 0.5
+        a = _q(ref_prologue(_q(x, dtype), scale, shift, False, None, False), dtype)
+        ref = F.conv2d(a, _q(wt, dtype), None, padding=1) * alpha + (b + b2)[None, :, None, None]
+        seg = ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda())
+        kw = dict(bias=b.cuda(), bias2=b2.cuda(), alpha=alpha)
+    ops.KERNEL_LOG = []
+    try:
+        y, _ = ops.conv_fused([seg], ops.prep_weight(wt.cuda(), dtype), c, **kw)
+        assert ops.KERNEL_LOG == [2], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    _assert_close(ops.to_nchw(y, c), ref, dtype, f'whole-image conv: {case}')
+
+
+# MCGatedPixelCNN's layers on its 8x8 code maps (mcpixelcnn.py:16-61, hidden 128): (segments [(Cin, ksize)], Cout, stats)
+PIXEL_SHAPES = [([(128, 3)], 256, True),              # vertical stack
+                ([(256, 1), (128, 3)], 256, True),     # vert_to_horiz (1x1) + horizontal stack, K-concatenated
+                ([(256, 3)], 128, False),              # their input gradients
+                ([(256, 1)], 256, False), ([(128, 1)], 128, True), ([(128, 1)], 128, False)]
+
+
+@pytest.mark.parametrize('n', [128, 6])
+@pytest.mark.parametrize('segs,co,stats', PIXEL_SHAPES)
+def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
+    """The same kernel on MCGatedPixelCNN's layer shapes: 128 / 256 channels, 1x1 and 3x3, a K-concatenated second segment,
+    BatchNorm partial sums per image in the epilogue (one row of `stats` per image) -- against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1301 + n + co + 7 * len(segs))
+    ref, sg, ws = 0, [], []
+    for ci, ks in segs:
+        x = _rnd(g, n, ci, 8, 8)
+        wt = _rnd(g, co, ci, ks, ks) * (0.03 if ks == 3 else 0.08)
+        code = (torch.rand(n, ci, generator=g) < 0.5).float()
+        a = _q(ref_prologue(_q(x, dtype), None, None, True, code, False), dtype)
+        ref = ref + F.conv2d(a, _q(wt, dtype), None, padding=ks // 2)
+        sg.append(ops.Seg(_nhwc(ops, x, dtype), ksize=ks, code=code.cuda(), relu=True))
+        ws.append(ops.prep_weight(wt.cuda(), dtype))
+    b = _rnd(g, co)
+    ref = ref + b[None, :, None, None]
+    ops.KERNEL_LOG = []
+    try:
+        y, st = ops.conv_fused(sg, torch.cat(ws), co, bias=b.cuda(), stats_mode=1 if stats else 0)
+        assert ops.KERNEL_LOG == [2], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    _assert_close(ops.to_nchw(y, co), ref, dtype, 'whole-image conv, PixelCNN shape')
+    if stats:
+        assert st.shape == (n, 2, co)                  # one row per image
+        yq = ops.to_nchw(y, co).cpu()
+        np.testing.assert_allclose(st[:, 0].cpu(), yq.sum((2, 3)), rtol=2e-2, atol=0.5)
+        np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
+
+
 MULTI_PASSES = {
     # one backward pass = the layers whose weight gradients share ONE mcgen_wgrad_multi launch:
     # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves[, ksize])
