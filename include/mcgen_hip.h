@@ -120,12 +120,14 @@ typedef struct {
                             * fp32 before it meets the accumulator, as bias + bias2 on the host would be)   */
 } mcgen_conv_t;
 
-/* number of M tiles (rows of `stats`) the launch of `p` will use */
+/* number of M tiles (rows of `stats`) the launch of `p` will use.  Depends on the shape / mode fields only -- callers ask
+ * BEFORE they allocate `stats`, so no kernel's eligibility may depend on p->stats (or any other buffer pointer being set) */
 int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype);
 /* the (pixels x channels) output tile the launcher will pick for `p` (names the kernel instantiation) */
 int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn);
 /* which kernel family mcgen_conv_fused hands `p` to: 0 the tiled forms named by mcgen_conv_tile, 1 the split-K skinny
- * kernel (Cout <= 16, deep K, maps up to 16x16), 2 the one-image-per-workgroup kernel (3x3, 128 -> 128, 8x8 maps) */
+ * kernel (Cout <= 16, deep K, maps up to 16x16), 2 the whole-image kernel (8x8 maps, 128 / 256 channels), 3 the
+ * resident-pixel-tile 1x1 kernel (512 -> 512 on 16x16 / 8x8 / 4x4 maps) */
 int mcgen_conv_form(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream);
 

@@ -2575,6 +2575,7 @@ extern "C" int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype) {
         return (int)(((long)p->N * p->H * p->W + bm - 1) / bm);
     }
     if (mcgen_conv_smap_ok(p, dtype)) return p->N;              // whole-image kernel: one statistics row per image
+    if (const int bm = mcgen_conv_px1_bm(p, dtype)) return (int)((long)p->N * p->H * p->W / bm);
     const TilePick t = pick_tile(p, dtype);
     const long Mtot = (long)p->N * p->H * p->W;
     return (int)((Mtot + t.BM - 1) / t.BM);
@@ -2595,6 +2596,7 @@ extern "C" int mcgen_conv_form(const mcgen_conv_t* p, int dtype) {
     if (!p || p->w_layout != 0) return 0;
     if (mcgen_conv_skinny_ok(p, dtype)) return 1;
     if (mcgen_conv_smap_ok(p, dtype)) return 2;
+    if (mcgen_conv_px1_bm(p, dtype)) return 3;
     return 0;
 }
 
@@ -2605,6 +2607,7 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
     if (mcgen_conv_skinny_ok(p, dtype)) return mcgen_conv_skinny(p, reinterpret_cast<hipStream_t>(stream));
     if (mcgen_conv_smap_ok(p, dtype)) return mcgen_conv_smap(p, reinterpret_cast<hipStream_t>(stream));
+    if (mcgen_conv_px1_bm(p, dtype)) return mcgen_conv_px1(p, reinterpret_cast<hipStream_t>(stream));
     const TilePick t = pick_tile(p, dtype);
     if (p->ycmap) MCGEN_CHECK(dtype == MCGEN_BF16 && t.BM <= p->H * p->W && p->Cout_w <= t.BN,
                               "conv_fused: compacted output: the %dx%d tile must lie inside one image and hold all %d channels", t.BM, t.BN, p->Cout_w);

@@ -308,7 +308,7 @@ struct ImPick { int c0, k0, c1, k1, imgs; };
 static bool im_pick(const mcgen_conv_t* p, int dtype, ImPick* out) {
     if (dtype != MCGEN_BF16 || p->w_layout != 0 || p->nseg < 1 || p->nseg > 2) return false;
     if (p->H != 8 || p->W != 8 || p->Cout % IM_COT || p->Cout_w != p->Cout || p->Cy != p->Cout) return false;
-    if (p->pool || p->gscale || p->tanh_out || p->ycmap || p->stats_mode > 1 || (p->stats_mode == 1 && !p->stats)) return false;
+    if (p->pool || p->gscale || p->tanh_out || p->ycmap || p->stats_mode > 1) return false;       // (p->stats: validated by mcgen_conv_fused)
     for (int s = 0; s < p->nseg; ++s) {
         const mcgen_seg_t& g = p->seg[s];
         if ((g.ksize != 1 && g.ksize != 3) || g.ups || g.group_n || g.cmap || (g.C != 128 && g.C != 256)) return false;

@@ -9,6 +9,9 @@ int mcgen_conv_skinny(const mcgen_conv_t* p, hipStream_t st);
 // conv_smap.hip: 3x3 128 -> 128 on 8x8 maps, one image per workgroup, weight fragments straight from L2
 int mcgen_conv_smap_ok(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_smap(const mcgen_conv_t* p, hipStream_t st);
+// conv_px1.hip: 1x1 512 -> 512 with the pixel tile resident in LDS (pixels per tile, 0 = not taken)
+int mcgen_conv_px1_bm(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_px1(const mcgen_conv_t* p, hipStream_t st);
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

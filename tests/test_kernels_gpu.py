@@ -889,6 +889,53 @@ def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
         np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize('n,h', [(8, 16), (128, 16), (16, 8), (32, 4)])
+@pytest.mark.parametrize('case', ['forward', 'input gradient'])
+def test_resident_tile_1x1_conv_bf16(n, h, case):
+    """conv_px1.hip: the 512 -> 512 1x1 convolution of MCGlow's coupling networks (mcglow.py:133-160) on 16x16 / 8x8 / 4x4
+    maps with the pixel tile resident in LDS.  Forward: ActNorm affine + ReLU + code prologue, bias.  Input gradient: output
+    code, ReLU gate through the ActNorm affine of the gated tensor, residual, and the ActNorm-gradient partial sums
+    (stats_mode 2: sum v and sum v * (x - mean) * rstd per tile) -- against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    c = 512
+    g = torch.Generator().manual_seed(1401 + n + h)
+    x = _rnd(g, n, c, h, h)
+    wt = _rnd(g, c, c, 1, 1) * 0.04
+    ops.KERNEL_LOG = []
+    try:
+        if case == 'forward':
+            scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+            code = (torch.rand(n, c, generator=g) < 0.5).float()
+            b = _rnd(g, c)
+            a = _q(ref_prologue(_q(x, dtype), scale, shift, True, code, False), dtype)
+            ref = F.conv2d(a, _q(wt, dtype), b)
+            seg = ops.Seg(_nhwc(ops, x, dtype), ksize=1, scale=scale.cuda(), shift=shift.cuda(), code=code.cuda(), relu=True)
+            y, _ = ops.conv_fused([seg], ops.prep_weight(wt.cuda(), dtype), c, bias=b.cuda())
+        else:
+            oc = (torch.rand(n, c, generator=g) < 0.5).float()
+            gx, r = _rnd(g, n, c, h, h), _rnd(g, n, c, h, h)
+            gsc, gsh, gme = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3, _rnd(g, c) * 0.2
+            grs = torch.rand(c, generator=g) + 0.5
+            gxq = _q(gx, dtype)
+            gate = ((gxq * gsc[None, :, None, None] + gsh[None, :, None, None]) > 0).float()
+            v = F.conv2d(_q(x, dtype), _q(wt, dtype), None) * oc[:, :, None, None] * gate
+            ref = v + _q(r, dtype)
+            y, st = ops.conv_fused([ops.Seg(_nhwc(ops, x, dtype), ksize=1)], ops.prep_weight(wt.cuda(), dtype), c, ocode=oc.cuda(),
+                                   gate_x=_nhwc(ops, gx, dtype), gscale=gsc.cuda(), gshift=gsh.cuda(), gmean=gme.cuda(), grstd=grs.cuda(),
+                                   res=_nhwc(ops, r, dtype), stats_mode=2)
+            s = st.sum(0).cpu()
+            xhat = (gxq - gme[None, :, None, None]) * grs[None, :, None, None]
+            s1, s2 = v.sum((0, 2, 3)), (v * xhat).sum((0, 2, 3))
+            tol = max(1.0, float(s2.abs().max())) * 1e-2
+            np.testing.assert_allclose(s[0], s1, rtol=2e-2, atol=tol)
+            np.testing.assert_allclose(s[1], s2, rtol=2e-2, atol=tol)
+        assert ops.KERNEL_LOG == [3], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    _assert_close(ops.to_nchw(y, c), ref, dtype, f'resident-tile 1x1: {case}')
+
+
 MULTI_PASSES = {
     # one backward pass = the layers whose weight gradients share ONE mcgen_wgrad_multi launch:
     # (N, H, Cin, Cout, ups(x), dy_ups, affine, two halves[, ksize])
