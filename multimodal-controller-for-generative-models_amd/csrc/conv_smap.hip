@@ -4,7 +4,9 @@
 //
 // The discriminator's 8x8 residual blocks (DisResBlock, mcgan.py:95-138: 3x3, 128 -> 128, forward and input gradient: 48
 // of the ~350 launches of a training iteration) and every layer of MCGatedPixelCNN (mcpixelcnn.py:16-61 on 8x8 code
-// maps: 3x3 / 1x1, 128 or 256 channels, optionally a K-concatenated second segment, BatchNorm statistics in the epilogue).
+// maps: 3x3 / 1x1, 128 or 256 channels, optionally a K-concatenated second segment, BatchNorm statistics in the epilogue)
+// and the generator's first block (GenResBlock at 8x8, mcgan.py:9-44: 256 channels, inputs through the nearest x2 upsample,
+// BatchNorm groups of the grouped 5 N pass).
 // On the general 64x64 tile such a launch is 256-1024 workgroups that each run their K chunks behind barriers with the
 // weights re-staged through LDS per workgroup: 13-22 us for 2-10 GFLOP (rocprofv3, profiles/r03_*_kernel_stats.csv).
 //
@@ -59,9 +61,14 @@ struct ImSeg {
     static constexpr int PC = KS == 3 ? 10 : 8, HALO = KS == 3 ? 1 : 0, ROWB = C * 2;
     static __device__ __forceinline__ void load(const mcgen_seg_t& sg, int n, int tid, u32x4 (&raw)[NI]) {
         const int u = tid & (UPP - 1), px0 = tid / UPP;
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(sg.x) + ((size_t)n * 64) * C + u * 8;
+        // ups: x is the 4x4 map under a nearest x2 upsample (mcgan.py:17,27) -- pixel (r, c) reads (r >> 1, c >> 1)
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(sg.x) + ((size_t)n * (sg.ups ? 16 : 64)) * C + u * 8;
 #pragma unroll
-        for (int k = 0; k < NI; ++k) raw[k] = *reinterpret_cast<const u32x4*>(xs + (size_t)(px0 + PSTEP * k) * C);
+        for (int k = 0; k < NI; ++k) {
+            const int px = px0 + PSTEP * k;
+            const int src = sg.ups ? ((px >> 4) << 2) + ((px & 7) >> 1) : px;
+            raw[k] = *reinterpret_cast<const u32x4*>(xs + (size_t)src * C);
+        }
     }
     static __device__ __forceinline__ void write(const mcgen_seg_t& sg, int tid, const u32x4 (&raw)[NI], const float (&sc)[8],
                                                  const float (&sh)[8], const float (&cd)[8], char* win) {
@@ -93,10 +100,12 @@ struct ImSeg {
 // prologue vectors of a segment for this thread's channel unit (unconditional loads from a valid address, selected
 // afterwards: a branch here makes the compiler wait for them before it requests the weights)
 template <int C>
-static __device__ __forceinline__ void im_affine(const mcgen_seg_t& sg, int tid, const float* anyf, float (&sc)[8], float (&sh)[8]) {
+static __device__ __forceinline__ void im_affine(const mcgen_seg_t& sg, int n0, int tid, const float* anyf, float (&sc)[8], float (&sh)[8]) {
     const int u = tid & (C / 8 - 1);
-    load8f(sg.scale ? sg.scale + u * 8 : anyf, sc);
-    load8f(sg.scale ? sg.shift + u * 8 : anyf, sh);
+    // group_n > 0: BatchNorm statistics groups of group_n images each; the workgroup's images lie in one group (host check)
+    const size_t row = sg.group_n > 0 ? (size_t)(n0 / sg.group_n) * C : 0;
+    load8f(sg.scale ? sg.scale + row + u * 8 : anyf, sc);
+    load8f(sg.scale ? sg.shift + row + u * 8 : anyf, sh);
 }
 template <int C>
 static __device__ __forceinline__ void im_code(const mcgen_seg_t& sg, int n, int tid, const float* anyf, float (&cd)[8]) {
@@ -127,8 +136,8 @@ void conv_img_kernel(const mcgen_conv_t p) {
         if (C1) S1::load(p.seg[1], n0 + k, tid, raw1[k]);
     }
     float sc0[8], sh0[8], sc1[8], sh1[8], cd0[IMGS][8], cd1[IMGS][8];
-    im_affine<C0>(p.seg[0], tid, anyf, sc0, sh0);
-    if (C1) im_affine<(C1 ? C1 : 128)>(p.seg[1], tid, anyf, sc1, sh1);
+    im_affine<C0>(p.seg[0], n0, tid, anyf, sc0, sh0);
+    if (C1) im_affine<(C1 ? C1 : 128)>(p.seg[1], n0, tid, anyf, sc1, sh1);
 #pragma unroll
     for (int k = 0; k < IMGS; ++k) {
         im_code<C0>(p.seg[0], n0 + k, tid, anyf, cd0[k]);
@@ -311,13 +320,19 @@ static bool im_pick(const mcgen_conv_t* p, int dtype, ImPick* out) {
     if (p->pool || p->gscale || p->tanh_out || p->ycmap || p->stats_mode > 1) return false;       // (p->stats: validated by mcgen_conv_fused)
     for (int s = 0; s < p->nseg; ++s) {
         const mcgen_seg_t& g = p->seg[s];
-        if ((g.ksize != 1 && g.ksize != 3) || g.ups || g.group_n || g.cmap || (g.C != 128 && g.C != 256)) return false;
+        if ((g.ksize != 1 && g.ksize != 3) || g.cmap || (g.C != 128 && g.C != 256)) return false;
+        if (g.group_n < 0 || (g.group_n > 0 && p->N % g.group_n)) return false;
     }
     ImPick k{p->seg[0].C, p->seg[0].ksize, p->nseg == 2 ? p->seg[1].C : 0, p->nseg == 2 ? p->seg[1].ksize : 0, 1};
-    const bool known = (k.c1 == 0 && k.k0 == 3) || (k.c1 == 0 && k.k0 == 1) || (k.c0 == 256 && k.k0 == 1 && k.c1 == 128 && k.k1 == 3);
+    const bool known = (k.c1 == 0 && k.k0 == 3) || (k.c1 == 0 && k.k0 == 1) || (k.c0 == 256 && k.k0 == 1 && k.c1 == 128 && k.k1 == 3) ||
+                       (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1);
     if (!known) return false;
-    // two images per workgroup while the launch still covers the chip (halves the weight bytes per pixel)
-    if (p->N % 2 == 0 && (long)p->N * (p->Cout / IM_COT) >= 512) k.imgs = 2;
+    // two images per workgroup while the launch still covers the chip (halves the weight bytes per pixel), the windows of
+    // both fit in LDS, and the pair shares its BatchNorm group
+    const int win = (k.k0 == 3 ? 100 : 64) * k.c0 * 2 + (k.c1 ? (k.k1 == 3 ? 100 : 64) * k.c1 * 2 : 0);
+    bool pair_ok = p->N % 2 == 0 && (long)p->N * (p->Cout / IM_COT) >= 512 && 2 * win <= 160 * 1024;
+    for (int s = 0; s < p->nseg; ++s) if (p->seg[s].group_n > 0 && p->seg[s].group_n % 2) pair_ok = false;
+    if (pair_ok) k.imgs = 2;
     *out = k;
     return true;
 }
@@ -353,5 +368,6 @@ int mcgen_conv_smap(const mcgen_conv_t* p, hipStream_t st) {
         return k.imgs == 2 ? launch_img<A, B, C, D, 2>(p, st) : launch_img<A, B, C, D, 1>(p, st);
     IM_CASE(128, 3, 0, 0) IM_CASE(256, 3, 0, 0) IM_CASE(128, 1, 0, 0) IM_CASE(256, 1, 0, 0) IM_CASE(256, 1, 128, 3)
 #undef IM_CASE
+    if (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1) return launch_img<256, 3, 256, 1, 1>(p, st);   // (two images' windows exceed the LDS)
     return mcgen_fail("conv_smap: no instantiation");
 }

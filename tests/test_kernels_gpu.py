@@ -889,6 +889,57 @@ def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
         np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize('n,gn', [(640, 128), (10, 2), (6, 3)])
+@pytest.mark.parametrize('two_seg', [False, True])
+def test_whole_image_conv_generator_first_block_bf16(n, gn, two_seg):
+    """The same kernel on the generator's 8x8 block of the grouped pass (GenResBlock, mcgan.py:9-44): conv_a reads the 4x4
+    input through the nearest x2 upsample with the BatchNorm affine of its statistics group (`gn` images per group), ReLU
+    and code; conv_b ++ shortcut is a 3x3 segment on h plus a 1x1 segment on the upsampled block input; BatchNorm partial
+    sums per image -- against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    c = 256
+    g = torch.Generator().manual_seed(1501 + n + int(two_seg))
+    groups = n // gn
+    x = _rnd(g, n, c, 4, 4)
+    code1 = (torch.rand(n, c, generator=g) < 0.5).float()
+    b = _rnd(g, c)
+
+    def grouped_affine(t, scale, shift):                  # row n // gn of [groups, C]
+        idx = torch.arange(n) // gn
+        return t * scale[idx][:, :, None, None] + shift[idx][:, :, None, None]
+    if not two_seg:
+        scale, shift = _rnd(g, groups, c) * 0.5 + 1, _rnd(g, groups, c) * 0.3
+        wt = _rnd(g, c, c, 3, 3) * 0.02
+        xu = _q(x, dtype).repeat_interleave(2, 2).repeat_interleave(2, 3)
+        a = _q(torch.relu(grouped_affine(xu, scale, shift)) * code1[:, :, None, None], dtype)
+        ref = F.conv2d(a, _q(wt, dtype), b, padding=1)
+        segs = [ops.Seg(_nhwc(ops, x, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code1.cuda(), ups=True, relu=True, group_n=gn)]
+        wimg = ops.prep_weight(wt.cuda(), dtype)
+    else:
+        hmap = _rnd(g, n, c, 8, 8)
+        scale, shift = _rnd(g, groups, c) * 0.5 + 1, _rnd(g, groups, c) * 0.3
+        code2 = (torch.rand(n, c, generator=g) < 0.5).float()
+        w2, ws = _rnd(g, c, c, 3, 3) * 0.02, _rnd(g, c, c, 1, 1) * 0.05
+        a = _q(torch.relu(grouped_affine(_q(hmap, dtype), scale, shift)) * code2[:, :, None, None], dtype)
+        xu = _q(_q(x, dtype).repeat_interleave(2, 2).repeat_interleave(2, 3) * code1[:, :, None, None], dtype)
+        ref = F.conv2d(a, _q(w2, dtype), b, padding=1) + F.conv2d(xu, _q(ws, dtype), None)
+        segs = [ops.Seg(_nhwc(ops, hmap, dtype), scale=scale.cuda(), shift=shift.cuda(), code=code2.cuda(), relu=True, group_n=gn),
+                ops.Seg(_nhwc(ops, x, dtype), ksize=1, code=code1.cuda(), ups=True)]
+        wimg = torch.cat([ops.prep_weight(w2.cuda(), dtype), ops.prep_weight(ws.cuda(), dtype)])
+    ops.KERNEL_LOG = []
+    try:
+        y, st = ops.conv_fused(segs, wimg, c, bias=b.cuda(), stats_mode=1)
+        assert ops.KERNEL_LOG == [2], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    _assert_close(ops.to_nchw(y, c), ref, dtype, 'whole-image conv, generator first block')
+    assert st.shape == (n, 2, c)
+    yq = ops.to_nchw(y, c).cpu()
+    np.testing.assert_allclose(st[:, 0].cpu(), yq.sum((2, 3)), rtol=2e-2, atol=0.5)
+    np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
+
+
 @pytest.mark.parametrize('n,h', [(8, 16), (128, 16), (16, 8), (32, 4)])
 @pytest.mark.parametrize('case', ['forward', 'input gradient'])
 def test_resident_tile_1x1_conv_bf16(n, h, case):

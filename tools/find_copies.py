@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which Python lines issue device-to-device copies / small torch ops in one EAGER MCGlow (or MCPixelCNN) train step:
 patches Tensor.copy_ / clone / contiguous / torch.cat / index_select and counts callers (file:line inside the package).
-usage (GPU box): python tools/find_copies.py [mcglow|mcpixelcnn]"""
+usage (GPU box): python tools/find_copies.py [mcglow|mcpixelcnn|cifar10]"""
 import collections
 import os
 import sys
@@ -46,7 +46,7 @@ wrap(torch, 'zeros')
 wrap(torch, 'exp')
 
 wl = sys.argv[1] if len(sys.argv) > 1 else 'mcglow'
-sys.argv = ['bench.py', '--workload', wl, '--no-graph', '--steps', '1', '--warmup', '1', '--no-roofline', '--no-cpu-baseline']
+sys.argv = ['bench.py', '--workload', wl, '--no-graph', '--steps', '1', '--warmup', '1', '--no-roofline', '--no-cpu-baseline', '--sustain-steps', '0']
 orig_sync = torch.cuda.synchronize
 state = {'n': 0}
 

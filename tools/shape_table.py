@@ -16,4 +16,4 @@ rows = sorted(r['by_kernel'].items(), key=lambda kv: -kv[1]['total_ms'])
 tot = sum(v['total_ms'] for _, v in rows)
 print(f'MFMA kernels: {tot:.3f} ms over the profiled iterations')
 for k, v in rows:
-    print(f"{k:75s} x{v['launches']:3d} {v['total_ms']:7.3f} ms  {v['total_ms'] / v['launches'] * 1e3:7.1f} us  {v['tflops']:7.1f} TF  {v['gbytes_per_s']:7.1f} GB/s")
+    print(f"{k:75s} x{v['launches']:5.1f} {v['total_ms']:7.3f} ms  {v['total_ms'] / v['launches'] * 1e3:7.1f} us  {v['tflops']:7.1f} TF  {v['gbytes_per_s']:7.1f} GB/s")
