@@ -12,6 +12,9 @@ int mcgen_conv_smap(const mcgen_conv_t* p, hipStream_t st);
 // conv_px1.hip: 1x1 512 -> 512 with the pixel tile resident in LDS (pixels per tile, 0 = not taken)
 int mcgen_conv_px1_bm(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_px1(const mcgen_conv_t* p, hipStream_t st);
+// conv_c8.hip: 3x3 on an 8-channel (image) tensor -> 128 channels, 32x32 maps: K = (tap, channel), stores straight from the accumulators
+int mcgen_conv_c8_ok(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_c8(const mcgen_conv_t* p, hipStream_t st);
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

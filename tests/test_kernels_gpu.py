@@ -889,6 +889,28 @@ def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
         np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize('n', [256, 128, 3])
+def test_image_conv_bf16(n):
+    """conv_c8.hip: the discriminator's first convolution (FirstDisResBlock, mcgan.py:72-93: 3 -> 128 on the 32x32 image,
+    channel pitch 8) with K = (tap, channel) and stores straight from the accumulators; per-sample code on the input (the
+    paired pass's sigma ratio), bias -- against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1601 + n)
+    x = _rnd(g, n, 3, 32, 32)
+    wt, b = _rnd(g, 128, 3, 3, 3) * 0.2, _rnd(g, 128)
+    code = torch.rand(n, 1, generator=g).expand(n, 8).contiguous() + 0.5        # one scalar per sample on every input channel
+    a = _q(_q(x, dtype) * code[:, :3, None, None], dtype)
+    ref = F.conv2d(a, _q(wt, dtype), b, padding=1)
+    ops.KERNEL_LOG = []
+    try:
+        y, _ = ops.conv_fused([ops.Seg(_nhwc(ops, x, dtype), code=code.cuda())], ops.prep_weight(wt.cuda(), dtype), 128, bias=b.cuda())
+        assert ops.KERNEL_LOG == [4], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    _assert_close(ops.to_nchw(y, 128), ref, dtype, 'image convolution')
+
+
 @pytest.mark.parametrize('n,gn', [(640, 128), (10, 2), (6, 3)])
 @pytest.mark.parametrize('two_seg', [False, True])
 def test_whole_image_conv_generator_first_block_bf16(n, gn, two_seg):
