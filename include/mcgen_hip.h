@@ -127,7 +127,8 @@ int mcgen_conv_m_tiles(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* bn);
 /* which kernel family mcgen_conv_fused hands `p` to: 0 the tiled forms named by mcgen_conv_tile, 1 the split-K skinny
  * kernel (Cout <= 16, deep K, maps up to 16x16), 2 the whole-image kernel (8x8 maps, 128 / 256 channels), 3 the
- * resident-pixel-tile 1x1 kernel (512 -> 512 on 16x16 / 8x8 / 4x4 maps), 4 the image convolution (8 -> 128 channels, 3x3, 32x32) */
+ * resident-pixel-tile 1x1 kernel (512 -> 512 on 16x16 / 8x8 / 4x4 maps), 4 the image convolution (8 -> 128 channels, 3x3, 32x32),
+ * 5 the image head (3x3 to <= 8 channels of pitch 8, 32x32) */
 int mcgen_conv_form(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream);
 

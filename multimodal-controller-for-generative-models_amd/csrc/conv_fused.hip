@@ -2598,6 +2598,7 @@ extern "C" int mcgen_conv_form(const mcgen_conv_t* p, int dtype) {
     if (mcgen_conv_smap_ok(p, dtype)) return 2;
     if (mcgen_conv_px1_bm(p, dtype)) return 3;
     if (mcgen_conv_c8_ok(p, dtype)) return 4;
+    if (mcgen_conv_head_ok(p, dtype)) return 5;
     return 0;
 }
 
@@ -2610,6 +2611,7 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (mcgen_conv_smap_ok(p, dtype)) return mcgen_conv_smap(p, reinterpret_cast<hipStream_t>(stream));
     if (mcgen_conv_px1_bm(p, dtype)) return mcgen_conv_px1(p, reinterpret_cast<hipStream_t>(stream));
     if (mcgen_conv_c8_ok(p, dtype)) return mcgen_conv_c8(p, reinterpret_cast<hipStream_t>(stream));
+    if (mcgen_conv_head_ok(p, dtype)) return mcgen_conv_head(p, reinterpret_cast<hipStream_t>(stream));
     const TilePick t = pick_tile(p, dtype);
     if (p->ycmap) MCGEN_CHECK(dtype == MCGEN_BF16 && t.BM <= p->H * p->W && p->Cout_w <= t.BN,
                               "conv_fused: compacted output: the %dx%d tile must lie inside one image and hold all %d channels", t.BM, t.BN, p->Cout_w);

@@ -15,6 +15,9 @@ int mcgen_conv_px1(const mcgen_conv_t* p, hipStream_t st);
 // conv_c8.hip: 3x3 on an 8-channel (image) tensor -> 128 channels, 32x32 maps: K = (tap, channel), stores straight from the accumulators
 int mcgen_conv_c8_ok(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_c8(const mcgen_conv_t* p, hipStream_t st);
+// conv_head.hip: 3x3 to <= 8 output channels (pitch 8) on 32x32 maps, double-buffered input windows (the generator's image head)
+int mcgen_conv_head_ok(const mcgen_conv_t* p, int dtype);
+int mcgen_conv_head(const mcgen_conv_t* p, hipStream_t st);
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

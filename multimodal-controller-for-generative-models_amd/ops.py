@@ -54,7 +54,7 @@ _PROF = None
 _PROF_SHAPES = _flag('MCGEN_PROF_SHAPES', '') != ''      # per-shape kernel names in the profile (tools/shape_table.py)
 TILE_LOG = None        # tests set this to a list: every conv_fused launch appends the (BM, BN) tile the policy picked
 FORM_LOG = None        # tests set this to a list: every conv_fused launch appends its weight layout (0 dense, 1 mc, 2 gk)
-KERNEL_LOG = None      # tests set this to a list: every conv_fused launch appends mcgen_conv_form (0 tiled, 1 skinny, 2 whole images per workgroup, 3 resident-tile 1x1, 4 image convolution)
+KERNEL_LOG = None      # tests set this to a list: every conv_fused launch appends mcgen_conv_form (0 tiled, 1 skinny, 2 whole images per workgroup, 3 resident-tile 1x1, 4 image convolution, 5 image head)
 
 
 def _timed(name_fn, flops: float, launch, nbytes_fn=None, extra_fn=None):
@@ -381,7 +381,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         form = lib.mcgen_conv_form(C.byref(p), _dt(dtype))
         base = f'conv_fused<{"bf16" if dtype == torch.bfloat16 else "f32"},{bm.value},{bn.value}{(",mc", ",gk")[kmajor - 1] if kmajor else ""}>'
         if form:
-            base = ('conv_skinny<bf16>', 'conv_smap<bf16>', 'conv_px1<bf16>', 'conv_c8<bf16>')[form - 1]
+            base = ('conv_skinny<bf16>', 'conv_smap<bf16>', 'conv_px1<bf16>', 'conv_c8<bf16>', 'conv_head<bf16>')[form - 1]
         if _PROF_SHAPES:
             base += f' N{n} {h}x{w} ' + '+'.join(f'{s.x.shape[-1]}k{s.ksize}' for s in segs) + f'->{cout}' + \
                 ('g' if gate_x is not None else '') + ('p' if pool else '') + (f's{stats_mode}' if stats_mode else '')

@@ -889,6 +889,35 @@ def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
         np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize('n,c,gn', [(6, 256, 3), (5, 160, 0), (128, 256, 128)])
+def test_image_head_conv_bf16(n, c, gn):
+    """conv_head.hip: the generator's image head (mcgan.py:55-60: BatchNorm -> ReLU -> MC -> Conv3x3(C, 3) -> Tanh on 32x32
+    maps; C = 256, or a compacted 160) with double-buffered input windows; BatchNorm affine per statistics group of `gn`
+    images -- against F.conv2d on the CPU."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1701 + n + c)
+    groups = n // gn if gn else 1
+    x = _rnd(g, n, c, 32, 32)
+    scale, shift = _rnd(g, groups, c) * 0.5 + 1, _rnd(g, groups, c) * 0.3
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    wt, b = _rnd(g, 3, c, 3, 3) * 0.05, _rnd(g, 3)
+    idx = torch.arange(n) // gn if gn else torch.zeros(n, dtype=torch.long)
+    a = _q(x, dtype) * scale[idx][:, :, None, None] + shift[idx][:, :, None, None]
+    a = _q(torch.relu(a) * code[:, :, None, None], dtype)
+    ref = torch.tanh(F.conv2d(a, _q(wt, dtype), b, padding=1))
+    seg = ops.Seg(_nhwc(ops, x, dtype), scale=(scale if gn else scale[0]).cuda(), shift=(shift if gn else shift[0]).cuda(),
+                  code=code.cuda(), relu=True, group_n=gn)
+    ops.KERNEL_LOG = []
+    try:
+        y, _ = ops.conv_fused([seg], ops.prep_weight(wt.cuda(), dtype), 3, bias=b.cuda(), tanh=True)
+        assert ops.KERNEL_LOG == [5], ops.KERNEL_LOG
+    finally:
+        ops.KERNEL_LOG = None
+    assert y.shape[-1] == 8 and float(y[..., 3:].float().abs().max()) == 0.0
+    _assert_close(ops.to_nchw(y, 3), ref, dtype, 'image head')
+
+
 @pytest.mark.parametrize('n', [256, 128, 3])
 def test_image_conv_bf16(n):
     """conv_c8.hip: the discriminator's first convolution (FirstDisResBlock, mcgan.py:72-93: 3 -> 128 on the 32x32 image,
