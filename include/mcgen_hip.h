@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -301,6 +301,14 @@ int mcgen_sn_power_iter(const float* w_base, float* uv_base, const mcgen_sn_laye
  * this writes the clone from the kernels that produce the values.  Every float of the u/v buffer must belong to a layer. */
 int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                              float* sigma, float* workspace, int max_rows, int max_cols, float* uv_snap, void* stream);
+/* `rounds` successive training-mode power iterations of all layers in 2 * rounds + 1 launches (column-slice W^T u without
+ * row partials, the next round's u formed from the previous round's t on the fly; a paired discriminator update -- two
+ * rounds, train_gan.py:144-150 -- costs five launches instead of eight).  sigma: [rounds, nlayers]; uv_snap (or NULL):
+ * [rounds, uv_total] receives (u, v) after every round (the forward's copy, as mcgen_sn_power_iter_snap); workspace as
+ * mcgen_sn_power_iter.  Layers up to 1024 rows. */
+int mcgen_sn_power_iter_rounds(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                               int rounds, float* sigma, float* workspace, int max_rows, int max_cols,
+                               float* uv_snap, int64_t uv_total, void* stream);
 /* `rounds` successive power iterations of every layer in ONE launch (one workgroup per layer; u, v, W v stay in LDS):
  * sigma[r][l] and -- when uv_snap != NULL -- the whole u/v buffer as it stands after round r (uv_snap[r][uv_total]:
  * torch's hook clones u, v for the backward, torch/nn/utils/spectral_norm.py) are written per round; uv_base holds the

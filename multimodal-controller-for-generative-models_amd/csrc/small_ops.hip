@@ -501,6 +501,109 @@ __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
     } else if (threadIdx.x == 0) sigma[blockIdx.x] = a;
 }
 
+// ---- power iteration in TWO launches per round (training mode, several rounds per call) ---------------------------
+// The four kernels above are launch-latency chains (4.7-4.9 us each for 4 MB of weights), and a paired discriminator
+// update runs two rounds: eight launches.  Here a round is
+//   c1  column slices: vt[j] = sum_i W[i][j] u[i] over ALL rows (no row-slice partials to combine), |vt|^2 per slice;
+//       from the second round on u = t / |t| is formed on the fly from the previous round's t (its k4), and slice 0
+//       writes that u, its snapshot and the previous round's sigma;
+//   c3  row slices: t[i] = (W[i][:] . vt) / |vt|  (= W v), and slice s normalises columns slice s of v (state + snapshot);
+// and one k4 closes the last round: 2 R + 1 launches instead of 4 R.  v / max(|v|, eps) as torch's normalize.
+constexpr int SN_CS = 32;
+__global__ __launch_bounds__(256)
+void sn_c1_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws,
+                  int ws_stride, int v_off, int n_off, int t_off, int from_t, float* sigma_prev, float* snap_prev) {
+    __shared__ float red[32];
+    __shared__ float su[1024];
+    __shared__ float part[4][64];
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* W = wb + L.w_off;
+    float* wl = ws + (size_t)blockIdx.x * ws_stride;
+    const int rows = L.rows, cols = L.cols, tid = threadIdx.x;
+    float* u = uvb + L.u_off;
+    if (from_t) {
+        const float* t = wl + t_off;
+        float a = 0.f;
+        for (int i = tid; i < rows; i += blockDim.x) a += t[i] * t[i];
+        a = block_sum(a, red);
+        const float inv = 1.f / fmaxf(sqrtf(a), 1e-12f);
+        for (int i = tid; i < rows; i += blockDim.x) {
+            const float x = t[i] * inv;
+            su[i] = x;
+            if (blockIdx.y == 0) { u[i] = x; if (snap_prev) snap_prev[L.u_off + i] = x; }
+        }
+        if (blockIdx.y == 0 && tid == 0) sigma_prev[blockIdx.x] = a * inv;
+    } else {
+        for (int i = tid; i < rows; i += blockDim.x) su[i] = u[i];
+    }
+    __syncthreads();
+    const int per = (cols + SN_CS - 1) / SN_CS;
+    const int c0 = blockIdx.y * per;
+    const int wave = tid >> 6, lane = tid & 63;
+    float qsum = 0.f;
+    for (int jb = 0; jb < per; jb += 64) {                            // (64 columns per pass: one for layers up to 2048 columns)
+        const int j = c0 + jb + lane;
+        const bool live = jb + lane < per && j < cols;
+        float s = 0.f;
+        if (live) {
+            // four independent partial sums per wave (rows = wave + 4 k + 16 m), combined pairwise: the rounding error of a
+            // column stays at that of the 32-slice form (one serial chain over rows / 4 terms measurably moved sigma)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int i = wave;
+            for (; i + 12 < rows; i += 16) {
+                a0 = fmaf(W[(size_t)i * cols + j], su[i], a0);
+                a1 = fmaf(W[(size_t)(i + 4) * cols + j], su[i + 4], a1);
+                a2 = fmaf(W[(size_t)(i + 8) * cols + j], su[i + 8], a2);
+                a3 = fmaf(W[(size_t)(i + 12) * cols + j], su[i + 12], a3);
+            }
+            for (; i < rows; i += 4) a0 = fmaf(W[(size_t)i * cols + j], su[i], a0);
+            s = (a0 + a1) + (a2 + a3);
+        }
+        if (jb > 0) __syncthreads();                                  // the previous pass's reads of `part`
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0) {
+            const float v = live ? (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]) : 0.f;
+            if (live) wl[v_off + j] = v;
+            qsum = fmaf(v, v, qsum);
+        }
+    }
+    if (wave == 0) {
+        for (int o = 32; o > 0; o >>= 1) qsum += __shfl_down(qsum, o);
+        if (lane == 0) wl[n_off + blockIdx.y] = qsum;
+    }
+}
+__global__ __launch_bounds__(256)
+void sn_c3_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer_t* __restrict__ layers, float* __restrict__ ws,
+                  int ws_stride, int v_off, int n_off, int t_off, float* snap) {
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    const float* W = wb + L.w_off;
+    float* wl = ws + (size_t)blockIdx.x * ws_stride;
+    const float* vt = wl + v_off;
+    const int rows = L.rows, cols = L.cols, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    float nn = lane < SN_CS ? wl[n_off + lane] : 0.f;                 // every wave: the slices' squared norms, fixed order
+    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
+    const float inv = 1.f / fmaxf(sqrtf(nn), 1e-12f);
+    const int per = (rows + SN_RS - 1) / SN_RS;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    for (int i = r0 + wave; i < r1; i += nw) {
+        float s = 0.f;
+#pragma unroll 6
+        for (int j = lane; j < cols; j += 64) s = fmaf(W[(size_t)i * cols + j], vt[j] * inv, s);      // (v itself, as the four-kernel form)
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) wl[t_off + i] = s;
+    }
+    // this block's column slice of the normalised v: the state and the forward's copy
+    const int cper = (cols + SN_CS - 1) / SN_CS, c0 = blockIdx.y * cper;
+    float* v = uvb + L.v_off;
+    for (int j = c0 + tid; j < min(cols, c0 + cper); j += blockDim.x) {
+        const float x = vt[j] * inv;
+        v[j] = x;
+        if (snap) snap[L.v_off + j] = x;
+    }
+}
+
 // ---- fused power iteration: ONE launch for `rounds` successive iterations over all layers ------------------------
 // One 1024-thread workgroup per layer keeps u, v and t = W v in LDS and streams W (L2-resident: the largest layer of
 // the headline model is 128 x 1152 floats) twice per round:  v <- normalize(W^T u);  t = W v;  u <- normalize(t);
@@ -1120,6 +1223,26 @@ extern "C" int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, con
                                         float* sigma, float* workspace, int max_rows, int max_cols, float* uv_snap, void* stream) {
     MCGEN_CHECK(uv_snap, "sn_power_iter_snap: uv_snap is NULL");
     return sn_power_iter_impl(w_base, uv_base, layers_dev, nlayers, 1, sigma, workspace, max_rows, max_cols, uv_snap, stream);
+}
+extern "C" int mcgen_sn_power_iter_rounds(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
+                                          int rounds, float* sigma, float* workspace, int max_rows, int max_cols,
+                                          float* uv_snap, int64_t uv_total, void* stream) {
+    MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0 && rounds >= 1 && max_rows > 0 && max_cols > 0,
+                "sn_power_iter_rounds: bad arguments (workspace: nlayers * (32 * max_cols + max_rows) floats, as mcgen_sn_power_iter)");
+    MCGEN_CHECK(max_rows <= 1024, "sn_power_iter_rounds: layers up to 1024 rows");
+    const int v_off = 0, n_off = max_cols, t_off = max_cols + SN_CS, ws_stride = SN_RS * max_cols + max_rows;   // (the four-kernel form's stride)
+    MCGEN_CHECK(t_off + max_rows <= ws_stride, "sn_power_iter_rounds: workspace plan");
+    for (int r = 0; r < rounds; ++r) {
+        float* snap_prev = (uv_snap && r > 0) ? uv_snap + (size_t)(r - 1) * uv_total : nullptr;
+        float* snap_r = uv_snap ? uv_snap + (size_t)r * uv_total : nullptr;
+        hipLaunchKernelGGL(sn_c1_kernel, dim3(nlayers, SN_CS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride,
+                           v_off, n_off, t_off, r > 0 ? 1 : 0, r > 0 ? sigma + (size_t)(r - 1) * nlayers : nullptr, snap_prev);
+        hipLaunchKernelGGL(sn_c3_kernel, dim3(nlayers, SN_RS), dim3(256), 0, STREAM(stream), w_base, uv_base, layers_dev, workspace, ws_stride,
+                           v_off, n_off, t_off, snap_r);
+    }
+    hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, 1,
+                       sigma + (size_t)(rounds - 1) * nlayers, uv_snap ? uv_snap + (size_t)(rounds - 1) * uv_total : nullptr);
+    MCGEN_LAUNCH_CHECK("sn_power_iter_rounds"); return 0;
 }
 extern "C" int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                          int rounds, int do_iter, float* sigma, float* uv_snap, int64_t uv_total,

@@ -90,6 +90,8 @@ _PAIR_WGRAD = _flag('MCGEN_PAIR_WGRAD', '1') != '0'
 # one-launch multi-round power iteration (mcgen_sn_power_iter_fused): opt-in -- one workgroup per layer streams W through a
 # single CU and measured 0.08 ms / iteration SLOWER than the four row-sliced kernels that fill the chip (tools/ab_bench.sh)
 _SN_FUSED = _flag('MCGEN_SN_FUSED', '0') == '1'
+# training-mode power iterations as 2 launches per round + 1 (ops.sn_power_iter_rounds) instead of 4 per round
+_SN_ROUNDS = _flag('MCGEN_SN_ROUNDS', '1') != '0'
 _BUCKETS = _flag('MCGEN_BUCKETS', '1') != '0'        # two gradient buckets per network (callers ask for them only when world > 1)
 # mode-compacted forward convolutions (bf16, maps >= 16x16, conv_a launches): opt-in -- measured x1.10 on those launches
 # (tools/bench_mc.py), about 0.5 % of the step after the map / K-major image launches are paid: see DESIGN.md section 4.6
@@ -625,6 +627,12 @@ class DiscriminatorEngine:
         round -- torch's hook clones u, v for the backward pass, the snapshot is that clone."""
         fp, fuv = self._ensure_flat()
         nsn = len(self.sn)
+        if train and _SN_ROUNDS and not _SN_FUSED and rounds >= int(_flag('MCGEN_SN_ROUNDS_MIN', '1')):
+            sigma, snap = ops.sn_power_iter_rounds(fp, fuv, self._layers_dev, nsn, rounds,
+                                                   max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
+            for s in self.sn:
+                _bump(s.m.weight_u); _bump(s.m.weight_v)
+            return [(sigma[r], snap[r]) for r in range(rounds)]
         if not _SN_FUSED:                                   # the four-kernel form, one round per call
             out = []
             for _ in range(rounds):

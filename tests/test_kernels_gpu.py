@@ -421,6 +421,21 @@ def test_spectral_norm_kernels():
     assert torch.equal(snap[1], UVb)
     se, _ = ops.sn_power_iter_fused(W, UVb, ld, len(sn), 1, False, 24, 144, snapshot=False)
     np.testing.assert_allclose(se[0].cpu(), sf[1].cpu(), rtol=1e-5)
+    # the rounds form (2 launches per round + 1; the next round's u formed from the previous round's t): same numbers
+    for rounds in (1, 2, 3):
+        UVc = UV.clone()
+        UVr = UV.clone()
+        refs = []
+        for _ in range(rounds):
+            sr = torch.zeros_like(sigma)
+            ops.sn_power_iter(W, UVr, ld, len(sn), True, sr, 24, 144)
+            refs.append((sr, UVr.clone()))
+        sg, sp = ops.sn_power_iter_rounds(W, UVc, ld, len(sn), rounds, 24, 144)
+        for r in range(rounds):
+            np.testing.assert_allclose(sg[r].cpu(), refs[r][0].cpu(), rtol=1e-5)
+            np.testing.assert_allclose(sp[r].cpu(), refs[r][1].cpu(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(UVc.cpu(), UVr.cpu(), rtol=1e-4, atol=1e-6)
+        assert torch.equal(sp[rounds - 1], UVc)
     # eval mode: no iteration, same sigma formula
     sig2 = torch.zeros_like(sigma)
     UV2 = UV.clone()

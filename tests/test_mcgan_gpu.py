@@ -590,9 +590,11 @@ def test_fused_discriminator_update_equals_fix_then_adam(dtype):
     for a_, b_ in ((m1, m0), (v1, v0)):
         assert float((a_ - b_).abs().max()) <= rel * float(b_.abs().max()) + 1e-12
     for k in s1:
-        # (generator: a conv bias in front of a BatchNorm has an exact-zero gradient, so Adam turns the SIGN of its rounding
-        # residue into a step of ~0.6 lr -- DESIGN.md section 2; the discriminator, whose update this test is about, is tight)
-        tol = rel * (1 + float(s0[k].abs().max())) if k.startswith('discriminator.') else 3e-4
+        # (generator: its single update is Adam's FIRST step, +-lr per element whatever |g| -- an element whose gradient is a
+        # rounding residue (a conv bias in front of a BatchNorm: exact-zero gradient; in bf16 also
+        # elements that a last-bit difference of the discriminator moves across zero) can land on the other sign: 2 lr =
+        # 4e-4 apart; the discriminator, whose update this test is about, is tight)
+        tol = rel * (1 + float(s0[k].abs().max())) if k.startswith('discriminator.') else 4.5e-4
         assert float((s1[k] - s0[k]).abs().max()) <= tol, k
 
 
