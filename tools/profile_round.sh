@@ -9,7 +9,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --sustain-steps 0 > $OUT/bench_trace.log 2>&1
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sustain-steps 0 > $OUT/bench_fetch.log 2>&1
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sustain-steps 0 > $OUT/bench_write.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sustain-steps 0 --real-data uniform --pool 1 > $OUT/bench_fetch.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sustain-steps 0 --real-data uniform --pool 1 > $OUT/bench_write.log 2>&1
 find $OUT -name "*.csv" | head -20
 tail -c 400 $OUT/bench_trace.log

@@ -19,6 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def bench_name(k: str):
     """rocprof kernel symbol -> the name bench.py's roofline.by_kernel uses (None: not a conv/wgrad kernel)."""
+    for sym, name in (('conv_img_kernel', 'conv_smap<bf16>'), ('conv_px1_kernel', 'conv_px1<bf16>'), ('conv_c8_kernel', 'conv_c8<bf16>'),
+                      ('conv_head_kernel', 'conv_head<bf16>'), ('conv_skinny_kernel', 'conv_skinny<bf16>')):
+        if sym in k:                                            # round 3: whole-image / resident-tile / image-layer kernels (bf16 only)
+            return name
     m = re.search(r'conv_\w+?_kernelI(DF16b|f)Li(\d+)ELi(\d+)E', k)
     if m:
         return f'conv_fused<{"bf16" if m.group(1) == "DF16b" else "f32"},{m.group(2)},{m.group(3)}>'
