@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -254,6 +254,9 @@ typedef struct { const float* codebook; int64_t out_off; int32_t M, C; int32_t s
  * scale[descs[j].scale_idx] (scale_idx < 0 or scale == NULL: no scaling) */
 int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
                         const float* scale, int n_half, void* stream);
+/* the same for one-hot indicators given as int64 labels: code_j[n, :] = codebook_j[label[n], :] (every C a multiple of 4;
+ * labels outside 0 .. M-1 are clamped) */
+int mcgen_mc_gather_batch(const int64_t* label, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream);
 /* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);
@@ -434,6 +437,26 @@ int mcgen_actnorm_bwd(const float* partials, int tiles, int pitch, int C, const 
 int mcgen_invconv_bwd(const float* w_p, const float* w_l, const float* w_u, const float* w_s, const float* s_sign,
                       const float* dW, int C, int ldw, float ld_coef, float* dw_l, float* dw_u, float* dw_s,
                       int accumulate, void* stream);
+/* ---- batched forms of the per-module MCGlow kernels above: all modules of a pass in one launch per kind (the job
+ * table travels by value, MCGEN_GLOW_BATCH_MAX jobs per launch).  Same arithmetic per job as the single forms; the
+ * parameter-only log-determinants of all flows are added to logdet[n] as ONE sum (mcglow.py:46-47,101). */
+#define MCGEN_GLOW_BATCH_MAX 24
+#define MCGEN_GLOW_PLD_MAX 64
+typedef struct { const float* loc; const float* scale; float* a; float* b; float* negloc; int32_t C, Cp; } mcgen_an_affine_t;
+typedef struct { const float* scale; const float* w_s; int32_t C, Cw; float hw; int32_t _pad; } mcgen_pld_t;
+typedef struct { const float *w_p, *w_l, *w_u, *w_s, *s_sign; float* weight; float* weight_inv; int32_t C, _pad; } mcgen_icw_t;
+typedef struct { const float *w_p, *w_l, *w_u, *w_s, *s_sign; const float* dW; float *dw_l, *dw_u, *dw_s;
+                 int32_t C, ldw, accumulate; float ld_coef; } mcgen_icb_t;
+typedef struct { const float* partials; const float* scale; float* dloc; float* dscale;
+                 int32_t tiles, pitch, C, input_side, accumulate; float ld_coef; } mcgen_an_bwd_t;
+typedef struct { const void* a; const void* b; float* out; int64_t pixels; int32_t pitch_a, pitch_b, C, accumulate;
+                 float alpha; int32_t _pad; } mcgen_pcs_t;
+int mcgen_actnorm_affine_batch(const mcgen_an_affine_t* jobs, int n, void* stream);
+int mcgen_glow_param_logdet_batch(const mcgen_pld_t* jobs, int n, float* logdet, int N, void* stream);
+int mcgen_invconv_weight_batch(const mcgen_icw_t* jobs, int n, void* stream);
+int mcgen_invconv_bwd_batch(const mcgen_icb_t* jobs, int n, void* stream);
+int mcgen_actnorm_bwd_batch(const mcgen_an_bwd_t* jobs, int n, void* stream);
+int mcgen_prod_colsum_batch(const mcgen_pcs_t* jobs, int n, int dtype, float* workspace /* n * 256 * max C floats */, void* stream);
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) over one flat gradient buffer (train_vae.py:110) */
 int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* norm_out, float* workspace /* 256 floats */, void* stream);
 

@@ -65,6 +65,38 @@ class Code(C.Structure):
                 ('scale_idx', C.c_int32), ('_pad', C.c_int32)]
 
 
+class AnAffine(C.Structure):                               # mcgen_an_affine_t
+    _fields_ = [('loc', C.c_void_p), ('scale', C.c_void_p), ('a', C.c_void_p), ('b', C.c_void_p), ('negloc', C.c_void_p),
+                ('C', C.c_int32), ('Cp', C.c_int32)]
+
+
+class Pld(C.Structure):                                    # mcgen_pld_t
+    _fields_ = [('scale', C.c_void_p), ('w_s', C.c_void_p), ('C', C.c_int32), ('Cw', C.c_int32), ('hw', C.c_float), ('_pad', C.c_int32)]
+
+
+class Icw(C.Structure):                                    # mcgen_icw_t
+    _fields_ = [('w_p', C.c_void_p), ('w_l', C.c_void_p), ('w_u', C.c_void_p), ('w_s', C.c_void_p), ('s_sign', C.c_void_p),
+                ('weight', C.c_void_p), ('weight_inv', C.c_void_p), ('C', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Icb(C.Structure):                                    # mcgen_icb_t
+    _fields_ = [('w_p', C.c_void_p), ('w_l', C.c_void_p), ('w_u', C.c_void_p), ('w_s', C.c_void_p), ('s_sign', C.c_void_p),
+                ('dW', C.c_void_p), ('dw_l', C.c_void_p), ('dw_u', C.c_void_p), ('dw_s', C.c_void_p),
+                ('C', C.c_int32), ('ldw', C.c_int32), ('accumulate', C.c_int32), ('ld_coef', C.c_float)]
+
+
+class AnBwd(C.Structure):                                  # mcgen_an_bwd_t
+    _fields_ = [('partials', C.c_void_p), ('scale', C.c_void_p), ('dloc', C.c_void_p), ('dscale', C.c_void_p),
+                ('tiles', C.c_int32), ('pitch', C.c_int32), ('C', C.c_int32), ('input_side', C.c_int32), ('accumulate', C.c_int32),
+                ('ld_coef', C.c_float)]
+
+
+class Pcs(C.Structure):                                    # mcgen_pcs_t
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('out', C.c_void_p), ('pixels', C.c_int64),
+                ('pitch_a', C.c_int32), ('pitch_b', C.c_int32), ('C', C.c_int32), ('accumulate', C.c_int32),
+                ('alpha', C.c_float), ('_pad', C.c_int32)]
+
+
 class SnLayer(C.Structure):
     _fields_ = [('w_off', C.c_int64), ('u_off', C.c_int64), ('v_off', C.c_int64),
                 ('rows', C.c_int32), ('cols', C.c_int32)]
@@ -99,6 +131,12 @@ SYMBOLS = {
     'mcgen_copy_channels': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i64, _i, _vp]),
     'mcgen_glow_coupling_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
     'mcgen_gaussian_logp_bwd': (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _f, _i64, _i, _i, _vp]),
+    'mcgen_actnorm_affine_batch': (_i, [_vp, _i, _vp]),
+    'mcgen_glow_param_logdet_batch': (_i, [_vp, _i, _vp, _i, _vp]),
+    'mcgen_invconv_weight_batch': (_i, [_vp, _i, _vp]),
+    'mcgen_invconv_bwd_batch': (_i, [_vp, _i, _vp]),
+    'mcgen_actnorm_bwd_batch': (_i, [_vp, _i, _vp]),
+    'mcgen_prod_colsum_batch': (_i, [_vp, _i, _i, _vp, _vp]),
     'mcgen_prod_colsum': (_i, [_vp, _i, _vp, _i, _i, _i64, _i, _vp, _f, _i, _vp, _vp]),
     'mcgen_actnorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _vp]),
     'mcgen_invconv_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
@@ -127,6 +165,7 @@ SYMBOLS = {
     'mcgen_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_pool2_sum': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mcgen_mc_gather_batch': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -69,12 +69,38 @@ __global__ void actnorm_init_kernel(const float* __restrict__ part, int tiles, i
     scale[c] = (float)(1.0 / (sqrt(var) + 1e-6));
 }
 // prologue vectors of the op that consumes an ActNorm: y = s * (x + loc) = x * s + s * loc
+__device__ __forceinline__ void actnorm_affine_body(const float* loc, const float* scale, int C, int Cp, float* a, float* b, float* negloc) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < Cp; c += gridDim.x * blockDim.x) {
+        a[c] = c < C ? scale[c] : 0.f;
+        b[c] = c < C ? scale[c] * loc[c] : 0.f;
+        if (negloc) negloc[c] = c < C ? -loc[c] : 0.f;       // "mean" of the backward gate: x - mean = x + loc
+    }
+}
 __global__ void actnorm_affine_kernel(const float* loc, const float* scale, int C, int Cp, float* a, float* b, float* negloc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cp) return;
-    a[c] = c < C ? scale[c] : 0.f;
-    b[c] = c < C ? scale[c] * loc[c] : 0.f;
-    if (negloc) negloc[c] = c < C ? -loc[c] : 0.f;       // "mean" of the backward gate: x - mean = x + loc
+    actnorm_affine_body(loc, scale, C, Cp, a, b, negloc);
+}
+// Batched forms (blockIdx.y = job, the job table travels by value in the kernel arguments: graph-capture safe).  MCGlow
+// at K = 16, L = 3 runs 144 ActNorms, 48 LU weights and 51 ZeroConv2d scales per step: as one launch each per KIND instead
+// of one per module -- these launches were ~700 of the step's 1400, 3-6 us apiece.
+struct AnAffineJobs { mcgen_an_affine_t j[MCGEN_GLOW_BATCH_MAX]; };
+__global__ void actnorm_affine_batch_kernel(const AnAffineJobs jobs) {
+    const mcgen_an_affine_t& j = jobs.j[blockIdx.y];
+    actnorm_affine_body(j.loc, j.scale, j.C, j.Cp, j.a, j.b, j.negloc);
+}
+struct PldJobs { mcgen_pld_t j[MCGEN_GLOW_PLD_MAX]; };
+// all flows' parameter-only log-determinants in one launch: logdet[n] += sum_f hw_f * (sum log|scale_f| + sum w_s_f)
+__global__ void glow_param_logdet_batch_kernel(const PldJobs jobs, int njobs, float* __restrict__ logdet, int N) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (int f = 0; f < njobs; ++f) {
+        const mcgen_pld_t& j = jobs.j[f];
+        float t = 0.f;
+        for (int i = threadIdx.x; i < j.C; i += blockDim.x) t += logf(fabsf(j.scale[i]));
+        for (int i = threadIdx.x; i < j.Cw; i += blockDim.x) t += j.w_s[i];
+        s = fmaf(j.hw, t, s);
+    }
+    s = block_sum_g(s, red);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) logdet[n] += s;
 }
 // parameter-only log-determinant of a flow (mcglow.py:46-47,101): logdet[n] += HW * (sum log|scale| + sum w_s), one launch
 __global__ void glow_param_logdet_kernel(const float* __restrict__ scale, int C, const float* __restrict__ ws, int Cw, float hw,
@@ -89,9 +115,9 @@ __global__ void glow_param_logdet_kernel(const float* __restrict__ scale, int C,
 
 // ---- InvConv2dLU.calc_weight (mcglow.py:105-111) and its inverse, one workgroup, C <= 64 -----------------------
 // W = P (L o l_mask + I) (U o u_mask + diag(s_sign * exp(w_s)))
-__global__ void invconv_weight_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
-                                      const float* __restrict__ ws, const float* __restrict__ ssign, int C,
-                                      float* __restrict__ W, float* __restrict__ Winv) {
+__device__ void invconv_weight_body(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                    const float* __restrict__ ws, const float* __restrict__ ssign, int C,
+                                    float* __restrict__ W, float* __restrict__ Winv) {
     extern __shared__ float sh[];
     float* Lm = sh; float* Um = sh + C * C; float* A = sh + 2 * C * C; float* B = sh + 3 * C * C;
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
@@ -149,6 +175,16 @@ __global__ void invconv_weight_kernel(const float* __restrict__ wp, const float*
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) Winv[i] = A[i];
+}
+__global__ void invconv_weight_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                      const float* __restrict__ ws, const float* __restrict__ ssign, int C,
+                                      float* __restrict__ W, float* __restrict__ Winv) {
+    invconv_weight_body(wp, wl, wu, ws, ssign, C, W, Winv);
+}
+struct IcwJobs { mcgen_icw_t j[MCGEN_GLOW_BATCH_MAX]; };
+__global__ void invconv_weight_batch_kernel(const IcwJobs jobs) {
+    const mcgen_icw_t& j = jobs.j[blockIdx.x];
+    invconv_weight_body(j.w_p, j.w_l, j.w_u, j.w_s, j.s_sign, j.C, j.weight, j.weight_inv);
 }
 
 // ---- affine coupling (mcglow.py:153-175), one workgroup per sample --------------------------------------------
@@ -272,9 +308,8 @@ __global__ void gaussian_logp_bwd_kernel(const T* __restrict__ z, int Cpz, int c
 }
 // out[c] (+)= alpha * sum_p a[p, c] * b[p, c]   (two stages, fixed order)
 template <typename T>
-__global__ __launch_bounds__(256)
-void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
-                        float* __restrict__ ws, size_t ppb) {
+__device__ __forceinline__ void prod_colsum_stage1_body(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
+                                                        float* __restrict__ ws, size_t ppb) {
     __shared__ float sh[4][64];
     const size_t p0 = blockIdx.x * ppb, p1 = (p0 + ppb < pixels) ? p0 + ppb : pixels;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -289,7 +324,24 @@ void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b
         __syncthreads();
     }
 }
-__global__ void prod_colsum_stage2(const float* __restrict__ ws, int blocks, int C, float* out, float alpha, int accumulate) {
+template <typename T>
+__global__ __launch_bounds__(256)
+void prod_colsum_stage1(const T* __restrict__ a, int pa, const T* __restrict__ b, int pb, size_t pixels, int C,
+                        float* __restrict__ ws, size_t ppb) {
+    prod_colsum_stage1_body<T>(a, pa, b, pb, pixels, C, ws, ppb);
+}
+static __host__ __device__ inline int pcs_blocks(long pixels) { return pixels < 1024 ? (int)((pixels + 3) / 4) : 256; }
+struct PcsJobs { mcgen_pcs_t j[MCGEN_GLOW_BATCH_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256)
+void prod_colsum_stage1_batch(const PcsJobs jobs, float* __restrict__ ws, int ws_stride) {
+    const mcgen_pcs_t& j = jobs.j[blockIdx.y];
+    const int blocks = pcs_blocks(j.pixels);
+    if ((int)blockIdx.x >= blocks) return;
+    prod_colsum_stage1_body<T>(reinterpret_cast<const T*>(j.a), j.pitch_a, reinterpret_cast<const T*>(j.b), j.pitch_b, (size_t)j.pixels, j.C,
+                               ws + (size_t)blockIdx.y * ws_stride, ((size_t)j.pixels + blocks - 1) / blocks);
+}
+__device__ __forceinline__ void prod_colsum_stage2_body(const float* __restrict__ ws, int blocks, int C, float* out, float alpha, int accumulate) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // one wave per channel
     if (c >= C) return;
     const int lane = threadIdx.x & 63;
@@ -298,12 +350,18 @@ __global__ void prod_colsum_stage2(const float* __restrict__ ws, int blocks, int
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if (lane == 0) { const float v = alpha * s; out[c] = accumulate ? out[c] + v : v; }
 }
+__global__ void prod_colsum_stage2(const float* __restrict__ ws, int blocks, int C, float* out, float alpha, int accumulate) {
+    prod_colsum_stage2_body(ws, blocks, C, out, alpha, accumulate);
+}
+__global__ void prod_colsum_stage2_batch(const PcsJobs jobs, const float* __restrict__ ws, int ws_stride) {
+    const mcgen_pcs_t& j = jobs.j[blockIdx.y];
+    prod_colsum_stage2_body(ws + (size_t)blockIdx.y * ws_stride, pcs_blocks(j.pixels), j.C, j.out, j.alpha, j.accumulate);
+}
 // ActNorm parameter gradients from the (sum dx, sum dx * (x + loc)) partials of a dgrad epilogue, where
 // dx is the gradient w.r.t. the ActNorm INPUT (dx = scale * du):
 //   dloc = sum dx,   dscale = (1/scale) * sum dx * (x + loc) + ld_coef / scale      (ld_coef = g * N * H * W or 0)
-__global__ __launch_bounds__(1024)
-void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
-                        float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
+__device__ __forceinline__ void actnorm_bwd_body(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
+                                                 float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
     __shared__ double sh[16][2][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -322,12 +380,24 @@ void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, in
     dloc[c] = accumulate ? dloc[c] + gl : gl;
     dscale[c] = accumulate ? dscale[c] + gs : gs;
 }
+__global__ __launch_bounds__(1024)
+void actnorm_bwd_kernel(const float* __restrict__ part, int tiles, int pitch, int C, const float* __restrict__ scale,
+                        float ld_coef, int input_side, float* dloc, float* dscale, int accumulate) {
+    actnorm_bwd_body(part, tiles, pitch, C, scale, ld_coef, input_side, dloc, dscale, accumulate);
+}
+struct AnBwdJobs { mcgen_an_bwd_t j[MCGEN_GLOW_BATCH_MAX]; };
+__global__ __launch_bounds__(1024)
+void actnorm_bwd_batch_kernel(const AnBwdJobs jobs) {
+    const mcgen_an_bwd_t& j = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.C) return;
+    actnorm_bwd_body(j.partials, j.tiles, j.pitch, j.C, j.scale, j.ld_coef, j.input_side, j.dloc, j.dscale, j.accumulate);
+}
 // InvConv2dLU parameter gradients from dW (gradient w.r.t. the C x C weight):  W = P L U,
 //   dL = P^T dW U^T (strictly lower part -> dw_l),  dU = (P L)^T dW (strictly upper -> dw_u,
 //   diagonal * sign * exp(w_s) + ld_coef -> dw_s)
-__global__ void invconv_bwd_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
-                                   const float* __restrict__ ws, const float* __restrict__ ssign, const float* __restrict__ dW,
-                                   int C, int ldw, float ld_coef, float* dwl, float* dwu, float* dws, int accumulate) {
+__device__ void invconv_bwd_body(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                 const float* __restrict__ ws, const float* __restrict__ ssign, const float* __restrict__ dW,
+                                 int C, int ldw, float ld_coef, float* dwl, float* dwu, float* dws, int accumulate) {
     extern __shared__ float sh[];
     float* Lm = sh; float* Um = sh + C * C; float* A = sh + 2 * C * C; float* B = sh + 3 * C * C;
     float* Pm = sh + 4 * C * C; float* G = sh + 5 * C * C;
@@ -358,6 +428,16 @@ __global__ void invconv_bwd_kernel(const float* __restrict__ wp, const float* __
         const float v = B[r * C + r] * ssign[r] * expf(ws[r]) + ld_coef;
         dws[r] = accumulate ? dws[r] + v : v;
     }
+}
+__global__ void invconv_bwd_kernel(const float* __restrict__ wp, const float* __restrict__ wl, const float* __restrict__ wu,
+                                   const float* __restrict__ ws, const float* __restrict__ ssign, const float* __restrict__ dW,
+                                   int C, int ldw, float ld_coef, float* dwl, float* dwu, float* dws, int accumulate) {
+    invconv_bwd_body(wp, wl, wu, ws, ssign, dW, C, ldw, ld_coef, dwl, dwu, dws, accumulate);
+}
+struct IcbJobs { mcgen_icb_t j[MCGEN_GLOW_BATCH_MAX]; };
+__global__ void invconv_bwd_batch_kernel(const IcbJobs jobs) {
+    const mcgen_icb_t& j = jobs.j[blockIdx.x];
+    invconv_bwd_body(j.w_p, j.w_l, j.w_u, j.w_s, j.s_sign, j.dW, j.C, j.ldw, j.ld_coef, j.dw_l, j.dw_u, j.dw_s, j.accumulate);
 }
 // global L2 norm of a flat gradient buffer (clip_grad_norm_, train_vae.py:110) and the scaled copy
 __global__ void sqsum_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
@@ -527,4 +607,104 @@ extern "C" int mcgen_clip_grad_norm(float* g, int64_t n, float max_norm, float* 
     hipLaunchKernelGGL(sqsum_kernel, dim3(blocks), dim3(256), 0, STREAM(stream), g, (size_t)n, workspace);
     hipLaunchKernelGGL(clip_scale_kernel, dim3(grid_for((size_t)n, 256, 1024)), dim3(256), 0, STREAM(stream), g, (size_t)n, workspace, blocks, max_norm, norm_out);
     MCGEN_LAUNCH_CHECK("clip_grad_norm"); return 0;
+}
+
+// ---- batched forms: one launch per kind for all modules of a pass (job tables by value, MCGEN_GLOW_BATCH_MAX per launch) ----
+template <typename J, typename F>
+static int glow_batches(const J* jobs, int n, int cap, F launch) {
+    for (int base = 0; base < n; base += cap) {
+        const int m = n - base < cap ? n - base : cap;
+        if (int rc = launch(jobs + base, m)) return rc;
+    }
+    return 0;
+}
+extern "C" int mcgen_actnorm_affine_batch(const mcgen_an_affine_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "actnorm_affine_batch: bad arguments");
+    return glow_batches(jobs, n, MCGEN_GLOW_BATCH_MAX, [&](const mcgen_an_affine_t* j, int m) {
+        AnAffineJobs t; int cpmax = 1;
+        for (int i = 0; i < m; ++i) {
+            MCGEN_CHECK(j[i].loc && j[i].scale && j[i].a && j[i].b && j[i].C > 0 && j[i].Cp >= j[i].C, "actnorm_affine_batch: bad job %d", i);
+            t.j[i] = j[i]; if (j[i].Cp > cpmax) cpmax = j[i].Cp;
+        }
+        for (int i = m; i < MCGEN_GLOW_BATCH_MAX; ++i) t.j[i] = t.j[0];
+        hipLaunchKernelGGL(actnorm_affine_batch_kernel, dim3((cpmax + 63) / 64, m), dim3(64), 0, STREAM(stream), t);
+        MCGEN_LAUNCH_CHECK("actnorm_affine_batch"); return 0;
+    });
+}
+extern "C" int mcgen_glow_param_logdet_batch(const mcgen_pld_t* jobs, int n, float* logdet, int N, void* stream) {
+    MCGEN_CHECK(jobs && n > 0 && logdet && N > 0, "glow_param_logdet_batch: bad arguments");
+    return glow_batches(jobs, n, MCGEN_GLOW_PLD_MAX, [&](const mcgen_pld_t* j, int m) {
+        PldJobs t;
+        for (int i = 0; i < m; ++i) { MCGEN_CHECK(j[i].scale && j[i].w_s && j[i].C > 0 && j[i].Cw > 0, "glow_param_logdet_batch: bad job %d", i); t.j[i] = j[i]; }
+        for (int i = m; i < MCGEN_GLOW_PLD_MAX; ++i) t.j[i] = t.j[0];
+        hipLaunchKernelGGL(glow_param_logdet_batch_kernel, dim3(1), dim3(256), 0, STREAM(stream), t, m, logdet, N);
+        MCGEN_LAUNCH_CHECK("glow_param_logdet_batch"); return 0;
+    });
+}
+extern "C" int mcgen_invconv_weight_batch(const mcgen_icw_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "invconv_weight_batch: bad arguments");
+    return glow_batches(jobs, n, MCGEN_GLOW_BATCH_MAX, [&](const mcgen_icw_t* j, int m) {
+        IcwJobs t; int cmax = 1;
+        for (int i = 0; i < m; ++i) {
+            MCGEN_CHECK(j[i].w_p && j[i].w_l && j[i].w_u && j[i].w_s && j[i].s_sign && j[i].weight && j[i].C > 0 && j[i].C <= 64, "invconv_weight_batch: bad job %d (C in 1..64)", i);
+            t.j[i] = j[i]; if (j[i].C > cmax) cmax = j[i].C;
+        }
+        for (int i = m; i < MCGEN_GLOW_BATCH_MAX; ++i) t.j[i] = t.j[0];
+        hipLaunchKernelGGL(invconv_weight_batch_kernel, dim3(m), dim3(256), 4 * cmax * cmax * sizeof(float), STREAM(stream), t);
+        MCGEN_LAUNCH_CHECK("invconv_weight_batch"); return 0;
+    });
+}
+extern "C" int mcgen_invconv_bwd_batch(const mcgen_icb_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "invconv_bwd_batch: bad arguments");
+    return glow_batches(jobs, n, MCGEN_GLOW_BATCH_MAX, [&](const mcgen_icb_t* j, int m) {
+        IcbJobs t; int cmax = 1;
+        for (int i = 0; i < m; ++i) {
+            MCGEN_CHECK(j[i].w_p && j[i].w_l && j[i].w_u && j[i].w_s && j[i].s_sign && j[i].dW && j[i].dw_l && j[i].dw_u && j[i].dw_s &&
+                        j[i].C > 0 && j[i].C <= 64 && j[i].ldw >= j[i].C, "invconv_bwd_batch: bad job %d", i);
+            t.j[i] = j[i]; if (j[i].C > cmax) cmax = j[i].C;
+        }
+        for (int i = m; i < MCGEN_GLOW_BATCH_MAX; ++i) t.j[i] = t.j[0];
+        const size_t lds = 6 * (size_t)cmax * cmax * sizeof(float);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(invconv_bwd_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * sizeof(float));
+            if (e != hipSuccess) return mcgen_fail("invconv_bwd_batch: cannot raise LDS limit: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(invconv_bwd_batch_kernel, dim3(m), dim3(1024), lds, STREAM(stream), t);
+        MCGEN_LAUNCH_CHECK("invconv_bwd_batch"); return 0;
+    });
+}
+extern "C" int mcgen_actnorm_bwd_batch(const mcgen_an_bwd_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n > 0, "actnorm_bwd_batch: bad arguments");
+    return glow_batches(jobs, n, MCGEN_GLOW_BATCH_MAX, [&](const mcgen_an_bwd_t* j, int m) {
+        AnBwdJobs t; int cmax = 1;
+        for (int i = 0; i < m; ++i) {
+            MCGEN_CHECK(j[i].partials && j[i].scale && j[i].dloc && j[i].dscale && j[i].tiles > 0 && j[i].pitch >= j[i].C && j[i].C > 0, "actnorm_bwd_batch: bad job %d", i);
+            t.j[i] = j[i]; if (j[i].C > cmax) cmax = j[i].C;
+        }
+        for (int i = m; i < MCGEN_GLOW_BATCH_MAX; ++i) t.j[i] = t.j[0];
+        hipLaunchKernelGGL(actnorm_bwd_batch_kernel, dim3((cmax + 63) / 64, m), dim3(1024), 0, STREAM(stream), t);
+        MCGEN_LAUNCH_CHECK("actnorm_bwd_batch"); return 0;
+    });
+}
+extern "C" int mcgen_prod_colsum_batch(const mcgen_pcs_t* jobs, int n, int dtype, float* workspace, void* stream) {
+    MCGEN_CHECK(jobs && n > 0 && workspace, "prod_colsum_batch: bad arguments (workspace: n * 256 * max C floats)");
+    int cmax = 1;
+    for (int i = 0; i < n; ++i) {
+        MCGEN_CHECK(jobs[i].a && jobs[i].b && jobs[i].out && jobs[i].pixels > 0 && jobs[i].C > 0, "prod_colsum_batch: bad job %d", i);
+        if (jobs[i].C > cmax) cmax = jobs[i].C;
+    }
+    const int ws_stride = 256 * cmax;
+    int base_done = 0;
+    return glow_batches(jobs, n, MCGEN_GLOW_BATCH_MAX, [&](const mcgen_pcs_t* j, int m) {
+        PcsJobs t;
+        for (int i = 0; i < m; ++i) t.j[i] = j[i];
+        for (int i = m; i < MCGEN_GLOW_BATCH_MAX; ++i) t.j[i] = t.j[0];
+        float* ws = workspace + (size_t)base_done * ws_stride;
+        base_done += m;
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL(prod_colsum_stage1_batch<float>, dim3(256, m), dim3(256), 0, STREAM(stream), t, ws, ws_stride),
+            hipLaunchKernelGGL(prod_colsum_stage1_batch<bf16_t>, dim3(256, m), dim3(256), 0, STREAM(stream), t, ws, ws_stride));
+        hipLaunchKernelGGL(prod_colsum_stage2_batch, dim3((cmax + 3) / 4, m), dim3(256), 0, STREAM(stream), t, ws, ws_stride);
+        MCGEN_LAUNCH_CHECK("prod_colsum_batch"); return 0;
+    });
 }

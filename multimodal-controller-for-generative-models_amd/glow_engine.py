@@ -28,6 +28,8 @@ class GlowEngine:
         self._gsink = None          # id(param) -> gradient tensor while an autograd backward is collecting
         self.assume_initialized = False   # set by a graph capture: skip the host read of ActNorm.initialized
         self._const = {}
+        self._pass = None                          # per-pass batches (ActNorm vectors, codes): _begin_pass
+        self._dfr = None                           # deferred parameter-gradient reductions of a backward pass
 
     def _full(self, value: float, n: int, device) -> Tensor:
         key = (value, n, str(device))
@@ -57,6 +59,10 @@ class GlowEngine:
             self._rs = {id(z): r for z, r in zip(zcs, rs)}
             self._wmat = {}
         jobs, keys = [], []
+        if not backward:
+            ics = [f.invconv for b in m.blocks for f in b.flows]
+            for ic, wmat in zip(ics, ops.invconv_weight_batch(ics)):      # every flow's LU weight, two launches
+                self._wmat[id(ic)] = wmat
 
         def add(key, w, **kw):
             keys.append(key); jobs.append((w.detach(), dict(kw, transpose=backward)))
@@ -67,8 +73,7 @@ class GlowEngine:
                 conv0, an1, conv1, an5, zc = net[0].module, net[1].module, net[4].module, net[5].module, net[8].module
                 hid, ic, rs = conv0.out_channels, flow.invconv, self._rs[id(zc)]
                 if not backward:
-                    wmat, _ = ops.invconv_weight(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign)
-                    self._wmat[id(ic)] = wmat
+                    wmat = self._wmat[id(ic)]
                     add((id(conv0), 'f'), conv0.weight, k_img=cp)
                     add((id(conv1), 'f'), conv1.weight)
                     add((id(zc), 'f'), zc.conv.weight, row_scale=rs, k_img=hid)
@@ -96,6 +101,9 @@ class GlowEngine:
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _actnorm(self, an, x_stats_fn, count, train: bool, cp: int):
         """Prologue vectors (a, b) of an ActNorm; runs the data-dependent init on the first training forward."""
+        cached = self._pass.get('an') if self._pass else None
+        if cached is not None:
+            return cached[id(an)]
         if train and not self.assume_initialized and int(an.initialized) == 0:
             ops.actnorm_init(x_stats_fn(), count, an.loc.data, an.scale.data)
             an.initialized.fill_(1)
@@ -146,7 +154,8 @@ class GlowEngine:
         out, _ = ops.conv_fused([Seg(x, ksize=1, scale=a, shift=b)],
                                 self._img((id(ic), 'f'), lambda: ops.prep_weight_ex(wmat, dt, 1, k_img=cp)), c, cy=cp)
         # parameter-only log-determinants: H*W * (sum log|scale| + sum w_s)   (mcglow.py:46-47,101)
-        ops.glow_param_logdet(flow.actnorm.scale.detach(), ic.w_s.detach(), h * w, logdet)
+        if not (self._pass and self._pass.get('logdet')):
+            ops.glow_param_logdet(flow.actnorm.scale.detach(), ic.w_s.detach(), h * w, logdet)
         net = flow.coupling.net
         codes = self._codes(net, indicator, label)
         rec = None if tape is None else dict(x=x, a=a, b=b, nl=nl, out=out, codes=codes, wmat=wmat)
@@ -156,11 +165,42 @@ class GlowEngine:
             tape.append(rec)
         return ops.glow_coupling(out, hz, c, logdet, reverse=False, accumulate=True)
 
-    @staticmethod
-    def _codes(net, indicator, label):
+    def _codes(self, net, indicator, label):
+        cached = self._pass.get('codes') if self._pass else None
+        if cached is not None:
+            return cached[id(net[3])], cached[id(net[7])]
         if label is not None:
             return net[3].code_of_labels(label), net[7].code_of_labels(label)
         return net[3].code(indicator), net[7].code(indicator)
+
+    def _begin_pass(self, train: bool, label, n: int, logdet):
+        """Per-pass batches of what depends on the parameters (and labels) alone: every ActNorm's prologue vectors, every
+        MultimodalController's codes, all parameter-only log-determinants -- one launch per kind instead of one per module
+        (~390 of a step's launches).  Needs initialised ActNorms (the data-dependent init runs module by module)."""
+        self._pass = {}
+        if not (self.assume_initialized or not train):
+            return
+        m = self.m
+        ans, cps, lds = [], [], []
+        for blk, (c, cp) in zip(m.blocks, self._block_dims()):
+            for flow in blk.flows:
+                net = flow.coupling.net
+                hid = net[0].module.out_channels
+                ans += [flow.actnorm, net[1].module, net[5].module]; cps += [cp, hid, hid]
+        self._pass['an'] = {id(an): v for an, v in zip(ans, ops.actnorm_affine_batch(ans, cps))}
+        if label is not None:
+            mcs = [mc for blk in m.blocks for f in blk.flows for mc in (f.coupling.net[3], f.coupling.net[7])]
+            if getattr(self, '_code_batch', None) is None or [id(x) for x in self._code_batch.mcs] != [id(x) for x in mcs]:
+                self._code_batch = ops.CodeBatch(mcs)
+            self._pass['codes'] = {id(mc): cd for mc, cd in zip(mcs, self._code_batch.run_labels(label))}
+        if logdet is not None:
+            hw = int(m.data_shape[1]) * int(m.data_shape[2])
+            items = []
+            for blk in m.blocks:
+                hw //= 4
+                items += [(f.actnorm.scale.detach(), f.invconv.w_s.detach(), hw) for f in blk.flows]
+            ops.glow_param_logdet_batch(items, logdet)
+            self._pass['logdet'] = True
 
     def _flow_reverse(self, flow, y: Tensor, c: int, indicator: Tensor, label=None) -> Tensor:
         dt = self.dtype
@@ -187,6 +227,7 @@ class GlowEngine:
         x = ops.to_nhwc(x0.contiguous(), dt)
         logdet = torch.zeros(n, dtype=torch.float32, device=img.device)
         logp = torch.zeros(n, dtype=torch.float32, device=img.device)
+        self._begin_pass(train, label, n, logdet)
         zs: List[Tensor] = []
         for blk in m.blocks:
             x = ops.glow_squeeze(x, c)
@@ -220,6 +261,7 @@ class GlowEngine:
         n_pixel = float(img[0].numel())
         loss = -(-math.log(256.) * n_pixel + logdet + logp) / (math.log(2.) * n_pixel)       # loss_fn, mcglow.py:283-293
         loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss) if train else loss[~torch.isnan(loss)]
+        self._pass = None                           # (the batches belong to this pass's parameters)
         return loss.mean(), zs
 
     # ---- backward: gradients of the mean bits/dim w.r.t. every parameter -------------------------------------------
@@ -241,7 +283,7 @@ class GlowEngine:
         rs = getattr(self, '_rs', {}).get(id(zc)) if getattr(self, '_I', None) else None
         if rs is None:
             rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
-        ops.prod_colsum(out, dout, cout, self._grad(zc.scale).view(-1), alpha=3.0)
+        (self._dfr or ops).prod_colsum(out, dout, cout, self._grad(zc.scale).view(-1), alpha=3.0)
         if seg_in is not None:
             # weight / bias gradients land in place: the split-K reduce scales row co by exp(3 * scale[co])
             ops.wgrad(seg_in, dout, cout, cin, self._grad(zc.conv.weight), bias_grad=self._grad(zc.conv.bias), row_scale=rs)
@@ -270,7 +312,7 @@ class GlowEngine:
         v5, st5 = self._zero_conv_bwd(zc, Seg(r['h2'], scale=r['a5'], shift=r['b5'], relu=True, code=codes[1]), hz, dhz, c, hid,
                                       True, ocode=codes[1], gate_x=r['h2'], gscale=r['a5'], gshift=r['b5'],
                                       gmean=r['nl5'], grstd=ones, stats_mode=2)
-        ops.actnorm_bwd(st5, an5.scale.detach(), 0.0, False, self._grad(an5.loc), self._grad(an5.scale))
+        (self._dfr or ops).actnorm_bwd(st5, an5.scale.detach(), 0.0, False, self._grad(an5.loc), self._grad(an5.scale))
         s5 = an5.scale.detach().reshape(-1)
         # 1x1 conv <- MC <- ReLU <- ActNorm(1)
         ops.wgrad(Seg(r['h1'], ksize=1, scale=r['a1'], shift=r['b1'], relu=True, code=codes[0]), v5, hid, hid,
@@ -278,7 +320,7 @@ class GlowEngine:
         w1t = self._img((id(conv1), 'b'), lambda: ops.prep_weight_ex(conv1.weight.detach(), dt, transpose=True, row_scale=s5))
         v1, st1 = ops.conv_fused([Seg(v5, ksize=1)], w1t, hid, ocode=codes[0], gate_x=r['h1'],
                                  gscale=r['a1'], gshift=r['b1'], gmean=r['nl1'], grstd=ones, stats_mode=2)
-        ops.actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
+        (self._dfr or ops).actnorm_bwd(st1, an1.scale.detach(), 0.0, False, self._grad(an1.loc), self._grad(an1.scale))
         s1 = an1.scale.detach().reshape(-1)
         # 3x3 conv on the first c/2 channels of v; its input gradient joins the direct coupling gradient dv
         ops.wgrad(Seg(out), v1, hid, c // 2, self._grad(conv0.weight), bias_grad=self._grad(conv0.bias), row_scale=s1)
@@ -290,7 +332,10 @@ class GlowEngine:
         ops.wgrad(Seg(x, ksize=1, scale=r['a'], shift=r['b']), dvt, c, cp, gW)
         gl, gu, gs = self._grad(ic.w_l), self._grad(ic.w_u), self._grad(ic.w_s)
         # the LU-parameter gradients need the reduced dW: after the pass's batched split-K reduction
-        self._post.append(lambda: ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef, gl, gu, gs))
+        if self._dfr is not None:
+            self._dfr.invconv_bwd(ic, gW, ld_coef, gl, gu, gs)
+        else:
+            self._post.append(lambda: ops.invconv_bwd(ic.w_p, ic.w_l.data, ic.w_u.data, ic.w_s.data, ic.s_sign, gW, ld_coef, gl, gu, gs))
         s = an.scale.detach().reshape(-1)
         wmat = r['wmat']
         wt = self._img((id(ic), 'b'), lambda: ops.prep_weight_ex(wmat, dt, 1, transpose=True, col_scale=s, k_img=cp))   # [ci, co] = W[co, ci] * s[ci]
@@ -298,7 +343,7 @@ class GlowEngine:
                                 gscale=self._full(0.0, c, dev), gshift=self._full(1.0, c, dev),
                                 gmean=r['nl'], grstd=self._full(1.0, c, dev),
                                 stats_mode=2)
-        ops.actnorm_bwd(st, an.scale.detach(), ld_coef, True, self._grad(an.loc), self._grad(an.scale))
+        (self._dfr or ops).actnorm_bwd(st, an.scale.detach(), ld_coef, True, self._grad(an.loc), self._grad(an.scale))
         return dx
 
     def backward(self, tape, n: int, n_pixel: float):
@@ -307,11 +352,16 @@ class GlowEngine:
         g0 = -1.0 / (n * math.log(2.) * n_pixel)
         self._post = []
         self._prepare(True)
-        with ops.deferred_reduces():               # every split-K reduction of the pass: a handful of batched launches
-            dkeep = self._backward_body(tape, g0)
-        for f in self._post:
-            f()
-        self._post = []
+        self._dfr = ops.GlowDeferred()             # parameter-gradient reductions nothing in the pass reads: batched at its end
+        try:
+            with ops.deferred_reduces():           # every split-K reduction of the pass: a handful of batched launches
+                dkeep = self._backward_body(tape, g0)
+            for f in self._post:
+                f()
+            self._dfr.run()
+        finally:
+            self._dfr = None
+            self._post = []
         return dkeep
 
     def _backward_body(self, tape, g0: float):
@@ -337,6 +387,7 @@ class GlowEngine:
     def reverse(self, zs: List[Tensor], indicator: Tensor, reconstruct: bool, label=None) -> Tensor:
         m, dt = self.m, self.dtype
         self._I = None                              # images are built per use on this path
+        self._pass = None
         L = len(m.blocks)
         x = None
         c_in = [m.data_shape[0] * 2 ** i for i in range(L)]               # channels entering block i

@@ -899,10 +899,24 @@ class CodeBatch:
             self._key = key
             self._n_cached = None
 
-    def run(self, indicator: Tensor, scale: Optional[Tensor] = None, n_half: int = 0):
-        """-> list of [N, C] code tensors (views of one buffer), in module order."""
+    def run_labels(self, label: Tensor):
+        """The same for one-hot indicators given as int64 labels: code_i = codebook_i[label] (a row gather per module, all in
+        one launch: mcgen_mc_gather_batch)."""
         self._ensure()
-        n = indicator.shape[0]
+        n = label.shape[0]
+        self._tables_for(n, label.device)
+        if label.dtype != torch.int64 or any(d.C % 4 for d in self._arr):
+            raise _lib.McgenError('run_labels: int64 labels and channel counts that are multiples of 4')
+        buf = torch.empty(self._total, dtype=torch.float32, device=label.device)
+        check(_lib.load().mcgen_mc_gather_batch(_p(label.contiguous()), _p(self._table), len(self.mcs), _f32(buf), n, _stream()),
+              'mc_gather_batch')
+        out, off = [], 0
+        for d in self._arr:
+            out.append(buf[off:off + n * d.C].view(n, d.C))
+            off += n * d.C
+        return out
+
+    def _tables_for(self, n: int, device):
         if self._n_cached != n:
             # one descriptor table per batch size (the paired discriminator pass alternates 2N and N)
             if not isinstance(getattr(self, '_tables', None), dict) or self._tables.get('key') != self._key:
@@ -912,9 +926,15 @@ class CodeBatch:
                 for d in self._arr:
                     d.out_off = off
                     off += n * d.C
-                self._tables[n] = (off, _struct_table(self._arr, indicator.device))
+                self._tables[n] = (off, _struct_table(self._arr, device))
             self._total, self._table = self._tables[n]
             self._n_cached = n
+
+    def run(self, indicator: Tensor, scale: Optional[Tensor] = None, n_half: int = 0):
+        """-> list of [N, C] code tensors (views of one buffer), in module order."""
+        self._ensure()
+        n = indicator.shape[0]
+        self._tables_for(n, indicator.device)
         if indicator.shape[1] != self._arr[0].M:
             raise _lib.McgenError(f'indicator has {indicator.shape[1]} modes, codebook has {self._arr[0].M}')
         buf = torch.empty(self._total, dtype=torch.float32, device=indicator.device)
@@ -983,6 +1003,91 @@ def invconv_weight(w_p, w_l, w_u, w_s, s_sign, inverse: bool = False):
     check(_lib.load().mcgen_invconv_weight(_f32(w_p), _f32(w_l), _f32(w_u), _f32(w_s), _f32(s_sign), c, _f32(w), _f32(winv),
                                            _stream()), 'invconv_weight')
     return w, winv
+
+
+# ---- batched MCGlow per-module ops (one launch per kind for all modules of a pass) --------------------------------------
+def actnorm_affine_batch(ans, cps):
+    """[(a, b, negloc)] for ActNorm modules `ans` (loc / scale parameters) padded to `cps[i]` channels: ONE buffer, one launch
+    per MCGEN_GLOW_BATCH_MAX modules (mcgen_actnorm_affine_batch)."""
+    dev = ans[0].loc.device
+    buf = torch.empty(3 * sum(cps), dtype=torch.float32, device=dev)
+    arr = (_lib.AnAffine * len(ans))()
+    out, off = [], 0
+    for d, an, cp in zip(arr, ans, cps):
+        a, b, nl = buf[off:off + cp], buf[off + cp:off + 2 * cp], buf[off + 2 * cp:off + 3 * cp]
+        off += 3 * cp
+        d.loc, d.scale, d.a, d.b, d.negloc, d.C, d.Cp = _f32(an.loc.data), _f32(an.scale.data), _f32(a), _f32(b), _f32(nl), an.loc.numel(), cp
+        out.append((a, b, nl))
+    check(_lib.load().mcgen_actnorm_affine_batch(arr, len(ans), _stream()), 'actnorm_affine_batch')
+    return out
+
+
+def glow_param_logdet_batch(items, logdet: Tensor):
+    """logdet[n] += sum over `items` = [(actnorm scale, w_s, H * W)] of HW * (sum log|scale| + sum w_s), one launch."""
+    arr = (_lib.Pld * len(items))()
+    for d, (scale, w_s, hw) in zip(arr, items):
+        d.scale, d.w_s, d.C, d.Cw, d.hw = _f32(scale), _f32(w_s), scale.numel(), w_s.numel(), float(hw)
+    check(_lib.load().mcgen_glow_param_logdet_batch(arr, len(items), _f32(logdet), logdet.numel(), _stream()), 'glow_param_logdet_batch')
+
+
+def invconv_weight_batch(ics):
+    """[W] of InvConv2dLU modules `ics` (mcglow.py:105-111), one launch per MCGEN_GLOW_BATCH_MAX modules."""
+    arr = (_lib.Icw * len(ics))()
+    out = []
+    for d, ic in zip(arr, ics):
+        c = ic.w_s.numel()
+        w = torch.empty((c, c), dtype=torch.float32, device=ic.w_s.device)
+        d.w_p, d.w_l, d.w_u, d.w_s, d.s_sign, d.weight, d.weight_inv, d.C = (_f32(ic.w_p), _f32(ic.w_l.data), _f32(ic.w_u.data),
+                                                                            _f32(ic.w_s.data), _f32(ic.s_sign), _f32(w), None, c)
+        out.append(w)
+    check(_lib.load().mcgen_invconv_weight_batch(arr, len(ics), _stream()), 'invconv_weight_batch')
+    return out
+
+
+class GlowDeferred:
+    """Parameter-gradient reductions of an MCGlow backward pass that nothing later in the pass reads (ActNorm loc / scale from
+    the dgrad epilogues' partial sums, ZeroConv2d scale, the LU parameters): queued while the pass runs, launched batched at
+    its end -- they were ~250 launches of 3-6 us."""
+
+    def __init__(self):
+        self.an, self.pcs, self.icb, self.keep = [], [], [], []
+
+    def actnorm_bwd(self, partials, scale, ld_coef, input_side, dloc, dscale, accumulate=False):
+        self.an.append((partials, scale, float(ld_coef), int(input_side), dloc, dscale, int(accumulate)))
+
+    def prod_colsum(self, a, b, c, out, alpha=1.0, accumulate=False):
+        self.pcs.append((a, b, c, out, float(alpha), int(accumulate)))
+
+    def invconv_bwd(self, ic, dW, ld_coef, dw_l, dw_u, dw_s, accumulate=False):
+        self.icb.append((ic, dW, float(ld_coef), dw_l, dw_u, dw_s, int(accumulate)))
+
+    def run(self):
+        lib = _lib.load()
+        if self.an:
+            arr = (_lib.AnBwd * len(self.an))()
+            for d, (p, sc, ld, side, dl, ds, acc) in zip(arr, self.an):
+                tiles, _, pitch = p.shape
+                d.partials, d.scale, d.dloc, d.dscale = _f32(p), _f32(sc), _f32(dl), _f32(ds)
+                d.tiles, d.pitch, d.C, d.input_side, d.accumulate, d.ld_coef = tiles, pitch, sc.numel(), side, acc, ld
+            check(lib.mcgen_actnorm_bwd_batch(arr, len(self.an), _stream()), 'actnorm_bwd_batch')
+        if self.pcs:
+            dt = self.pcs[0][0].dtype
+            arr = (_lib.Pcs * len(self.pcs))()
+            cmax = max(j[2] for j in self.pcs)
+            for d, (a, b, c, out, alpha, acc) in zip(arr, self.pcs):
+                assert a.dtype == dt and b.dtype == dt
+                d.a, d.b, d.out, d.pixels = _p(a), _p(b), _f32(out), a.numel() // a.shape[-1]
+                d.pitch_a, d.pitch_b, d.C, d.accumulate, d.alpha = a.shape[-1], b.shape[-1], c, acc, alpha
+            ws = torch.empty(len(self.pcs) * 256 * cmax, dtype=torch.float32, device=self.pcs[0][0].device)
+            check(lib.mcgen_prod_colsum_batch(arr, len(self.pcs), _dt(dt), _f32(ws), _stream()), 'prod_colsum_batch')
+        if self.icb:
+            arr = (_lib.Icb * len(self.icb))()
+            for d, (ic, dW, ld, dl, du, dsg, acc) in zip(arr, self.icb):
+                d.w_p, d.w_l, d.w_u, d.w_s, d.s_sign = _f32(ic.w_p), _f32(ic.w_l.data), _f32(ic.w_u.data), _f32(ic.w_s.data), _f32(ic.s_sign)
+                d.dW, d.dw_l, d.dw_u, d.dw_s = _f32(dW), _f32(dl), _f32(du), _f32(dsg)
+                d.C, d.ldw, d.accumulate, d.ld_coef = ic.w_s.numel(), dW.shape[-1], acc, ld
+            check(lib.mcgen_invconv_bwd_batch(arr, len(self.icb), _stream()), 'invconv_bwd_batch')
+        self.an, self.pcs, self.icb = [], [], []
 
 
 def prep_weight_rows(w: Tensor, dtype: torch.dtype, row_scale: Tensor) -> Tensor:
