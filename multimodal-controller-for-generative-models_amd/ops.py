@@ -1354,7 +1354,11 @@ def prep_weight_ex_many(jobs, dtype: torch.dtype):
         ks = kw.get('ksize') or kh
         rows = kw.get('rows_img') or (cin if transpose else cout)
         kk = kw.get('k_img') or (cout if transpose else cin)
-        out = torch.empty(weight_image_elems(rows, kk, ks, False), dtype=dtype, device=w.device)
+        out = kw.get('out')                                 # (a caller-owned slice: K-concatenated images without a torch.cat)
+        if out is None:
+            out = torch.empty(weight_image_elems(rows, kk, ks, False), dtype=dtype, device=w.device)
+        elif out.numel() != weight_image_elems(rows, kk, ks, False) or out.dtype != dtype or not out.is_contiguous():
+            raise _lib.McgenError('prep_weight_ex_many: `out` must be a contiguous image-sized tensor of the compute dtype')
         a.w, a.s_co, a.s_ci = w.data_ptr(), st[0], st[1]
         a.s_kh, a.s_kw = (st[2], st[3]) if w.dim() == 4 else (0, 0)
         a.Cout, a.Cin, a.KH, a.KW = cout, cin, kh, kwid

@@ -78,16 +78,33 @@ class PixelCNNEngine:
         def add(key, w, **kw):
             keys.append(key); jobs.append((w.detach(), dict(kw, transpose=backward)))
 
+        cats = {}
         for i, L in enumerate(m.layers):
             if L.kernel == 3:
                 add((i, 'v'), L.vert_stack.weight, ksize=3)
+                if not backward:
+                    # vert_to_horiz ++ horiz_stack feed ONE K-concatenated launch: both images into one buffer
+                    c2, c = L.vert_to_horiz.weight.shape[0], L.horiz_stack.weight.shape[1]
+                    n1, n2 = ops.weight_image_elems(c2, c2, 1, False), ops.weight_image_elems(c2, c, 3, False)
+                    buf = torch.empty(n1 + n2, dtype=dt, device=L.vert_to_horiz.weight.device)
+                    cats[(i, 'v2h+h')] = buf
+                    add((i, 'v2h'), L.vert_to_horiz.weight, out=buf[:n1])
+                    add((i, 'h'), L.horiz_stack.weight, ksize=3, kh0=1, out=buf[n1:])
+                    add((i, 'r'), L.horiz_resid[0].module.weight)
+                    continue
                 add((i, 'h'), L.horiz_stack.weight, ksize=3, kh0=1)
             add((i, 'v2h'), L.vert_to_horiz.weight)
             add((i, 'r'), L.horiz_resid[0].module.weight)
         oc = m.output_conv
         add(('head', 0), oc[0].module.weight)
         add(('head', 4), oc[4].module.weight, **({'k_img': pad8(oc[4].module.out_channels)} if backward else {}))
-        return dict(zip(keys, ops.prep_weight_ex_many(jobs, dt)))
+        images = dict(zip(keys, ops.prep_weight_ex_many(jobs, dt)))
+        images.update(cats)
+        return images
+
+    def _code(self, mc, label):
+        cached = getattr(self, '_codes', None)
+        return cached[id(mc)] if cached is not None and id(mc) in cached else mc.code_of_labels(label)
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def _layer_forward(self, L, x_v: Tensor, x_h: Tensor, label: Tensor, train: bool, tape, I, li):
@@ -109,10 +126,12 @@ class PixelCNNEngine:
             in_h = Seg(ops.im2col(x_h, 1, k2 + 1, 0, k2), ksize=1)
             img_v, img_h = ops.prep_weight(wv, dt), ops.prep_weight(wh, dt)
         h_vert, st_v = ops.conv_fused([in_v], img_v, 2 * c, bias=L.vert_stack.bias.detach(), stats_mode=sm)
-        wimg = torch.cat([I[(li, 'v2h')], img_h])
+        wimg = I.get((li, 'v2h+h'))
+        if wimg is None:
+            wimg = torch.cat([I[(li, 'v2h')], img_h])
         s, st_s = ops.conv_fused([Seg(h_vert, ksize=1), in_h], wimg, 2 * c,
-                                 bias=L.vert_to_horiz.bias.detach() + L.horiz_stack.bias.detach(), stats_mode=sm)
-        code_v, code_h = L.gate_v.mc.code_of_labels(label), L.gate_h.mc.code_of_labels(label)
+                                 bias=L.vert_to_horiz.bias.detach(), bias2=L.horiz_stack.bias.detach(), stats_mode=sm)
+        code_v, code_h = self._code(L.gate_v.mc, label), self._code(L.gate_h.mc, label)
         bn_v = self._bn(L.gate_v.bn, st_v, count, train)
         bn_h = self._bn(L.gate_h.bn, st_s, count, train)
         out_v = ops.gated_fwd(h_vert, bn_v[0], bn_v[1], code_v)
@@ -121,7 +140,7 @@ class PixelCNNEngine:
         r, st_r = ops.conv_fused([Seg(out_h, ksize=1)], I[(li, 'r')], c,
                                  bias=conv_r.bias.detach(), stats_mode=sm)
         bn_r = self._bn(bn_rm, st_r, count, train)
-        code_r = mc_r.code_of_labels(label)
+        code_r = self._code(mc_r, label)
         x_h_new = ops.affine_code_res(r, bn_r[0], bn_r[1], code_r, x_h if L.residual else None)
         if tape is not None:
             tape.append(dict(in_v=in_v, in_h=in_h, h_vert=h_vert, s=s, out_h=out_h, r=r, bn_v=bn_v, bn_h=bn_h, bn_r=bn_r,
@@ -136,6 +155,11 @@ class PixelCNNEngine:
         x_v = x_h = x
         layers = [] if tape is not None else None
         I = self._images(False)
+        # every MultimodalController's code rows of this batch in one launch (a row gather per module: one_hot(label) @ codebook)
+        mcs = [mc for L in m.layers for mc in (L.gate_v.mc, L.gate_h.mc, L.horiz_resid[2])] + [m.output_conv[3]]
+        if getattr(self, '_code_batch', None) is None or [id(x_) for x_ in self._code_batch.mcs] != [id(x_) for x_ in mcs]:
+            self._code_batch = ops.CodeBatch(mcs)
+        self._codes = {id(mc): cd for mc, cd in zip(mcs, self._code_batch.run_labels(label))}
         for li, L in enumerate(m.layers):
             x_v, x_h = self._layer_forward(L, x_v, x_h, label, train, layers, I, li)
         oc = m.output_conv
@@ -144,9 +168,10 @@ class PixelCNNEngine:
         h0, st0 = ops.conv_fused([Seg(x_h, ksize=1)], I[('head', 0)], conv0.out_channels,
                                  bias=conv0.bias.detach(), stats_mode=1 if train else 0)
         bn = self._bn(bn0, st0, count, train)
-        code0 = mc0.code_of_labels(label)
+        code0 = self._code(mc0, label)
         logits, _ = ops.conv_fused([Seg(h0, ksize=1, scale=bn[0], shift=bn[1], relu=True, code=code0)],
                                    I[('head', 4)], conv4.out_channels, bias=conv4.bias.detach())
+        self._codes = None
         rows, dlogits = ops.cross_entropy(logits, codes.reshape(-1), conv4.out_channels, want_grad)
         if tape is not None:
             tape.update(layers=layers, codes=codes, x_h=x_h, h0=h0, bn0=bn, code0=code0, dlogits=dlogits)
