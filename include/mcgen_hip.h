@@ -261,6 +261,16 @@ int mcgen_mc_gather_batch(const int64_t* label, const mcgen_code_t* descs_dev, i
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);
 
+/* mcgen_bn_finalize_groups with the statistics groups in parallel (one workgroup row per group).  The running statistics take
+ * the groups' updates in order, so this form leaves them alone: it also returns every group's unbiased variance (`unb`,
+ * [groups, C]) and the caller applies the updates of ALL layers of the forward pass with one mcgen_bn_running_batch launch
+ * (running = (1 - m) running + m stat, group after group: the arithmetic of the serial form). */
+int mcgen_bn_finalize_par(const float* partials, int tiles, int pitch, int fold, int C, double count, int groups,
+                          const float* gamma, const float* beta, float eps,
+                          float* scale, float* shift, float* mean, float* rstd, float* unb, void* stream);
+#define MCGEN_BN_RUN_MAX 24
+typedef struct { float* running_mean; float* running_var; const float* mean; const float* unb; int32_t groups, C; float momentum; int32_t _pad; } mcgen_bn_run_t;
+int mcgen_bn_running_batch(const mcgen_bn_run_t* jobs, int n, void* stream);
 /* BatchNorm2d training statistics from per-tile partial sums (mcgan.py:15,20,55):
  * mean/var over `count` elements per channel, scale = gamma*rstd, shift = beta-mean*scale,
  * running stats updated with momentum (unbiased variance), all in one launch.

@@ -97,6 +97,11 @@ class Pcs(C.Structure):                                    # mcgen_pcs_t
                 ('alpha', C.c_float), ('_pad', C.c_int32)]
 
 
+class BnRun(C.Structure):                                  # mcgen_bn_run_t
+    _fields_ = [('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('mean', C.c_void_p), ('unb', C.c_void_p),
+                ('groups', C.c_int32), ('C', C.c_int32), ('momentum', C.c_float), ('_pad', C.c_int32)]
+
+
 class SnLayer(C.Structure):
     _fields_ = [('w_off', C.c_int64), ('u_off', C.c_int64), ('v_off', C.c_int64),
                 ('rows', C.c_int32), ('cols', C.c_int32)]
@@ -170,6 +175,8 @@ SYMBOLS = {
     'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'mcgen_bn_finalize_groups': (_i, [_vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_bn_finalize_par': (_i, [_vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_bn_running_batch': (_i, [_vp, _i, _vp]),
     'mcgen_bn_eval_affine': (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'mcgen_bn_bwd_finalize': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'mcgen_bn_bwd_apply': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _vp, _vp, _vp, _vp]),

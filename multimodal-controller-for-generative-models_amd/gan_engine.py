@@ -118,7 +118,10 @@ class Nhwc:
 _SN_SNAP = _flag('MCGEN_SN_SNAP', '1') != '0'    # the power iteration's kernels write the forward's u/v copy (0: clone afterwards)
 # FirstDisResBlock: the 1x1 shortcut as a second K segment of conv2's launch (0: its own launch + a residual read)
 _D0_FUSE = _flag('MCGEN_D0_FUSE', '1') != '0'
+# grouped passes: BatchNorm statistics groups finalized in parallel, running statistics of the whole pass in one launch
+_BN_PAR = _flag('MCGEN_BN_PAR', '1') != '0'
 _pending_counters: Dict[int, List[Tensor]] = {}
+_pending_running: List = []                     # (running_mean, running_var, mean [groups, C], unb [groups, C], momentum)
 
 
 def _flush_counters():
@@ -126,6 +129,9 @@ def _flush_counters():
         if ts:
             torch._foreach_add_(ts, k)
     _pending_counters.clear()
+    if _pending_running:
+        ops.bn_running_batch(_pending_running)
+        _pending_running.clear()
 
 
 def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: bool, fold: int = 1, groups: int = 1) -> _BN:
@@ -135,8 +141,13 @@ def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: 
     s.count = count
     if train:
         mom = 0.1 if bn.momentum is None else bn.momentum
-        s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
-                                                           bn.running_var, mom, bn.eps, fold=fold, groups=groups)
+        if groups > 1 and _BN_PAR:
+            # the groups in parallel; the running statistics of all layers of the pass in one launch at its end (_flush_counters)
+            s.scale, s.shift, s.mean, s.rstd, unb = ops.bn_finalize_par(stats, count, bn.weight, bn.bias, bn.eps, fold=fold, groups=groups)
+            _pending_running.append((bn.running_mean, bn.running_var, s.mean, unb, mom))
+        else:
+            s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
+                                                               bn.running_var, mom, bn.eps, fold=fold, groups=groups)
         _bump(bn.running_mean); _bump(bn.running_var)
         _pending_counters.setdefault(groups, []).append(bn.num_batches_tracked)   # bumped together at the end of the forward
     else:

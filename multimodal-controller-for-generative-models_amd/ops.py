@@ -661,6 +661,28 @@ def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
     return out[0], out[1], out[2], out[3]
 
 
+def bn_finalize_par(partials: Tensor, count: int, gamma: Tensor, beta: Tensor, eps: float = 1e-5, fold: int = 1, groups: int = 1):
+    """bn_finalize with the statistics groups in parallel and the running statistics left alone
+    -> (scale, shift, mean, rstd, unbiased var), each [groups, C]; pair with bn_running_batch at the end of the pass."""
+    tiles, _, pitch = partials.shape
+    c = gamma.numel()
+    out = torch.empty((5, groups, c), dtype=torch.float32, device=partials.device)
+    check(_lib.load().mcgen_bn_finalize_par(_f32(partials), tiles, pitch, fold, c, float(count), groups, _f32(gamma), _f32(beta), eps,
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
+                                            _stream()), 'bn_finalize_par')
+    return out[0], out[1], out[2], out[3], out[4]
+
+
+def bn_running_batch(items):
+    """items = [(running_mean, running_var, mean [groups, C], unb [groups, C], momentum)]: every layer's running statistics
+    take its groups' updates in order, one launch (mcgen_bn_running_batch)."""
+    arr = (_lib.BnRun * len(items))()
+    for d, (rm, rv, mean, unb, mom) in zip(arr, items):
+        d.running_mean, d.running_var, d.mean, d.unb = _f32(rm), _f32(rv), _f32(mean), _f32(unb)
+        d.groups, d.C, d.momentum = mean.shape[0], rm.numel(), float(mom)
+    check(_lib.load().mcgen_bn_running_batch(arr, len(items), _stream()), 'bn_running_batch')
+
+
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float = 1e-5):
     c = gamma.numel()
     out = torch.empty((2, c), dtype=torch.float32, device=gamma.device)
