@@ -2096,32 +2096,60 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
             }
         };
         pp_barrier();                                          // every wave is past its last ring / window read
-        if (nrest > 0) tail_dma(0, 0);
+        // One exposed round trip per GROUP of chunks instead of one per chunk: the windows of up to TG consecutive chunks are
+        // requested together and staged side by side (over the two window buffers and ring slots 0 / 1 -- the main loop is
+        // done with them), the weight tiles cycle through ring slots 2 .. 4 two chunks ahead with counted waits, one barrier
+        // per chunk.  (The chunk-by-chunk form -- stage, wait, DMA, wait, 32 MFMAs -- spent 12 us per tile on the 160-channel
+        // shortcut of the grouped pass: 121 of that launch's 575 us.)
+        constexpr int SUBW = BM * APITCH;                      // one chunk's window of a 1x1 segment (no halo)
+        constexpr int A2 = 2 * (((PP * APITCH + 1023) / 1024) * 1024);
+        constexpr int TGMAX = (A2 + 2 * BB) / SUBW;
+#ifndef MCGEN_PP_TG
+#define MCGEN_PP_TG 4
+#endif
+        constexpr int TG = TGMAX < MCGEN_PP_TG ? TGMAX : MCGEN_PP_TG;
+        constexpr int NI1 = (BM * 4 + NT - 1) / NT;           // window items per thread of a 1x1 chunk (no halo)
+        static_assert(TG >= 1 && R >= 5, "tail groups: windows over the window buffers + two ring slots, weights in slots 2 .. 4");
+        auto tslot = [](int t) { return 2 + t % 3; };
+        auto tail_dma_c = [&](int t) { tail_dma(t < nrest ? t : nrest - 1, tslot(t)); };      // (past the end: the last tile again -- constant counts)
+        if (nrest > 0) { tail_dma_c(0); tail_dma_c(1); }
         for (int s = 1; s < p.nseg; ++s) {
             const mcgen_seg_t sg = seg_for_tile(p.seg[s], g);
-            PatchStager<T, NT, C::NI, APITCH> stager;
+            PatchStager<T, NT, NI1, APITCH> stager;
             stager.setup(sg, g, N, H, W, tid);
             const int b_lane = (wm * (BM / WM) + l15) * APITCH + lg * 16;
             const int nch = GK ? nrest : (sg.C + MCGEN_CK - 1) / MCGEN_CK;
 #pragma unroll 1
-            for (int q = 0; q < nch; ++q) {
-                __builtin_amdgcn_s_barrier();                  // everyone is past the previous chunk's window reads
-                stager.stage(sg, q * MCGEN_CK, ldsA0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (tg + 1 < nrest) tail_dma(tg + 1, (tg + 1) & 1);
-                const char* ldsB = ldsB0 + (tg & 1) * BB;
-                typename M::frag xf[FM], yf[FN];
+            for (int q0 = 0; q0 < nch; q0 += TG) {
+                const int ng = (nch - q0) < TG ? (nch - q0) : TG;
+                if (q0 > 0) __builtin_amdgcn_s_barrier();      // everyone is past the previous group's window reads
+                {
+                    typename PatchStager<T, NT, NI1, APITCH>::raw_t raw[TG];
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const typename M::frag*>(ldsA0 + b_lane + fm * 16 * APITCH);
+                    for (int i = 0; i < TG; ++i) if (i < ng) stager.load(sg, (q0 + i) * MCGEN_CK, raw[i]);
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn) yf[fn] = wfrag(ldsB, fn);
+                    for (int i = 0; i < TG; ++i) if (i < ng) stager.write(sg, (q0 + i) * MCGEN_CK, raw[i], ldsA0 + i * SUBW, g.n0 < N ? g.n0 : -1);
+                }
+#pragma unroll 1
+                for (int i = 0; i < ng; ++i) {
+                    // tile tg has landed (this wave's pieces; tile tg + 1 may still be in flight), the windows are written ...
+                    if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    pp_barrier();                              // ... everyone's; slot(tg + 2) = slot(tg - 1): its readers are past this barrier
+                    tail_dma_c(tg + 2);
+                    const char* ldsB = ldsB0 + tslot(tg) * BB;
+                    const char* ldsW = ldsA0 + i * SUBW + b_lane;
+                    typename M::frag xf[FM], yf[FN];
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
+                    for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const typename M::frag*>(ldsW + fm * 16 * APITCH);
 #pragma unroll
-                    for (int fm = 0; fm < FM; ++fm) M::run(yf[fn], xf[fm], acc[fn][fm]);
-                ++tg;
+                    for (int fn = 0; fn < FN; ++fn) yf[fn] = wfrag(ldsB, fn);
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                        for (int fm = 0; fm < FM; ++fm) M::run(yf[fn], xf[fm], acc[fn][fm]);
+                    ++tg;
+                }
             }
         }
     }
