@@ -31,16 +31,19 @@ namespace {
 
 constexpr int IM_NT = 512, IM_COT = 64;
 constexpr int IM_EP = IM_COT + 4;                      // floats per pixel row of a K-part exchange buffer
+constexpr int IM_UP1 = 5;                              // segment kind: 1x1 over the 4x4 source of a x2 upsample
 
 template <int C0, int KS0, int C1, int KS1, int IMGS>
 struct ImCfg {
     static constexpr int KH = 4;                        // K parts: wave = (32 of the 64 channels) x (K part), every image
-    static constexpr int T0 = KS0 * KS0, T1 = KS1 * KS1;
+    // (KS1 == IM_UP1: a 1x1 segment whose input arrives through the nearest x2 upsample -- its window holds the 4 x 4 SOURCE
+    // pixels, 8 KB instead of 32: two images' windows of the generator's conv_b ++ shortcut launch fit the LDS)
+    static constexpr int T0 = KS0 * KS0, T1 = KS1 == IM_UP1 ? 1 : KS1 * KS1;
     static constexpr int KT0 = (C0 / 32) * T0, KT1 = (C1 / 32) * T1, KT = KT0 + KT1;
     static_assert(KT % KH == 0, "K steps split evenly over the K parts");
     static constexpr int KPW = KT / KH;                 // K steps per wave
     static constexpr int PF = KPW < 9 ? KPW : 9;        // weight fragments in flight (K steps)
-    static constexpr int PP0 = KS0 == 3 ? 100 : 64, PP1 = KS1 == 3 ? 100 : 64;
+    static constexpr int PP0 = KS0 == 3 ? 100 : 64, PP1 = KS1 == 3 ? 100 : (KS1 == IM_UP1 ? 16 : 64);
     static constexpr int WIN0 = PP0 * C0 * 2, WIN1 = PP1 * C1 * 2;     // bytes per image
     static constexpr int WIN = IMGS * (WIN0 + WIN1);
     static constexpr int EBUF = IMGS * 64 * IM_EP * 4;  // one K part's accumulators
@@ -57,17 +60,19 @@ static __device__ __forceinline__ int im_off(int wr, int wc, int unit) {
 // one segment of one image: global -> prologue -> swizzled window
 template <int C, int KS>
 struct ImSeg {
-    static constexpr int UPP = C / 8, NI = 64 * UPP / IM_NT, PSTEP = IM_NT / UPP;
-    static constexpr int PC = KS == 3 ? 10 : 8, HALO = KS == 3 ? 1 : 0, ROWB = C * 2;
+    static constexpr int NPX = KS == IM_UP1 ? 16 : 64;   // pixels staged per image
+    static constexpr int UPP = C / 8, NI = (NPX * UPP + IM_NT - 1) / IM_NT, PSTEP = IM_NT / UPP;
+    static constexpr int PC = KS == 3 ? 10 : (KS == IM_UP1 ? 4 : 8), HALO = KS == 3 ? 1 : 0, ROWB = C * 2;
+    static constexpr int LGP = KS == IM_UP1 ? 2 : 3;     // log2 of the staged map's side
     static __device__ __forceinline__ void load(const mcgen_seg_t& sg, int n, int tid, u32x4 (&raw)[NI]) {
         const int u = tid & (UPP - 1), px0 = tid / UPP;
         // ups: x is the 4x4 map under a nearest x2 upsample (mcgan.py:17,27) -- pixel (r, c) reads (r >> 1, c >> 1)
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(sg.x) + ((size_t)n * (sg.ups ? 16 : 64)) * C + u * 8;
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(sg.x) + ((size_t)n * ((sg.ups || KS == IM_UP1) ? 16 : 64)) * C + u * 8;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int px = px0 + PSTEP * k;
-            const int src = sg.ups ? ((px >> 4) << 2) + ((px & 7) >> 1) : px;
-            raw[k] = *reinterpret_cast<const u32x4*>(xs + (size_t)src * C);
+            const int src = (sg.ups && KS != IM_UP1) ? ((px >> 4) << 2) + ((px & 7) >> 1) : px;
+            raw[k] = *reinterpret_cast<const u32x4*>(xs + (size_t)(src < NPX || KS != IM_UP1 ? src : 0) * C);
         }
     }
     static __device__ __forceinline__ void write(const mcgen_seg_t& sg, int tid, const u32x4 (&raw)[NI], const float (&sc)[8],
@@ -84,7 +89,8 @@ struct ImSeg {
                 const float v1 = fmaxf(fmaf(__uint_as_float(raw[k][e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), relu_lo) * cd[2 * e + 1];
                 o.h[2 * e] = (bf16_t)v0; o.h[2 * e + 1] = (bf16_t)v1;
             }
-            *reinterpret_cast<u32x4*>(win + im_off<PC, ROWB>((px >> 3) + HALO, (px & 7) + HALO, u)) = o.w;
+            if (KS != IM_UP1 || px < NPX)
+                *reinterpret_cast<u32x4*>(win + im_off<PC, ROWB>((px >> LGP) + HALO, (px & ((1 << LGP) - 1)) + HALO, u)) = o.w;
         }
         if (KS == 3) {                                  // the halo is the convolution's zero padding
             for (int i = tid; i < 36 * UPP; i += IM_NT) {
@@ -217,7 +223,9 @@ void conv_img_kernel(const mcgen_conv_t p) {
             const int q = k1 / G::T1, tap = k1 - q * G::T1;
             const int dh = KS1 == 3 ? tap / 3 : 0, dw = KS1 == 3 ? tap - 3 * dh : 0;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) xoff[f] = G::WIN0 + im_off<S1::PC, S1::ROWB>(2 * f + r0 + dh, c0 + dw, q * 4 + lg);
+            for (int f = 0; f < 4; ++f)
+                xoff[f] = G::WIN0 + (KS1 == IM_UP1 ? im_off<S1::PC, S1::ROWB>((2 * f + r0) >> 1, c0 >> 1, q * 4 + lg)      // (pixel (r, c) reads source (r >> 1, c >> 1))
+                                                   : im_off<S1::PC, S1::ROWB>(2 * f + r0 + dh, c0 + dw, q * 4 + lg));
         }
 #pragma unroll
         for (int k = 0; k < IMGS; ++k) {
@@ -325,11 +333,12 @@ static bool im_pick(const mcgen_conv_t* p, int dtype, ImPick* out) {
     }
     ImPick k{p->seg[0].C, p->seg[0].ksize, p->nseg == 2 ? p->seg[1].C : 0, p->nseg == 2 ? p->seg[1].ksize : 0, 1};
     const bool known = (k.c1 == 0 && k.k0 == 3) || (k.c1 == 0 && k.k0 == 1) || (k.c0 == 256 && k.k0 == 1 && k.c1 == 128 && k.k1 == 3) ||
-                       (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1);
+                       (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1 && !p->seg[0].ups && p->seg[1].ups);      // GenResBlock conv_b ++ shortcut
     if (!known) return false;
     // two images per workgroup while the launch still covers the chip (halves the weight bytes per pixel), the windows of
     // both fit in LDS, and the pair shares its BatchNorm group
-    const int win = (k.k0 == 3 ? 100 : 64) * k.c0 * 2 + (k.c1 ? (k.k1 == 3 ? 100 : 64) * k.c1 * 2 : 0);
+    const bool up1 = k.c1 && k.k1 == 1 && p->seg[1].ups;             // (only the form above: its shortcut window holds the 4x4 source)
+    const int win = (k.k0 == 3 ? 100 : 64) * k.c0 * 2 + (k.c1 ? (k.k1 == 3 ? 100 : (up1 ? 16 : 64)) * k.c1 * 2 : 0);
     bool pair_ok = p->N % 2 == 0 && (long)p->N * (p->Cout / IM_COT) >= 512 && 2 * win <= 160 * 1024;
     for (int s = 0; s < p->nseg; ++s) if (p->seg[s].group_n > 0 && p->seg[s].group_n % 2) pair_ok = false;
     if (pair_ok) k.imgs = 2;
@@ -368,6 +377,7 @@ int mcgen_conv_smap(const mcgen_conv_t* p, hipStream_t st) {
         return k.imgs == 2 ? launch_img<A, B, C, D, 2>(p, st) : launch_img<A, B, C, D, 1>(p, st);
     IM_CASE(128, 3, 0, 0) IM_CASE(256, 3, 0, 0) IM_CASE(128, 1, 0, 0) IM_CASE(256, 1, 0, 0) IM_CASE(256, 1, 128, 3)
 #undef IM_CASE
-    if (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1) return launch_img<256, 3, 256, 1, 1>(p, st);   // (two images' windows exceed the LDS)
+    if (k.c0 == 256 && k.k0 == 3 && k.c1 == 256 && k.k1 == 1)
+        return k.imgs == 2 ? launch_img<256, 3, 256, IM_UP1, 2>(p, st) : launch_img<256, 3, 256, IM_UP1, 1>(p, st);
     return mcgen_fail("conv_smap: no instantiation");
 }
