@@ -782,9 +782,17 @@ __global__ void sn_grad_dot2_kernel(const float* __restrict__ g0, const float* _
     const size_t n = (size_t)L.rows * L.cols;
     const size_t per = (n + SNF_CHUNKS - 1) / SNF_CHUNKS;
     const size_t i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
-    float d = 0.f;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) d = fmaf(G[i], W[i], d);
-    d = block_sum(d, red);
+    // four independent chains per thread: the loads of a chunk go out together (one dependent chain exposed a round trip per
+    // element: 11 us per launch for 8 MB)
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    size_t i = i0 + threadIdx.x;
+    const size_t st = blockDim.x;
+    for (; i + 3 * st < i1; i += 4 * st) {
+        d0 = fmaf(G[i], W[i], d0); d1 = fmaf(G[i + st], W[i + st], d1);
+        d2 = fmaf(G[i + 2 * st], W[i + 2 * st], d2); d3 = fmaf(G[i + 3 * st], W[i + 3 * st], d3);
+    }
+    for (; i < i1; i += st) d0 = fmaf(G[i], W[i], d0);
+    float d = block_sum((d0 + d1) + (d2 + d3), red);
     if (threadIdx.x == 0) partial[((size_t)blockIdx.z * nlayers + blockIdx.x) * SNF_CHUNKS + blockIdx.y] = d;
 }
 __global__ void sn_grad_apply2_kernel(const float* __restrict__ g0, const float* __restrict__ g1, float* gdst,
