@@ -318,10 +318,11 @@ int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, const mcgen_sn
  * row partials, the next round's u formed from the previous round's t on the fly; a paired discriminator update -- two
  * rounds, train_gan.py:144-150 -- costs five launches instead of eight).  sigma: [rounds, nlayers]; uv_snap (or NULL):
  * [rounds, uv_total] receives (u, v) after every round (the forward's copy, as mcgen_sn_power_iter_snap); workspace as
- * mcgen_sn_power_iter.  Layers up to 1024 rows. */
+ * mcgen_sn_power_iter.  ratio (or NULL; rounds >= 2): [nlayers] receives sigma[rounds - 2] / sigma[rounds - 1], the factor a
+ * paired pass scales its second half by.  Layers up to 1024 rows. */
 int mcgen_sn_power_iter_rounds(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                int rounds, float* sigma, float* workspace, int max_rows, int max_cols,
-                               float* uv_snap, int64_t uv_total, void* stream);
+                               float* uv_snap, int64_t uv_total, float* ratio, void* stream);
 /* `rounds` successive power iterations of every layer in ONE launch (one workgroup per layer; u, v, W v stay in LDS):
  * sigma[r][l] and -- when uv_snap != NULL -- the whole u/v buffer as it stands after round r (uv_snap[r][uv_total]:
  * torch's hook clones u, v for the backward, torch/nn/utils/spectral_norm.py) are written per round; uv_base holds the

@@ -183,7 +183,7 @@ SYMBOLS = {
     'mcgen_colsum': (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp]),
     'mcgen_sn_power_iter': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     'mcgen_sn_power_iter_snap': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
-    'mcgen_sn_power_iter_rounds': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i64, _vp]),
+    'mcgen_sn_power_iter_rounds': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp]),
     'mcgen_sn_power_iter_fused': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i, _i, _vp]),
     'mcgen_sn_grad_fix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'mcgen_sn_grad_fix_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

@@ -532,7 +532,8 @@ __global__ void sn_k3_wv(const float* __restrict__ wb, const float* __restrict__
     }
 }
 __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ ws,
-                        int ws_stride, int t_off, int do_iter, float* sigma, float* snap) {
+                        int ws_stride, int t_off, int do_iter, float* sigma, float* snap,
+                        const float* sigma_prev = nullptr, float* ratio = nullptr) {
     __shared__ float red[32];
     const mcgen_sn_layer_t L = layers[blockIdx.x];
     const float* t = ws + (size_t)blockIdx.x * ws_stride + t_off;
@@ -547,7 +548,11 @@ __global__ void sn_k4_u(float* uvb, const mcgen_sn_layer_t* __restrict__ layers,
             u[i] = x;
             if (snap) snap[L.u_off + i] = x;
         }
-        if (threadIdx.x == 0) sigma[blockIdx.x] = a * inv;
+        if (threadIdx.x == 0) {
+            sigma[blockIdx.x] = a * inv;
+            // (paired discriminator pass: sigma_1 / sigma_2, what its fake half's codes are scaled by -- saves the caller a launch)
+            if (ratio) ratio[blockIdx.x] = sigma_prev[blockIdx.x] / (a * inv);
+        }
     } else if (threadIdx.x == 0) sigma[blockIdx.x] = a;
 }
 
@@ -1318,7 +1323,7 @@ extern "C" int mcgen_sn_power_iter_snap(const float* w_base, float* uv_base, con
 }
 extern "C" int mcgen_sn_power_iter_rounds(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                           int rounds, float* sigma, float* workspace, int max_rows, int max_cols,
-                                          float* uv_snap, int64_t uv_total, void* stream) {
+                                          float* uv_snap, int64_t uv_total, float* ratio, void* stream) {
     MCGEN_CHECK(w_base && uv_base && layers_dev && sigma && workspace && nlayers > 0 && rounds >= 1 && max_rows > 0 && max_cols > 0,
                 "sn_power_iter_rounds: bad arguments (workspace: nlayers * (32 * max_cols + max_rows) floats, as mcgen_sn_power_iter)");
     MCGEN_CHECK(max_rows <= 1024, "sn_power_iter_rounds: layers up to 1024 rows");
@@ -1333,7 +1338,8 @@ extern "C" int mcgen_sn_power_iter_rounds(const float* w_base, float* uv_base, c
                            v_off, n_off, t_off, snap_r);
     }
     hipLaunchKernelGGL(sn_k4_u, dim3(nlayers), dim3(256), 0, STREAM(stream), uv_base, layers_dev, workspace, ws_stride, t_off, 1,
-                       sigma + (size_t)(rounds - 1) * nlayers, uv_snap ? uv_snap + (size_t)(rounds - 1) * uv_total : nullptr);
+                       sigma + (size_t)(rounds - 1) * nlayers, uv_snap ? uv_snap + (size_t)(rounds - 1) * uv_total : nullptr,
+                       rounds >= 2 ? sigma + (size_t)(rounds - 2) * nlayers : (const float*)nullptr, rounds >= 2 ? ratio : (float*)nullptr);
     MCGEN_LAUNCH_CHECK("sn_power_iter_rounds"); return 0;
 }
 extern "C" int mcgen_sn_power_iter_fused(const float* w_base, float* uv_base, const mcgen_sn_layer_t* layers_dev, int nlayers,

@@ -643,7 +643,9 @@ class DiscriminatorEngine:
                                                    max(s.cout for s in self.sn), max(s.cin * s.ks * s.ks for s in self.sn))
             for s in self.sn:
                 _bump(s.m.weight_u); _bump(s.m.weight_v)
+            self._sn_ratio = sigma[rounds] if rounds >= 2 else None       # sigma[rounds - 2] / sigma[rounds - 1], from the same launch
             return [(sigma[r], snap[r]) for r in range(rounds)]
+        self._sn_ratio = None
         if not _SN_FUSED:                                   # the four-kernel form, one round per call
             out = []
             for _ in range(rounds):
@@ -689,7 +691,7 @@ class DiscriminatorEngine:
         `codes` (optional): `pair_codes(ind2)`, computed once for several updates on the same labels."""
         n = x2.shape[0] // 2 if x2 is not None else real_nchw.shape[0]
         (sigma1, uv1), (sigma2, uv2) = self._power_iters(2, True)
-        ratio = sigma1 / sigma2
+        ratio = self._sn_ratio if getattr(self, '_sn_ratio', None) is not None else sigma1 / sigma2
         if ind2 is None:
             ind2 = torch.cat([indicator, indicator])
         uses = self._code_uses()

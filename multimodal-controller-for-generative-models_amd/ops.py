@@ -801,12 +801,14 @@ def sn_power_iter(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: 
 def sn_power_iter_rounds(w_base: Tensor, uv_base: Tensor, layers_dev: Tensor, nlayers: int, rounds: int,
                          max_rows: int, max_cols: int, snapshot: bool = True):
     """`rounds` training-mode power iterations in 2 * rounds + 1 launches (mcgen_sn_power_iter_rounds)
-    -> (sigma [rounds, nlayers], u/v snapshots [rounds, uv] or None)."""
-    sigma = torch.empty((rounds, nlayers), dtype=torch.float32, device=w_base.device)
+    -> (sigma [rounds + 1, nlayers], u/v snapshots [rounds, uv] or None); for rounds >= 2 the extra last row of `sigma` is
+    sigma[rounds - 2] / sigma[rounds - 1] (the ratio a paired pass scales its second half by)."""
+    sigma = torch.empty((rounds + 1, nlayers), dtype=torch.float32, device=w_base.device)
     snap = torch.empty((rounds, uv_base.numel()), dtype=torch.float32, device=w_base.device) if snapshot else None
     ws = torch.empty(nlayers * (32 * max_cols + max_rows), dtype=torch.float32, device=w_base.device)
     check(_lib.load().mcgen_sn_power_iter_rounds(_f32(w_base), _f32(uv_base), _p(layers_dev), nlayers, rounds, _f32(sigma), _f32(ws),
-                                                 max_rows, max_cols, _f32(snap), uv_base.numel(), _stream()), 'sn_power_iter_rounds')
+                                                 max_rows, max_cols, _f32(snap), uv_base.numel(), sigma[rounds].data_ptr(), _stream()),
+          'sn_power_iter_rounds')
     return sigma, snap
 
 

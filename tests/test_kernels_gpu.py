@@ -436,6 +436,8 @@ def test_spectral_norm_kernels():
             np.testing.assert_allclose(sp[r].cpu(), refs[r][1].cpu(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(UVc.cpu(), UVr.cpu(), rtol=1e-4, atol=1e-6)
         assert torch.equal(sp[rounds - 1], UVc)
+        if rounds >= 2:                                   # the extra row: sigma of the last round but one over the last round's
+            np.testing.assert_allclose(sg[rounds].cpu(), (sg[rounds - 2] / sg[rounds - 1]).cpu(), rtol=1e-6)
     # eval mode: no iteration, same sigma formula
     sig2 = torch.zeros_like(sigma)
     UV2 = UV.clone()
