@@ -78,33 +78,14 @@ def make_scheduler(optimizer):                               # train_gan.py:239-
     raise ValueError('Not valid scheduler name')
 
 
-class FusedSchedule:
-    """A torch LR scheduler for a `FusedAdam` (which is not a torch Optimizer): the scheduler runs on a host-side
-    torch.optim.Adam over one dummy parameter with the same learning rate, and every step pushes the resulting rate
-    into the fused optimizer.  `state_dict()` is therefore exactly torch's scheduler state (what train_gan.py:116-117
-    saves and :270-271 loads)."""
+from _single import FusedSchedule as _FusedScheduleBase  # noqa: E402
+
+
+class FusedSchedule(_FusedScheduleBase):
+    """compat/_single.FusedSchedule with this driver's scheduler table (train_gan.py:239-256)."""
 
     def __init__(self, fused):
-        self.fused = fused
-        self.host = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=fused.lr)
-        self.sched = make_scheduler(self.host)
-
-    def _push(self):
-        self.fused.set_lr(self.host.param_groups[0]['lr'])
-
-    def step(self, *a, **k):
-        self.sched.step(*a, **k)
-        self._push()
-
-    def state_dict(self):
-        return self.sched.state_dict()
-
-    def load_state_dict(self, sd):
-        self.sched.load_state_dict(sd)
-        last = sd.get('_last_lr')
-        if last:
-            self.host.param_groups[0]['lr'] = last[0]
-        self._push()
+        super().__init__(fused, make=make_scheduler)
 
 
 def train_autograd(loader, model, optimizer, epoch):
@@ -173,6 +154,10 @@ def run():
         model.set_compute_dtype(torch.bfloat16)
     if world > 1:
         mdist.broadcast_tensors(list(model.parameters()) + list(model.buffers()))
+        # every rank built the same model from the same seed; from here on the ranks must differ: their own shard of a
+        # common per-epoch permutation (DeviceLoader.set_shard = what DistributedSampler does) and their own latents
+        torch.manual_seed(seed + rank); torch.cuda.manual_seed(seed + rank)
+        loader.set_shard(rank, world, seed)
     path = os.path.join(extra['output_dir'], 'model', f'{cfg["model_tag"]}_checkpoint.pt')
     if extra['engine'] == 'fused':
         tr = GraphedGANTrainer(model, cfg['classes_size'], lr=2e-4, betas=(0.5, 0.999),
@@ -205,9 +190,9 @@ def run():
             last = (float(last[0]), float(last[1]))
         else:
             last = train_autograd(loader, model, optimizer, epoch)
-        n_img = len(loader) * loader.batch_size
+        n_img = len(loader) * loader.batch_size                 # this rank's share of the epoch (the loader is sharded)
         logger.append({'Loss_D': last[0], 'Loss_G': last[1], 'Loss': abs(last[0] - last[1])}, 'train', n=n_img)   # train_gan.py:177-180
-        rate = n_img * world / (time.time() - t0)
+        rate = n_img * world / (time.time() - t0)               # samples consumed by all ranks / wall time
         logger.append({'info': ['Model: {}'.format(cfg['model_tag']), 'Train Epoch: {}(100%)'.format(epoch),
                                 '{:.0f} images/s'.format(rate)]}, 'train', mean=False)
         if rank == 0:

@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -367,19 +367,22 @@ int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n
 
 /* Adam over one flat fp32 buffer (torch.optim.Adam as configured at train_gan.py:43-47,231):
  * step = int64[2] on the device: step[0] is the counter the call increments (by the last workgroup to finish: no
- * follow-up launch), step[1] a ticket word that is 0 between calls. */
-int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+ * follow-up launch), step[1] a ticket word that is 0 between calls.
+ * lr_dev: NULL, or one float in device memory that holds the learning rate -- read when the kernel RUNS, so a launch
+ * captured into a HIP graph follows a learning-rate scheduler (train_gan.py:105-106, train_vae.py:78-81) without a
+ * re-capture; `lr` is ignored then. */
+int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev, float beta1, float beta2,
                float eps, float weight_decay, int64_t* step, void* stream);
 /* mcgen_sn_grad_fix_pair with Adam's update in place of the store (a single-rank discriminator update, train_gan.py:154-158:
  * d/d(weight_orig) is never materialised): for the layers of the table, g = fix(g_src0; uv0, sigma0) + fix(g_src1; uv1, sigma1)
  * goes straight into m, v, p (p doubles as w_base: the dot <g, W> is taken before any element moves).  `advance_step` = 1:
  * the call's dot launch increments step[0] and the update launch behind it reads the new count -- a step that covers its
  * parameters with several tables passes 1 for the first table and 0 for the rest.  workspace: 2 * 32 * nlayers floats;
- * step as in mcgen_adam (the ticket word is not used). */
+ * step and lr_dev as in mcgen_adam (the ticket word is not used). */
 int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, float* p, float* m, float* v,
                            const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
                            const float* sigma0, const float* sigma1, float* workspace,
-                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
+                           float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
                            int advance_step, void* stream);
 
 /* ---- MCGlow-specific kernels (reference: models/mcglow.py) ------------------------------------------------- */

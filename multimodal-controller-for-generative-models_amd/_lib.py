@@ -193,8 +193,8 @@ SYMBOLS = {
     'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'mcgen_hinge_g': (_i, [_vp, _i, _vp, _vp, _vp]),
     'mcgen_tanh_bwd': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
-    'mcgen_adam': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _vp]),
-    'mcgen_sn_fix_pair_adam': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp]),
+    'mcgen_adam': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _vp, _f, _f, _f, _f, _vp, _vp]),
+    'mcgen_sn_fix_pair_adam': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _f, _f, _f, _f, _vp, _i, _vp]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 7; }
+extern "C" int mcgen_abi_version(void) { return 8; }
 
 namespace {
 
@@ -990,7 +990,8 @@ __device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restri
     p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr, float b1, float b2, float eps, float wd, int64_t* step) {
+                            size_t n, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd, int64_t* step) {
+    if (lr_dev) lr = lr_dev[0];          // learning rate read at execution time: a captured launch follows a scheduler
     const long t = (long)step[0] + 1;
     const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
@@ -1010,7 +1011,9 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
                                         const float* __restrict__ uv0, const float* __restrict__ uv1,
                                         const mcgen_sn_layer_t* __restrict__ layers, const float* __restrict__ sigma0,
                                         const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
-                                        float lr, float b1, float b2, float eps, float wd, const int64_t* __restrict__ step) {
+                                        float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd,
+                                        const int64_t* __restrict__ step) {
+    if (lr_dev) lr = lr_dev[0];
     const long t = (long)step[0];
     const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
@@ -1462,22 +1465,22 @@ extern "C" int mcgen_tanh_bwd(const void* dy, const void* y, void* dx, int dtype
     MCGEN_LAUNCH_CHECK("tanh_bwd"); return 0;
 }
 
-extern "C" int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+extern "C" int mcgen_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev, float beta1, float beta2,
                           float eps, float weight_decay, int64_t* step, void* stream) {
     MCGEN_CHECK(p && g && m && v && step && n > 0, "adam: bad arguments (step: int64[2] = {counter, ticket = 0})");
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, STREAM(stream), p, g, m, v, (size_t)n, lr, lr_dev, beta1, beta2, eps, weight_decay, step);
     MCGEN_LAUNCH_CHECK("adam"); return 0;
 }
 extern "C" int mcgen_sn_fix_pair_adam(const float* g_src0, const float* g_src1, float* p, float* m, float* v,
                                       const float* uv0, const float* uv1, const mcgen_sn_layer_t* layers_dev, int nlayers,
                                       const float* sigma0, const float* sigma1, float* workspace,
-                                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
+                                      float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
                                       int advance_step, void* stream) {
     MCGEN_CHECK(g_src0 && g_src1 && p && m && v && uv0 && uv1 && layers_dev && sigma0 && sigma1 && workspace && step && nlayers > 0,
                 "sn_fix_pair_adam: bad arguments (workspace: 2 * 32 * nlayers floats; step: int64[2] = {counter, ticket})");
     hipLaunchKernelGGL(sn_grad_dot2_kernel, dim3(nlayers, SNF_CHUNKS, 2), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, layers_dev,
                        workspace, nlayers, advance_step ? step : (int64_t*)nullptr);
     hipLaunchKernelGGL(sn_fix_pair_adam_kernel, dim3(nlayers, SNA_CHUNKS), dim3(256), 0, STREAM(stream), g_src0, g_src1, p, m, v, uv0, uv1,
-                       layers_dev, sigma0, sigma1, workspace, nlayers, lr, beta1, beta2, eps, weight_decay, step);
+                       layers_dev, sigma0, sigma1, workspace, nlayers, lr, lr_dev, beta1, beta2, eps, weight_decay, step);
     MCGEN_LAUNCH_CHECK("sn_fix_pair_adam"); return 0;
 }

@@ -43,15 +43,34 @@ class DeviceLoader:
         self.images, self.labels = images_u8_nhwc, labels.to(torch.int64)
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self.generator = generator
+        self.rank, self.world, self._shard_seed, self._epoch = 0, 1, 0, 0
+
+    def set_shard(self, rank: int, world: int, seed: int = 0):
+        """Data-parallel sharding (what torch's DistributedSampler does for the reference's loader under one process per
+        GPU): every rank draws the SAME permutation of the dataset per epoch -- from a host generator seeded with
+        `seed` + epoch, independent of the ranks' own RNG streams -- and keeps positions rank, rank + world, ... of it, so
+        one epoch covers the data once across the ranks (the tail that does not divide by `world` is dropped)."""
+        if not 0 <= rank < world:
+            raise ValueError('Not valid shard: rank must be in [0, world)')
+        self.rank, self.world, self._shard_seed = int(rank), int(world), int(seed)
+
+    def _samples(self) -> int:
+        return self.images.shape[0] // self.world
 
     def __len__(self) -> int:
-        n = self.images.shape[0]
+        n = self._samples()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         n = self.images.shape[0]
         dev = self.images.device
-        order = torch.randperm(n, device=dev, generator=self.generator) if self.shuffle else torch.arange(n, device=dev)
+        if self.world > 1:
+            g = torch.Generator().manual_seed(self._shard_seed + self._epoch)
+            self._epoch += 1
+            order = (torch.randperm(n, generator=g) if self.shuffle else torch.arange(n))[:self._samples() * self.world]
+            order = order[self.rank::self.world].to(dev)
+        else:
+            order = torch.randperm(n, device=dev, generator=self.generator) if self.shuffle else torch.arange(n, device=dev)
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             yield {'img': normalize_uint8(self.images.index_select(0, idx)), 'label': self.labels.index_select(0, idx)}

@@ -56,37 +56,69 @@ _NO_INCEPTION = ('{} on {} needs torchvision\'s pre-trained inception_v3 (metric
                  'downloaded here; pass features to inception_score_from_probs / fid_from_features instead')
 
 
-def feature_network(data_name: str, checkpoint: str | None = None, device=None):
+_MODEL_CACHE: dict = {}
+_REAL_CACHE: dict = {}
+
+
+def classifier_checkpoint_path(data_name: str, subset: str | None = 'label') -> str:
+    """Where the reference keeps the feature network's weights (metrics.py:50-53,90-93):
+    ./metrics_tf/res/classifier/0_<data>_<subset>_classifier_best.pt (empty tag parts dropped)."""
+    tag = '_'.join(filter(None, ['0', data_name, subset, 'classifier']))
+    return './metrics_tf/res/classifier/{}_best.pt'.format(tag)
+
+
+def feature_network(data_name: str, checkpoint: str | None = None, device=None, subset: str | None = 'label'):
     """The feature network the reference evaluates `data_name` with: its own `models.classifier()` for COIL100 /
-    Omniglot (metrics.py:49-53,89-94; weights from `checkpoint`, a reference-format `*_best.pt`), on the fused
-    convolution path.  Other datasets use inception_v3: ValueError."""
+    Omniglot (metrics.py:49-55,89-95) on the fused convolution path, with the weights of `checkpoint` -- default: the
+    reference's own location (classifier_checkpoint_path).  A missing file raises: an IS / FID from a randomly
+    initialised classifier is not a metric.  Other datasets use inception_v3: ValueError.  The model is cached per
+    (checkpoint file, mtime, device)."""
     if data_name not in ('COIL100', 'Omniglot'):
         raise ValueError(_NO_INCEPTION.format('IS / FID', data_name))
+    import os
     from .models.classifier import classifier
     from .checkpoint import load
-    model = classifier()
-    if checkpoint is not None:
-        model.load_state_dict(load(checkpoint)['model_dict'])
-    if device is not None:
-        model = model.to(device)
-    model.train(False)
-    return model
+    path = checkpoint if checkpoint is not None else classifier_checkpoint_path(data_name, subset)
+    if not os.path.exists(path):
+        raise FileNotFoundError('IS / FID on {} need the trained feature classifier at {} (metrics.py:50-55; written by the '
+                                "reference's train_classifier.py): refusing to score with random weights".format(data_name, path))
+    key = (os.path.abspath(path), os.path.getmtime(path), str(device))
+    if key not in _MODEL_CACHE:
+        model = classifier()
+        model.load_state_dict(load(path)['model_dict'])
+        if device is not None:
+            model = model.to(device)
+        model.train(False)
+        _MODEL_CACHE.clear()
+        _MODEL_CACHE[key] = model
+    return _MODEL_CACHE[key]
 
 
-def inception_score(img: torch.Tensor, data_name: str, splits: int = 1, model=None, batch_size: int = 512) -> float:
+def inception_score(img: torch.Tensor, data_name: str, splits: int = 1, model=None, batch_size: int = 512,
+                    subset: str | None = 'label') -> float:
     """metrics.py:44-81 with the class probabilities kept on the device: img [N, C, H, W] in (-1, 1)."""
-    model = model if model is not None else feature_network(data_name, device=img.device)
+    model = model if model is not None else feature_network(data_name, device=img.device, subset=subset)
     with torch.no_grad():
         pred = torch.cat([torch.softmax(model({'img': x, 'label': x.new_zeros(x.shape[0]).long()})['label'].float(), -1)
                           for x in img.split(batch_size)])
     return inception_score_from_probs(pred, splits)
 
 
-def fid(img: torch.Tensor, data_name: str, real: torch.Tensor | None = None, model=None, batch_size: int = 512) -> float:
-    """metrics.py:84-161: features of `real` (the training images, [N, C, H, W] in (-1, 1)) against those of `img`."""
+def fid(img: torch.Tensor, data_name: str, real=None, model=None, batch_size: int = 512, subset: str | None = 'label') -> float:
+    """metrics.py:84-161: features of the training images against those of `img` ([N, C, H, W] in (-1, 1)).  `real` is
+    a tensor of images, or an iterable of collated batches {'img': ...} (the reference re-reads its train loader,
+    metrics.py:88-105); its features are cached per (model, id(real))."""
     if real is None:
         raise ValueError('Not valid input: fid needs the real images (the reference re-reads its training set, metrics.py:88)')
-    model = model if model is not None else feature_network(data_name, device=img.device)
+    model = model if model is not None else feature_network(data_name, device=img.device, subset=subset)
     with torch.no_grad():
         f = lambda t: torch.cat([model.feature({'img': x}).float() for x in t.split(batch_size)])      # noqa: E731
-        return fid_from_features(f(real), f(img))
+        key = (id(model), id(real))
+        if key not in _REAL_CACHE:
+            if torch.is_tensor(real):
+                rf = f(real)
+            else:
+                rf = torch.cat([model.feature({'img': b['img'].to(img.device)}).float() for b in real])
+            _REAL_CACHE.clear()
+            _REAL_CACHE[key] = (real, rf)           # (keeps `real` alive so the id stays unique)
+        return fid_from_features(_REAL_CACHE[key][1], f(img))

@@ -840,22 +840,34 @@ def sn_grad_fix_pair(g_src0: Tensor, g_src1: Tensor, g_dst: Tensor, w_base: Tens
 
 
 def sn_fix_pair_adam(g_src0: Tensor, g_src1: Tensor, p: Tensor, m: Tensor, v: Tensor, uv0: Tensor, uv1: Tensor,
-                     layers_dev: Tensor, nlayers: int, sigma0: Tensor, sigma1: Tensor, step: Tensor, lr: float, betas,
+                     layers_dev: Tensor, nlayers: int, sigma0: Tensor, sigma1: Tensor, step: Tensor, lr, betas,
                      eps: float, weight_decay: float, advance_step: bool):
     """mcgen_sn_fix_pair_adam: the spectral-norm gradient fix of both halves of a paired discriminator pass fused with
-    Adam's update of the same layers (`step`: the int64[2] {counter, ticket} buffer of ops.adam)."""
+    Adam's update of the same layers (`step`: the int64[2] {counter, ticket} buffer of ops.adam; `lr` as in ops.adam)."""
     assert step.dtype == torch.int64 and step.numel() == 2
     ws = torch.empty(2 * 32 * nlayers, dtype=torch.float32, device=p.device)
+    lr_f, lr_dev = _lr_args(lr)
     check(_lib.load().mcgen_sn_fix_pair_adam(_f32(g_src0), _f32(g_src1), _f32(p), _f32(m), _f32(v), _f32(uv0), _f32(uv1),
-                                             _p(layers_dev), nlayers, _f32(sigma0), _f32(sigma1), _f32(ws), lr, betas[0], betas[1],
+                                             _p(layers_dev), nlayers, _f32(sigma0), _f32(sigma1), _f32(ws), lr_f, lr_dev, betas[0], betas[1],
                                              eps, weight_decay, _p(step), int(advance_step), _stream()), 'sn_fix_pair_adam')
 
 
-def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr: float, betas=(0.9, 0.999),
+def _lr_args(lr):
+    """(float, device pointer or None): a one-element fp32 device tensor is handed over as lr_dev (read when the kernel
+    runs, so captured launches follow a scheduler), a Python number as the immediate."""
+    if isinstance(lr, Tensor):
+        assert lr.dtype == torch.float32 and lr.numel() == 1 and lr.is_cuda
+        return 0.0, _f32(lr)
+    return float(lr), None
+
+
+def adam(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: Tensor, lr, betas=(0.9, 0.999),
          eps: float = 1e-8, weight_decay: float = 0.0):
-    """`step`: int64[2] on the device -- [0] the step counter (incremented by the launch), [1] a ticket word (0 between calls)."""
+    """`step`: int64[2] on the device -- [0] the step counter (incremented by the launch), [1] a ticket word (0 between calls).
+    `lr`: a Python number, or a one-element fp32 device tensor read at execution time (mcgen_adam's lr_dev)."""
     assert step.dtype == torch.int64 and step.numel() == 2
-    check(_lib.load().mcgen_adam(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, betas[0], betas[1], eps,
+    lr_f, lr_dev = _lr_args(lr)
+    check(_lib.load().mcgen_adam(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr_f, lr_dev, betas[0], betas[1], eps,
                                  weight_decay, _p(step), _stream()), 'adam')
 
 

@@ -46,18 +46,35 @@ class FusedAdam:
         self.v = torch.zeros_like(flat)
         self._step_buf = torch.zeros(2, dtype=torch.int64, device=flat.device)     # {step counter, launch ticket} (ops.adam)
         self.step_count = self._step_buf[:1]
+        # the learning rate lives in device memory and the kernels read it when they run (mcgen_adam's lr_dev): a
+        # scheduler step is one fill_ and the captured graphs stay valid
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=flat.device) if flat.is_cuda else None
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if getattr(self, '_lr_dev', None) is not None:
+            self._lr_dev.fill_(self._lr)
 
     def hyper(self):
         """The hyper-parameters a launch bakes in as kernel arguments (a captured HIP graph replays the values it was
-        captured with: the graphed trainers compare this key on every iteration and re-capture when it moved)."""
-        return (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps), float(self.wd))
+        captured with: the graphed trainers compare this key on every iteration and re-capture when it moved).  The
+        learning rate is NOT among them: it is read from device memory at execution time."""
+        return (tuple(float(b) for b in self.betas), float(self.eps), float(self.wd))
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
 
+    def _lr_arg(self):
+        return self._lr_dev if self._lr_dev is not None else self._lr
+
     def step(self, gflat: torch.Tensor):
         flat = self.fs.ensure()
-        ops.adam(flat, gflat, self.m, self.v, self._step_buf, self.lr, self.betas, self.eps, self.wd)
+        ops.adam(flat, gflat, self.m, self.v, self._step_buf, self._lr_arg(), self.betas, self.eps, self.wd)
         for p in self.fs.tensors:
             _bump(p)
 
@@ -68,7 +85,7 @@ class FusedAdam:
         tables = [t for t in pending['tables'] if t[0][1] > 0]
         for i, ((table, nl), sg_off) in enumerate(tables):
             ops.sn_fix_pair_adam(pending['g0'], pending['g1'], flat, self.m, self.v, pending['uv0'], pending['uv1'], table, nl,
-                                 pending['sigma0'][sg_off:], pending['sigma1'][sg_off:], self._step_buf, self.lr, self.betas,
+                                 pending['sigma0'][sg_off:], pending['sigma1'][sg_off:], self._step_buf, self._lr_arg(), self.betas,
                                  self.eps, self.wd, i == 0)
         for p in self.fs.tensors:
             _bump(p)

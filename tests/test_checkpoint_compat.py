@@ -172,6 +172,120 @@ print('SHIMS2-OK')
     assert r.returncode == 0 and 'SHIMS2-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_single_optimizer_drivers_import_blocks_and_utils_resume(tmp_path):
+    """The import blocks of the three single-optimizer drivers -- train_vae.py:1-14, train_glow.py:1-15,
+    train_pixelcnn.py:1-14 (restated here; `torch.backends.cudnn` is torch's own) -- bind against compat/, and
+    `utils.resume` behaves as utils.py:237-256: a missing ./output/model/<tag>_<load_tag>.pt prints, starts at epoch 1
+    with a fresh Logger and hands model / optimizer / scheduler back untouched; an existing file restores all three plus
+    the pickled Logger.  The Metric table carries the names those drivers log (BCE, NLL: metrics.py:22-33,189-190)."""
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(ROOT, 'compat'))
+# train_vae.py:1-14
+import argparse, datetime, models, os, shutil, time, torch
+import torch.backends.cudnn as cudnn
+import torch.optim as optim
+from config import cfg
+from data import fetch_dataset, make_data_loader
+from metrics import Metric
+from utils import save, to_device, process_control, process_dataset, resume, collate, save_img
+from logger import Logger
+# train_glow.py:10,14 adds islice and drops save_img; train_pixelcnn.py:13 the same names without save_img
+from itertools import islice
+from utils import save, to_device, process_control, process_dataset, resume, collate
+cfg.update(data_name='CIFAR10', model_name='mcvae', device='cpu'); cfg.pop('classes_size', None)
+process_control()
+cfg['vae'].update(hidden_size=[8, 16, 32], latent_size=16)
+cfg['model_tag'] = '0_CIFAR10_label_mcvae_0.5'
+model = models.mcvae()
+opt = optim.Adam(model.parameters(), lr=3e-4)
+sch = optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.5, patience=10, threshold=1e-3, threshold_mode='rel', min_lr=1e-5)
+last, m2, o2, s2, lg = resume(model, cfg['model_tag'], opt, sch)
+assert last == 1 and m2 is model and o2 is opt and s2 is sch and type(lg).__name__ == 'Logger' and 'train_0_CIFAR10' in lg.log_path
+# write a checkpoint the way train_vae.py:83-88 does, then resume it into fresh objects
+for p in model.parameters():
+    p.grad = torch.ones_like(p)
+opt.step(); sch.step(metrics=1.0)
+lg.safe(True); lg.append({'Loss': 2.0}, 'test', n=4); lg.safe(False)
+save({'cfg': cfg, 'epoch': 5, 'model_dict': model.state_dict(), 'optimizer_dict': opt.state_dict(),
+      'scheduler_dict': sch.state_dict(), 'logger': lg}, './output/model/{}_checkpoint.pt'.format(cfg['model_tag']))
+model3 = models.mcvae()
+opt3 = optim.Adam(model3.parameters(), lr=1.0)
+sch3 = optim.lr_scheduler.ReduceLROnPlateau(opt3, mode='min', factor=0.5, patience=10, threshold=1e-3, threshold_mode='rel', min_lr=1e-5)
+last, model3, opt3, sch3, lg3 = resume(model3, cfg['model_tag'], opt3, sch3)
+assert last == 5 and opt3.param_groups[0]['lr'] == 3e-4 and sch3.best == 1.0 and lg3.history['test/Loss'] == [2.0]
+for (k, a), (_, b) in zip(model.state_dict().items(), model3.state_dict().items()):
+    assert torch.equal(a, b), k
+p0 = next(iter(model3.parameters()))
+assert int(opt3.state[p0]['step']) == 1
+# load_tag='best' (train_pixelcnn.py:59) with no file: scratch, model returned as given
+ae = models.vqvae() if 'vqvae' in cfg else None
+_, m4, _, _, _ = resume(model3, '0_CIFAR10_label_vqvae', load_tag='best')
+assert m4 is model3
+out = {'loss': torch.tensor(2.0), 'img': torch.tensor([[0.0, 0.5]]), 'logits': torch.tensor([[[2.0], [0.0]]])}
+ev = Metric().evaluate(['Loss', 'BCE'], {'img': torch.tensor([[0.0, 0.5]])}, dict(out, img=torch.tensor([[0.0, 0.5]])))
+ref_bce = float(torch.nn.functional.binary_cross_entropy(torch.tensor([[0.5, 0.75]]), torch.tensor([[0.5, 0.75]])))
+assert abs(ev['BCE'] - ref_bce) < 1e-7
+nll = Metric().evaluate(['NLL'], {'img': torch.tensor([[0]])}, out)['NLL']
+assert abs(nll - float(torch.nn.functional.cross_entropy(out['logits'], torch.tensor([[0]])))) < 1e-7
+print('SINGLE-OK')
+'''.replace('ROOT', repr(ROOT))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and 'SINGLE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert 'Not exists model tag: 0_CIFAR10_label_mcvae_0.5, start from scratch' in r.stdout and 'Resume from 5' in r.stdout
+
+
+def test_is_fid_refuse_to_score_without_the_trained_classifier(tmp_path):
+    """ADVICE round 3: InceptionScore / FID on COIL100 / Omniglot load the reference's classifier checkpoint
+    (./metrics_tf/res/classifier/0_<data>_<subset>_classifier_best.pt, metrics.py:50-55,90-95); when it is missing they
+    raise instead of scoring a randomly initialised network."""
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(ROOT, 'compat'))
+import torch
+from config import cfg
+from metrics import Metric
+from utils import process_control
+from mcgen_amd.metrics import classifier_checkpoint_path
+cfg.update(data_name='COIL100', model_name='mcgan', device='cpu', subset='label'); cfg.pop('classes_size', None)
+process_control()
+assert classifier_checkpoint_path('COIL100', 'label') == './metrics_tf/res/classifier/0_COIL100_label_classifier_best.pt'
+for name in ('InceptionScore', 'FID'):
+    try:
+        Metric().evaluate([name], None, {'img': torch.zeros(4, 3, 32, 32)})
+        raise SystemExit(name + ' scored without a checkpoint')
+    except FileNotFoundError as e:
+        assert '0_COIL100_label_classifier_best.pt' in str(e) and 'random' in str(e)
+print('ISFID-OK')
+'''.replace('ROOT', repr(ROOT))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and 'ISFID-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_device_loader_shards_cover_the_data_once():
+    """DeviceLoader.set_shard (ADVICE round 3: every rank of compat/train_gan.py used to train on identical batches):
+    the ranks of a world draw one common permutation per epoch and keep disjoint, equally sized slices of it; the next
+    epoch's permutation differs; a single-rank loader is unchanged."""
+    from mcgen_amd.data import DeviceLoader
+    n, world = 103, 4
+    img = torch.arange(n, dtype=torch.uint8).view(n, 1, 1, 1).expand(n, 2, 2, 1).contiguous()
+    lab = torch.arange(n)
+    loaders = [DeviceLoader(img, lab, 8, shuffle=True) for _ in range(world)]
+    for r, ld in enumerate(loaders):
+        torch.manual_seed(100 + r)                       # the ranks' own RNG streams differ -- the shards must not depend on them
+        ld.set_shard(r, world, seed=7)
+    epochs = []
+    for _ in range(2):
+        seen = [torch.cat([b['label'] for b in ld]) for ld in loaders]
+        assert all(s.numel() == n // world for s in seen) and len(loaders[0]) == (n // world + 7) // 8
+        allv = torch.cat(seen)
+        assert allv.unique().numel() == allv.numel() == (n // world) * world      # disjoint: the data once per epoch
+        epochs.append(allv)
+    assert not torch.equal(epochs[0], epochs[1])
+    with pytest.raises(ValueError):
+        loaders[0].set_shard(4, 4)
+
+
 def test_reference_checkpoint_with_pickled_logger_resumes(tmp_path):
     """A reference `*_checkpoint.pt` pickles a `logger.Logger` INSTANCE and the scheduler states (train_gan.py:112-118).
     (1) A file whose logger was pickled by a class laid out like the reference's own (module `logger`, plain attribute
@@ -324,6 +438,37 @@ def test_driver_counterpart_runs_and_resumes(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'Resume from 2' in r.stdout and 'Train Epoch: 2' in r.stdout and 'Train Epoch: 1' not in r.stdout
     assert int(ck.load(path)['optimizer_dict']['discriminator']['state'][0]['step']) == 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('driver,model,flags,metric', [
+    ('train_vae.py', 'mcvae', ['--batch', '32'], 'BCE'),
+    ('train_glow.py', 'mcglow', ['--batch', '16', '--synthetic_size', '128'], 'Loss'),
+    ('train_pixelcnn.py', 'mcpixelcnn', ['--batch', '64'], 'NLL')])
+def test_single_optimizer_driver_counterparts_run_and_resume(tmp_path, driver, model, flags, metric):
+    """compat/train_vae.py / train_glow.py / train_pixelcnn.py with the reference's CLI (train_vae.py:18-28) on the
+    synthetic on-device dataset: one epoch on the fused trainers (graph replay), the checkpoint in the reference's layout
+    (train_vae.py:83-92: single optimizer / scheduler state dicts, pickled Logger, *_best.pt copied on improvement), then
+    --resume_mode 1 through utils.resume picks it up at epoch 2."""
+    from mcgen_amd import checkpoint as ck
+    base = [sys.executable, os.path.join(ROOT, 'compat', driver), '--data_name', 'CIFAR10', '--model_name', model,
+            '--control_name', '0.5', '--init_seed', '0', '--synthetic_size', '256'] + flags
+    r = subprocess.run(base + ['--num_epochs', '1'], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert 'Train Epoch: 1' in r.stdout and 'Test Epoch: 1' in r.stdout
+    tag = f'0_CIFAR10_label_{model}_0.5'
+    path = os.path.join(str(tmp_path), 'output', 'model', f'{tag}_checkpoint.pt')
+    raw = ck.load(path)
+    assert raw['epoch'] == 2 and set(raw['optimizer_dict']) == {'state', 'param_groups'}
+    assert raw['optimizer_dict']['param_groups'][0]['lr'] == 3e-4 and 'best' in raw['scheduler_dict']     # ReduceLROnPlateau
+    assert type(raw['logger']).__module__ == 'logger' and f'test/{metric}' in raw['logger'].history
+    assert os.path.exists(path.replace('_checkpoint.pt', '_best.pt'))
+    steps = int(raw['optimizer_dict']['state'][0]['step'])
+    assert steps >= 1
+    r = subprocess.run(base + ['--num_epochs', '2', '--resume_mode', '1'], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert 'Resume from 2' in r.stdout and 'Train Epoch: 2' in r.stdout and 'Train Epoch: 1(' not in r.stdout
+    assert int(ck.load(path)['optimizer_dict']['state'][0]['step']) == 2 * steps
 
 
 def test_is_fid_statistics_match_the_reference_formulas():

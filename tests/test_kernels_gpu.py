@@ -3,8 +3,11 @@ PyTorch fp32 CPU restatements of the same op chains.
 
 fp32 instantiation: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), compared at
 rtol 2e-5 / atol 2e-5 * scale (summation order differs from oneDNN).
-bf16 instantiation: inputs/weights rounded to bf16, fp32 accumulate; compared
-against the fp32 reference at 3e-2 of the output's max magnitude.
+bf16 instantiation: inputs/weights (and the prologue's output, as the kernel does) rounded to bf16 on BOTH
+sides, fp32 accumulate; what is left is one bf16 rounding of the stored output (2^-9 relative) plus fp32
+summation order, so the bound is atol 4e-3 * max|ref| + rtol 1e-2 (round 3 used 3e-2 / 3e-2, which a dropped
+border pixel at K = 2304 could pass).  Tests whose operands cannot be pre-rounded on the reference side pass
+`loose=` with the reason at the call site.
 """
 import numpy as np
 import pytest
@@ -21,13 +24,19 @@ def _ops():
     return ops
 
 
-def _tol(dtype, ref):
+BF16_ATOL, BF16_RTOL = 4e-3, 1e-2
+
+
+def _tol(dtype, ref, loose=None):
     scale = float(ref.abs().max()) + 1e-6
-    return (2e-5 * scale + 1e-6, 2e-5) if dtype == torch.float32 else (3e-2 * scale, 3e-2)
+    if dtype == torch.float32:
+        return (2e-5 * scale + 1e-6, 2e-5)
+    a, r = loose if loose is not None else (BF16_ATOL, BF16_RTOL)
+    return (a * scale, r)
 
 
-def _assert_close(got, ref, dtype, what=''):
-    atol, rtol = _tol(dtype, ref)
+def _assert_close(got, ref, dtype, what='', loose=None):
+    atol, rtol = _tol(dtype, ref, loose)
     got = got.float().cpu()
     err = (got - ref).abs()
     bad = err > atol + rtol * ref.abs()
@@ -36,6 +45,27 @@ def _assert_close(got, ref, dtype, what=''):
 
 def _rnd(gen, *shape):
     return torch.randn(*shape, generator=gen)
+
+
+def _hot(x, amp=24.0):
+    """Border probes: the same random tensor with a few entries made `amp` times larger than
+    the rest, so that a kernel which drops a border pixel, the last channel, or a channel next to the compacted-pitch /
+    32-channel chunk edges is off by a large fraction of max|ref| instead of 1/150 of it: all channels of the four corner
+    pixels of the first and the last image, and channels {C-1, 31, 32, 95, 96, 159, 160} (those < C) of every pixel of
+    the images in between.  Positive values, so a ReLU in the prologue keeps them."""
+    x = x.clone()
+    n, c, h, w = x.shape
+    for img in {0, n - 1}:
+        for r, q in ((0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1)):
+            x[img, :, r, q] = x[img, :, r, q].abs() * amp + amp
+    mid = slice(1, n - 1) if n > 2 else slice(0, n)
+    for ch in (c - 1, 31, 32, 95, 96, 159, 160):
+        if 0 <= ch < c:
+            x[mid, ch] = x[mid, ch].abs() * amp + amp
+    return x
+
+
+PROBES = [False, True]
 
 
 def _nhwc(ops, x, dtype):
@@ -512,17 +542,22 @@ BIG_A = [
 ]
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', BIG_A)
-def test_big_conv_a_upsample_bn_code_stats(case, dtype):
+def test_big_conv_a_upsample_bn_code_stats(case, dtype, probe):
     """G.conv_a at the bench's sizes: BN -> ReLU -> x2 upsample -> MC code -> conv3x3 + bias, next-BN sums."""
     ops = _ops()
     n, h, c, t16, t32 = case
     if dtype == torch.float32 and n * h * h > 65536:
         pytest.skip('fp32 parity instantiation covered at N=64 (same tile, half the CPU reference time)')
+    if probe and dtype == torch.float32:
+        pytest.skip('border probes target the bf16 forms the bench times')
     g = torch.Generator().manual_seed(101 + n + h + c)
     hs = h // 2
     x = _rnd(g, n, c, hs, hs)
+    if probe:
+        x = _hot(x)
     scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
     code = (torch.rand(n, c, generator=g) < 0.5).float()
     wt, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
@@ -541,16 +576,21 @@ def test_big_conv_a_upsample_bn_code_stats(case, dtype):
                                atol=tol['atol'] * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('n,h,c,t16', [(128, 32, 256, (256, 256)), (128, 16, 256, (128, 256))])
-def test_big_conv_b_with_shortcut_segment(n, h, c, t16, dtype):
+def test_big_conv_b_with_shortcut_segment(n, h, c, t16, dtype, probe):
     """G.conv_b at the bench's sizes: conv3x3(BN/ReLU/MC2(h)) + conv1x1(MC1(Up(x))) as one K-concatenated launch."""
     ops = _ops()
     if dtype == torch.float32:
+        if probe:
+            pytest.skip('border probes target the bf16 forms the bench times')
         n //= 2
     g = torch.Generator().manual_seed(211 + h)
     hs = h // 2
     h_in, x = _rnd(g, n, c, h, h), _rnd(g, n, c, hs, hs)
+    if probe:
+        h_in, x = _hot(h_in), _hot(x, 8.0)
     scale, shift = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
     code1 = (torch.rand(n, c, generator=g) < 0.5).float()
     code2 = (torch.rand(n, c, generator=g) < 0.5).float()
@@ -568,9 +608,10 @@ def test_big_conv_b_with_shortcut_segment(n, h, c, t16, dtype):
     _assert_close(ops.to_nchw(y, c), ref, dtype, 'big conv_b + shortcut')
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('pool', [False, True])
-def test_big_dgrad_gate_bnstats(dtype, pool):
+def test_big_dgrad_gate_bnstats(dtype, pool, probe):
     """Input-gradient launches of G's 32x32 layers at the bench's batch: transposed weights, MC code on the output
     channels, ReLU-after-BN gate, the two BatchNorm-backward sums; pool=True is conv_a's form (x2-upsample adjoint)."""
     ops = _ops()
@@ -578,6 +619,10 @@ def test_big_dgrad_gate_bnstats(dtype, pool):
     g = torch.Generator().manual_seed(307 + pool)
     ho = h // 2 if pool else h
     dy = _rnd(g, n, c, h, h)
+    if probe:
+        if dtype == torch.float32:
+            pytest.skip('border probes target the bf16 forms the bench times')
+        dy = _hot(dy)
     wt = _rnd(g, c, c, 3, 3) * 0.03
     xin = _rnd(g, n, c, ho, ho)
     mean, rstd = _rnd(g, c) * 0.2, torch.rand(c, generator=g) + 0.5
@@ -686,17 +731,22 @@ def test_big_conv_image_input_dma3_tile():
     _assert_close(ops.to_nchw(y, c), ref, dtype, 'image-input conv')
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('n,h,t16', [(128, 32, (256, 128)), (256, 32, (256, 128)), (256, 16, (256, 128)), (128, 16, (64, 128))])
-def test_big_conv_pool_residual(n, h, t16, dtype):
+def test_big_conv_pool_residual(n, h, t16, dtype, probe):
     """D's 128-channel layers at the bench's batch (128 images, 256 for the paired real + fake pass):
     ReLU -> MC -> conv3x3 -> AvgPool2 + residual.  bf16 from 65536 pixels up: the software-pipelined 256 x 128 tile."""
     ops = _ops()
     if dtype == torch.float32 and n > 128:
         pytest.skip('fp32: same tile as the N=128 case')
+    if probe and dtype == torch.float32:
+        pytest.skip('border probes target the bf16 forms the bench times')
     g = torch.Generator().manual_seed(401 + n + h)
     c = 128
     x, res = _rnd(g, n, c, h, h), _rnd(g, n, c, h // 2, h // 2)
+    if probe:
+        x = _hot(x)
     code = (torch.rand(n, c, generator=g) < 0.5).float() * (1.0 + 0.25 * (torch.arange(n) >= n // 2).float().view(n, 1))
     wt, b = _rnd(g, c, c, 3, 3) * 0.04, _rnd(g, c)
     a = ref_prologue(_q(x, dtype), None, None, True, code, False)
@@ -823,8 +873,9 @@ def test_skinny_split_k_conv_bf16(n, h, c, co, res, prol):
     _assert_close(ops.to_nchw(y, co), ref, dtype, 'skinny conv')
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('n,case', [(256, 'forward'), (128, 'forward'), (256, 'input gradient'), (128, 'input gradient'), (3, 'affine')])
-def test_whole_image_conv_bf16(n, case):
+def test_whole_image_conv_bf16(n, case, probe):
     """conv_smap.hip: 3x3, 128 -> 128 on 8x8 maps (the discriminator's 8x8 residual blocks, mcgan.py:95-138, forward and
     input-gradient direction): whole images per workgroup (two at N = 256), weight fragments straight from the image, K
     parts combined in LDS -- prologue (ReLU, code, affine) and epilogue (alpha, bias, bias2, output code, ReLU gate,
@@ -834,6 +885,8 @@ def test_whole_image_conv_bf16(n, case):
     c = 128
     g = torch.Generator().manual_seed(1201 + n)
     x = _rnd(g, n, c, 8, 8)
+    if probe:
+        x = _hot(x)
     wt, b = _rnd(g, c, c, 3, 3) * 0.03, _rnd(g, c)
     kw, alpha = {}, 1.0
     if case == 'forward':
@@ -906,8 +959,9 @@ def test_whole_image_conv_pixelcnn_shapes_bf16(segs, co, stats, n):
         np.testing.assert_allclose(st[:, 1].cpu(), (yq * yq).sum((2, 3)), rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('n,c,gn', [(6, 256, 3), (5, 160, 0), (128, 256, 128)])
-def test_image_head_conv_bf16(n, c, gn):
+def test_image_head_conv_bf16(n, c, gn, probe):
     """conv_head.hip: the generator's image head (mcgan.py:55-60: BatchNorm -> ReLU -> MC -> Conv3x3(C, 3) -> Tanh on 32x32
     maps; C = 256, or a compacted 160) with double-buffered input windows; BatchNorm affine per statistics group of `gn`
     images -- against F.conv2d on the CPU."""
@@ -916,6 +970,8 @@ def test_image_head_conv_bf16(n, c, gn):
     g = torch.Generator().manual_seed(1701 + n + c)
     groups = n // gn if gn else 1
     x = _rnd(g, n, c, 32, 32)
+    if probe:
+        x = _hot(x, 6.0)        # (tanh output: keep the pre-activation inside its sensitive range)
     scale, shift = _rnd(g, groups, c) * 0.5 + 1, _rnd(g, groups, c) * 0.3
     code = (torch.rand(n, c, generator=g) < 0.5).float()
     wt, b = _rnd(g, 3, c, 3, 3) * 0.05, _rnd(g, 3)
@@ -935,8 +991,9 @@ def test_image_head_conv_bf16(n, c, gn):
     _assert_close(ops.to_nchw(y, 3), ref, dtype, 'image head')
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('n', [256, 128, 3])
-def test_image_conv_bf16(n):
+def test_image_conv_bf16(n, probe):
     """conv_c8.hip: the discriminator's first convolution (FirstDisResBlock, mcgan.py:72-93: 3 -> 128 on the 32x32 image,
     channel pitch 8) with K = (tap, channel) and stores straight from the accumulators; per-sample code on the input (the
     paired pass's sigma ratio), bias -- against F.conv2d on the CPU."""
@@ -944,6 +1001,8 @@ def test_image_conv_bf16(n):
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(1601 + n)
     x = _rnd(g, n, 3, 32, 32)
+    if probe:
+        x = _hot(x)
     wt, b = _rnd(g, 128, 3, 3, 3) * 0.2, _rnd(g, 128)
     code = torch.rand(n, 1, generator=g).expand(n, 8).contiguous() + 0.5        # one scalar per sample on every input channel
     a = _q(_q(x, dtype) * code[:, :3, None, None], dtype)
@@ -1083,8 +1142,9 @@ MULTI_PASSES = {
 }
 
 
+@pytest.mark.parametrize('probe', PROBES)
 @pytest.mark.parametrize('name', list(MULTI_PASSES))
-def test_wgrad_multi_pass_bf16(name):
+def test_wgrad_multi_pass_bf16(name, probe):
     """mcgen_wgrad_multi (wgrad_multi.hip): the 3x3 weight gradients of one backward pass queued inside a deferred_reduces
     context run as ONE launch with FLOP-proportional pixel splits; every layer against the CPU reference
     (torch.nn.grad.conv2d_weight on the prologue-applied, bf16-rounded operands), bias gradients and the per-half
@@ -1103,6 +1163,8 @@ def test_wgrad_multi_pass_bf16(name):
         code = (torch.rand(n, ci, generator=g) < 0.5).float()
         hd = h // 2 if dy_ups else h
         dy = _rnd(g, n, co, hd, hd) * 0.1
+        if probe:
+            x, dy = _hot(x), _hot(dy, 8.0)
         a = _q(ref_prologue(_q(x, dtype), scale, shift, True, code, ups), dtype)
         dyf = _q(dy, dtype)
         if dy_ups:

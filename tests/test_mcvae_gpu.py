@@ -132,6 +132,37 @@ def test_mcvae_train_steps_vs_reference():
     assert all(np.isfinite(l2)) and abs(l2[0] - losses[1]) < 2e-2
 
 
+def test_replay_follows_a_learning_rate_change_without_recapture():
+    """the fused Adam reads its learning rate from device memory (mcgen_adam's lr_dev), so a scheduler
+    step between replays of a captured train step needs no re-capture: an eager trainer and a graph-replaying one, fed
+    the same noise, with the rate halved after the first step and restored after the second, end in the same
+    parameters; a parameter the kernels bake in (beta) still refuses to replay."""
+    from mcgen_amd.trainer import VAETrainer
+    d = gu.load_npz('mcvae_small.npz')
+    img, lab = torch.from_numpy(d['img']).cuda(), torch.from_numpy(d['label']).cuda()
+    eps = [torch.from_numpy(d[f'noise/{s}/0']).cuda() for s in range(3)]
+    te, tg = VAETrainer(_model(gu.state_from_npz(d))), VAETrainer(_model(gu.state_from_npz(d)))
+    tg.capture(img, lab, warmup=1)
+    key = tg._hyper_key
+    rates = [3e-4, 1.5e-4, 6e-4]
+    for s in range(3):
+        te.opt.set_lr(rates[s]); tg.opt.set_lr(rates[s])
+        le, lg = te.train_iteration(img, lab, eps[s]), tg.train_iteration(img, lab, eps[s])
+        assert abs(float(le) - float(lg)) < 1e-6 * (1 + abs(float(le))), (s, float(le), float(lg))
+    assert tg._hyper_key == key and tg.opt.state_dict()['param_groups'][0]['lr'] == 6e-4
+    for (k, a), (_, b) in zip(te.model.state_dict().items(), tg.model.state_dict().items()):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-6 * (1 + float(a.float().abs().max())), k
+    # the rate really is applied: a third trainer that never changes it ends elsewhere
+    t0 = VAETrainer(_model(gu.state_from_npz(d)))
+    for s in range(3):
+        t0.train_iteration(img, lab, eps[s])
+    w0, wg = next(iter(t0.model.parameters())), next(iter(tg.model.parameters()))
+    assert float((w0 - wg).abs().max()) > 1e-5
+    tg.opt.betas = (0.8, 0.999)
+    with pytest.raises(RuntimeError):
+        tg.train_iteration(img, lab, eps[0])
+
+
 def test_mcvae_config0_full_size():
     """BASELINE.json configs[0] (MCVAE CIFAR-10, hidden [64,128,256], latent 128, batch 32) on the HIP path:
     two optimizer steps against the reference's losses / digests (procedural weights, see golden_util)."""
