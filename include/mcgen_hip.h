@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -115,7 +115,11 @@ typedef struct {
                             * Cout_w.  Forward-only passes: needs pool = 0, no res / gate_x / ocode, tiles inside one image,
                             * one channel tile.  NULL: dense output.                              */
     int32_t ycmap_stride;
-    int32_t reserved_;
+    int32_t y_group;       /* > 0: y holds 2 N images in PAIRED layout -- output image n is stored in image slot
+                            * (n / y_group) * 2 * y_group + y_group + n % y_group, i.e. the second half of the
+                            * (n / y_group)-th [real (+) generated] batch of 2 * y_group images that a paired discriminator
+                            * update reads (train_gan.py:143-147: D(real), D(G(z)) on the same labels); the first halves are
+                            * the caller's.  The image head (form 5) only; every other form requires 0.             */
     const float* bias2;    /* [Cout] or NULL: added to `bias` (a fused shortcut segment's own bias: the sum is formed in
                             * fp32 before it meets the accumulator, as bias + bias2 on the host would be)   */
 } mcgen_conv_t;
@@ -240,6 +244,10 @@ int mcgen_mc_cmap(const float* code, int N, int C, int16_t* cmap, void* stream);
 
 /* layout / dtype conversion at the module boundary (the reference works on NCHW fp32) */
 int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+/* out[r][i][m] = (label[i] == m) for r < reps: F.one_hot(label, classes).float() (mcgan.py:196,201) written `reps` times back to
+ * back -- the indicator of a paired discriminator batch (2 N rows) and of the grouped generator pass (d_iters * N rows) are
+ * prefixes of one such buffer.  Labels outside [0, classes) fail the launch's precondition (the row stays all zero). */
+int mcgen_onehot_rep(const int64_t* label, float* out, int N, int classes, int reps, void* stream);
 int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 /* y[N, Ho, Wo, C] = 2x2 sums of x[N, 2 Ho, 2 Wo, C] (NHWC, C a multiple of 8): the adjoint of the nearest x2 upsample.
  * The generator's shortcut conv1x1(Up(x)) (mcgan.py:26-30,42) commutes with the upsample, so its weight gradient and
@@ -419,7 +427,7 @@ int mcgen_copy_channels(const void* src, int Cps, int s0, void* dst, int Cpd, in
 
 /* every split-K reduction of one backward pass in one launch (the per-layer mcgen_wgrad_reduce calls, batched);
  * slab size is derived from (Cin, ksize, Cout_w) as in mcgen_wgrad_slab_elems */
-#define MCGEN_WREDUCE_MAX 16
+#define MCGEN_WREDUCE_MAX 32
 typedef struct {
     const float* slabs;       /* [splits][slab_elems]                       */
     float*       grad;        /* [Cout][Cin][k][k] master layout             */

@@ -2632,6 +2632,11 @@ extern "C" int mcgen_conv_form(const mcgen_conv_t* p, int dtype) {
 
 extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) {
     if (int rc = validate(p)) return rc;
+    if (p->y_group != 0) {
+        MCGEN_CHECK(mcgen_conv_head_ok(p, dtype), "conv_fused: the paired output layout (y_group) is built for the image head only "
+                    "(bf16, one 3x3 segment to <= 8 channels of pitch 8 on 32x32 maps, N %% y_group == 0)");
+        return mcgen_conv_head(p, reinterpret_cast<hipStream_t>(stream));
+    }
     if (p->w_layout == 1) return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
     if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");

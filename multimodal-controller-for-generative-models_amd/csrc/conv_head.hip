@@ -111,7 +111,9 @@ void conv_head_kernel(const mcgen_conv_t p) {
             bs[r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
             if (p.bias2 && co < p.Cout) bs[r] += p.bias2[co];
         }
-        bf16_t* y = reinterpret_cast<bf16_t*>(p.y) + ((size_t)(n * HD_W + h0 + wv) * HD_W) * p.Cy + 4 * lg;
+        // paired output layout (mcgen_conv_t.y_group): the second half of the (n / y_group)-th batch of 2 * y_group images
+        const int ny = p.y_group > 0 ? (n / p.y_group) * 2 * p.y_group + p.y_group + n % p.y_group : n;
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y) + ((size_t)(ny * HD_W + h0 + wv) * HD_W) * p.Cy + 4 * lg;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             union { bf16_t h[4]; uint2 w; } o;
@@ -136,6 +138,7 @@ int mcgen_conv_head_ok(const mcgen_conv_t* p, int dtype) {
     if (p->H != HD_W || p->W != HD_W || p->Cout > 8 || p->Cout_w != 16 || p->Cy != 8) return 0;
     if (p->pool || p->res || p->ocode || p->gate_x || p->stats_mode || p->ycmap) return 0;
     if ((long)p->N * HD_W * HD_W * g.C >= (1L << 31)) return 0;          // (32-bit element offsets)
+    if (p->y_group < 0 || (p->y_group > 0 && p->N % p->y_group)) return 0;
     return 1;
 }
 

@@ -10,7 +10,7 @@ int mcgen_fail(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mcgen_last_error(void) { return g_err; }
-extern "C" int mcgen_abi_version(void) { return 8; }
+extern "C" int mcgen_abi_version(void) { return 9; }
 
 namespace {
 
@@ -1060,6 +1060,21 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
     if (dtype == MCGEN_F32) { CALL_F32; } else if (dtype == MCGEN_BF16) { CALL_BF16; } \
     else return mcgen_fail("unknown dtype %d", dtype)
 
+namespace {
+__global__ void onehot_rep_kernel(const int64_t* __restrict__ label, float* __restrict__ out, int n, int classes, int reps) {
+    const int per = n * classes, total = per * reps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i % per, row = e / classes, m = e - row * classes;
+        out[i] = (label[row] == (int64_t)m) ? 1.f : 0.f;
+    }
+}
+}  // namespace
+extern "C" int mcgen_onehot_rep(const int64_t* label, float* out, int N, int classes, int reps, void* stream) {
+    MCGEN_CHECK(label && out && N > 0 && classes > 0 && reps > 0 && (long)N * classes * reps < (1L << 31), "onehot_rep: bad arguments");
+    const int total = N * classes * reps;
+    hipLaunchKernelGGL(onehot_rep_kernel, dim3(grid_for((size_t)total, 256, 256)), dim3(256), 0, STREAM(stream), label, out, N, classes, reps);
+    MCGEN_LAUNCH_CHECK("onehot_rep"); return 0;
+}
 extern "C" int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream) {
     MCGEN_CHECK(src && dst && Cp >= C && Cp % 8 == 0, "nchw_to_nhwc: bad arguments");
     const size_t total = (size_t)N * H * W * Cp;

@@ -331,14 +331,18 @@ class GeneratorEngine:
         shapes.append((side, head_conv.out_channels))
         return all(gn % ops.tile_images(n_total, sd, sd, co, self.dtype) == 0 for sd, co in shapes)
 
-    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1, nhwc: bool = False, one_hot: bool = False):
+    def forward(self, z: Tensor, indicator: Tensor, train: bool, groups: int = 1, nhwc: bool = False, one_hot: bool = False,
+                pair_out: Optional[Tensor] = None):
         """`groups` > 1 (training mode, forward only): z / indicator hold `groups` batches back to back, each normalised
         with its OWN BatchNorm batch statistics -- `groups` successive generator forwards on unchanged weights
         (the five discriminator updates of train_gan.py:139-158) as one pass over groups * N images.
         `nhwc`: return the images as `Nhwc` (for the discriminator engine) instead of NCHW fp32.
         `one_hot`: the caller guarantees `indicator` rows are one-hot (the trainer builds them with F.one_hot); only then
         may a grouped pass keep its activations compacted -- the compacted pitch is the largest active-channel count of a
-        single codebook row (`_cap`), which a soft or multi-hot indicator could exceed."""
+        single codebook row (`_cap`), which a soft or multi-hot indicator could exceed.
+        `pair_out` ([groups * 2 * (N / groups), H, W, 8] in the compute dtype: GANTrainer.pair_buffers): the images go
+        into the second halves of its `groups` paired [real (+) generated] batches -- written there by the image head itself
+        (mcgen_conv_t.y_group) when the launch qualifies, by one strided copy otherwise."""
         self.flat_p.ensure()
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype
@@ -415,9 +419,26 @@ class GeneratorEngine:
         bnh = _bn_forward(head_bn, st, ng * s * s, train, fold, groups)
         codeh = codes[-1]
         seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True, group_n=gn)
-        out, _ = ops.conv_fused([seg_h], self.img['head'], head_conv.out_channels, bias=head_conv.bias, tanh=True)
+        cimg = head_conv.out_channels
+        if pair_out is not None:
+            if tuple(pair_out.shape) != (2 * n, x.shape[1], x.shape[2], ops.pad8(cimg)) or pair_out.dtype != dt:
+                raise McgenError(f'pair_out must be {(2 * n, x.shape[1], x.shape[2], ops.pad8(cimg))} {dt}')
+            # what mcgen_conv_head_ok asks for (conv_head.hip): the paired layout is the image head's
+            direct = (dt == torch.bfloat16 and x.shape[1] == 32 and x.shape[2] == 32 and cimg <= 8 and x.shape[-1] % 32 == 0
+                      and x.shape[-1] >= 64 and n * 32 * 32 * x.shape[-1] < (1 << 31))
+            if direct:
+                ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True, out=pair_out, y_group=ng)
+                out = None
+            else:
+                out, _ = ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True)
+                pv = pair_out.view(groups, 2 * ng, *pair_out.shape[1:])
+                pv[:, ng:].copy_(out.view(groups, ng, *out.shape[1:]))
+        else:
+            out, _ = ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
         _flush_counters()
+        if pair_out is not None:
+            return None, ctx
         return (Nhwc(out, head_conv.out_channels) if nhwc else ops.to_nchw(out, head_conv.out_channels)), ctx
 
     # ---- backward ----------------------------------------------------------------------------------

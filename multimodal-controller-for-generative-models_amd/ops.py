@@ -256,6 +256,18 @@ def cmap_stride(c: int) -> int:
     return int(_lib.load().mcgen_cmap_stride(c))
 
 
+def onehot_rep(label: Tensor, classes: int, reps: int, out: Optional[Tensor] = None) -> Tensor:
+    """[reps * N, classes] fp32: F.one_hot(label, classes).float() (mcgan.py:196,201) `reps` times back to back, one launch."""
+    n = label.shape[0]
+    if label.dtype != torch.int64 or not label.is_cuda:
+        raise _lib.McgenError('onehot_rep: int64 labels on the GPU')
+    if out is None:
+        out = torch.empty((reps * n, classes), dtype=torch.float32, device=label.device)
+    assert tuple(out.shape) == (reps * n, classes) and out.dtype == torch.float32 and out.is_contiguous()
+    check(_lib.load().mcgen_onehot_rep(_p(label.contiguous()), _f32(out), n, classes, reps, _stream()), 'onehot_rep')
+    return out
+
+
 def mc_cmap(code: Tensor) -> Tensor:
     """Per-sample compaction map of a code tensor [N, C] (mcgen_mc_cmap): int16 [N, cmap_stride(C)]."""
     n, c = code.shape
@@ -317,11 +329,14 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
                gscale: Optional[Tensor] = None, gshift: Optional[Tensor] = None,
                gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
                tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
-               out: Optional[Tensor] = None, kmajor: int = 0, ycmap: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               out: Optional[Tensor] = None, kmajor: int = 0, ycmap: Optional[Tensor] = None,
+               y_group: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
     """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None).  `kmajor`: `wimg` is the K-major image
     (prep_weight_k, segments concatenated); 1: every segment carries a compaction map and is compacted while staged;
     2: segments hold ALREADY compacted channels (Seg.cw, cmap) or are dense.  `ycmap` (+ `cy` = compacted pitch): the
-    output keeps, per image, only the channels of that map, compacted (forward-only passes)."""
+    output keeps, per image, only the channels of that map, compacted (forward-only passes).  `y_group` (image head only):
+    `out` holds 2 N images and output image n lands in slot (n // y_group) * 2 * y_group + y_group + n % y_group -- the
+    second halves of N / y_group paired [real (+) generated] batches (mcgen_conv_t.y_group)."""
     s0 = segs[0]
     n = s0.x.shape[0]
     h = s0.x.shape[1] * (2 if s0.ups else 1)
@@ -347,7 +362,11 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     if wimg.numel() != need:
         raise _lib.McgenError(f'weight image has {wimg.numel()} elements, the segments need {need}')
     y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=dtype, device=s0.x.device)
-    assert tuple(y.shape) == (n, ho, wo, cy) and y.dtype == dtype
+    if y_group:
+        if out is None or tuple(y.shape) != (2 * n, ho, wo, cy) or y.dtype != dtype or not y.is_contiguous():
+            raise _lib.McgenError(f'y_group: `out` must be a contiguous {(2 * n, ho, wo, cy)} {dtype} buffer')
+    else:
+        assert tuple(y.shape) == (n, ho, wo, cy) and y.dtype == dtype
     p.w, p.bias, p.y = _p(wimg), _f32(bias), _p(y)
     p.bias2 = _f32(bias2)
     p.N, p.H, p.W = n, h, w
@@ -362,6 +381,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     p.gscale, p.gshift, p.gmean, p.grstd = _f32(gscale), _f32(gshift), _f32(gmean), _f32(grstd)
     p.tanh_out, p.stats_mode = int(tanh), stats_mode
     p.w_layout = int(kmajor)
+    p.y_group = int(y_group)
     p.ycmap, p.ycmap_stride = None, 0
     if ycmap is not None:
         if ycmap.dtype != torch.int16 or tuple(ycmap.shape) != (n, cmap_stride(pad8(cout))):

@@ -33,6 +33,7 @@ _NHWC_PAIR = _flag('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images s
 _PAIR_D = _flag('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
 _GROUP_G = _flag('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
 _FUSE_D_ADAM = _flag('MCGEN_FUSE_D_ADAM', '1') != '0'     # single rank: spectral-norm gradient fix + Adam of a paired D update in one launch
+_ONE_GRAPH = _flag('MCGEN_ONE_GRAPH', '1') != '0'        # single rank: the whole loop body as one HIP graph (0: one graph per phase, as a multi-rank run)
 
 
 class FusedAdam:
@@ -226,30 +227,51 @@ class GANTrainer:
             return self.d_iters
         return 1
 
-    def g_fakes(self, ind_rep, z_cat, groups: int, nhwc: bool = False):
+    def g_fakes(self, ind_rep, z_cat, groups: int, nhwc: bool = False, pair_out: Optional[torch.Tensor] = None):
         """Training-mode generator forward(s) for `groups` discriminator updates: [groups * N, C, H, W], detached
-        (`nhwc`: as the engines' own `Nhwc`, for `pair_buffer`)."""
-        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups, nhwc=nhwc, one_hot=True)   # ind_rep comes from F.one_hot
+        (`nhwc`: as the engines' own `Nhwc`, for `pair_buffers`).  `pair_out` (the buffer of `pair_buffers`): the generated
+        batches are written straight into the second halves of its `groups` paired 2N batches and nothing is returned."""
+        fake, _ = self.geng.forward(z_cat, ind_rep, True, groups=groups, nhwc=nhwc, one_hot=True, pair_out=pair_out)   # ind_rep comes from F.one_hot
         return fake
 
     # The real batch is the same for the d_iters updates of an iteration and the generated batches come out of the generator
-    # engine in the discriminator engine's layout: the 2N batch of a paired update is assembled in that layout -- real half
-    # converted once per iteration, fake half one device copy per update (instead of slice copy + cat + conversion per update).
-    def pair_buffer(self, img: torch.Tensor):
-        """-> `Nhwc` [2N, H, W, 8] whose first half holds `img` (NCHW fp32), converted now."""
+    # engine in the discriminator engine's layout: the 2N batches of the paired updates are assembled in that layout -- one
+    # buffer of `groups` [real (+) generated] batches; the real half is converted once per iteration and replicated, the
+    # generated halves are written in place by the generator's image head (mcgen_conv_t.y_group): no copy per update.
+    def pair_buffers(self, img: torch.Tensor, groups: int = 1):
+        """-> (buffer [groups * 2N, H, W, 8], [`Nhwc` view of paired batch j]) with `img` (NCHW fp32) in every first half."""
         n, c, h, w = img.shape
         dt = self.deng.dtype
-        shape = (2 * n, h, w, ops.pad8(c))
+        shape = (groups * 2 * n, h, w, ops.pad8(c))
         buf = getattr(self, '_x2', None)
         if buf is None or tuple(buf.shape) != shape or buf.dtype != dt or buf.device != img.device:
             buf = self._x2 = torch.empty(shape, dtype=dt, device=img.device)
         ops.to_nhwc(img.detach().contiguous(), dt, out=buf[:n])
-        return Nhwc(buf, c)
+        if groups > 1:
+            v = buf.view(groups, 2 * n, h, w, shape[-1])
+            v[1:, :n].copy_(v[0, :n].unsqueeze(0).expand(groups - 1, -1, -1, -1, -1))
+        return buf, [Nhwc(buf[j * 2 * n:(j + 1) * 2 * n], c) for j in range(groups)]
+
+    def pair_buffer(self, img: torch.Tensor):
+        """-> `Nhwc` [2N, H, W, 8] whose first half holds `img` (NCHW fp32), converted now (one paired batch)."""
+        return self.pair_buffers(img, 1)[1][0]
 
     @staticmethod
     def pair_set_fake(x2: 'Nhwc', fakes: 'Nhwc', j: int):
         n = x2.t.shape[0] // 2
         x2.t[n:].copy_(fakes.t[j * n:(j + 1) * n])
+
+    def indicators(self, label: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None):
+        """F.one_hot(label, classes).float() (mcgan.py:196,201) max(2, groups) times back to back, ONE launch: the
+        indicator of the batch, of the paired 2N batch and of the grouped generator pass are prefixes of it.
+        -> (ind [N], ind2 [2N], ind_rep [groups * N])"""
+        n = label.shape[0]
+        reps = max(2, groups)
+        if label.is_cuda:
+            allr = ops.onehot_rep(label, self.classes, reps, out=out)
+        else:
+            allr = F.one_hot(label, self.classes).float().repeat(reps, 1)
+        return allr[:n], allr[:2 * n], allr[:groups * n]
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
@@ -327,24 +349,21 @@ class GANTrainer:
         last D and G update, as the reference logs them (train_gan.py:177)."""
         self.model.train(True)
         n = img.shape[0]
-        ind2 = F.one_hot(label, self.classes).float().repeat(2, 1)
-        ind = ind2[:n]
         zi = iter(zs) if zs is not None else None
         draw = (lambda: next(zi)) if zi is not None else (lambda: torch.randn(n, self.latent, device=img.device))
         d_loss = g_loss = None
         fg = self.fake_groups(n)
-        ind_rep = ind.repeat(fg, 1) if fg > 1 else ind
+        ind, ind2, ind_rep = self.indicators(label, fg)
         fakes = None
-        x2 = self.pair_buffer(img) if _NHWC_PAIR else None
+        xbuf, x2s = self.pair_buffers(img, fg) if _NHWC_PAIR else (None, None)
         codes = self.deng.pair_codes(ind2) if (_NHWC_PAIR and _PAIR_D) else None     # the labels' codes: once for the d_iters updates
         for k in range(self.d_iters):
             if k % fg == 0:
                 z_cat = torch.cat([draw() for _ in range(fg)]) if fg > 1 else draw()
-                fakes = self.g_fakes(ind_rep, z_cat, fg, nhwc=_NHWC_PAIR)
+                fakes = self.g_fakes(ind_rep, z_cat, fg, nhwc=_NHWC_PAIR, pair_out=xbuf)
             j = k % fg
             if _NHWC_PAIR:
-                self.pair_set_fake(x2, fakes, j)
-                d_loss = self.d_update(None, ind, None, ind2, x2=x2, codes=codes)
+                d_loss = self.d_update(None, ind, None, ind2, x2=x2s[j], codes=codes)
             else:
                 d_loss = self.d_update(img, ind, fakes[j * n:(j + 1) * n], ind2)
         for _ in range(self.g_iters):
@@ -417,12 +436,14 @@ class GraphedGANTrainer(GANTrainer):
         fg = self.fake_groups(n)
         self._fg = fg
         self.s_img = img.clone()
-        self.s_ind2 = F.one_hot(label, self.classes).float().repeat(2, 1)
-        self.s_ind = self.s_ind2[:n]
-        self.s_indg = self.s_ind.repeat(fg, 1) if fg > 1 else self.s_ind     # indicator of the generator pass(es)
+        self.s_label = label.clone()
+        self.s_indall = torch.empty((max(2, fg) * n, self.classes), dtype=torch.float32, device=dev)
+        # indicator of the batch / of the paired 2N batch / of the generator pass(es): prefixes of one buffer
+        self.s_ind, self.s_ind2, self.s_indg = self.indicators(self.s_label, fg, out=self.s_indall)
         self.s_z = torch.randn(n, self.latent, device=dev)                  # latent of the generator update
         self.s_zd = torch.randn(fg * n, self.latent, device=dev)            # latents of fg discriminator updates
-        self.s_x2 = self.pair_buffer(self.s_img) if _NHWC_PAIR else None    # real (+) the generated batch of the current D update
+        # real (+) generated batches of the fg discriminator updates that share a generator pass
+        self.s_xbuf, self.s_x2s = self.pair_buffers(self.s_img, fg) if _NHWC_PAIR else (None, None)
         self.s_fake = None if _NHWC_PAIR else torch.empty_like(self.s_img)
         self.model.train(True)
         snap = self._snapshot()
@@ -430,10 +451,9 @@ class GraphedGANTrainer(GANTrainer):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
+                fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR, pair_out=self.s_xbuf)
                 if _NHWC_PAIR:
-                    self.pair_set_fake(self.s_x2, fakes, 0)
-                    self.d_update(None, self.s_ind, None, self.s_ind2, x2=self.s_x2,
+                    self.d_update(None, self.s_ind, None, self.s_ind2, x2=self.s_x2s[0],
                                   codes=self.deng.pair_codes(self.s_ind2) if _PAIR_D else None)
                 else:
                     self.s_fake.copy_(fakes[:n])
@@ -444,13 +464,47 @@ class GraphedGANTrainer(GANTrainer):
         self._restore(snap)
         torch.cuda.synchronize()
         G = torch.cuda.CUDAGraph
-        self.g_zd, self.g_gf, self.g_z = G(), G(), G()
-        self.g_da, self.g_ga = G(), G()
-        with torch.cuda.graph(self.g_gf, capture_error_mode=_CAPTURE_MODE):
-            self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR)
+
+        def generator_pass():
+            """The iteration's inputs in the engines' layouts, then the fg generator forwards of the D updates."""
+            self.indicators(self.s_label, fg, out=self.s_indall)
             if _NHWC_PAIR:
-                self.pair_buffer(self.s_img)                                # the iteration's real batch -> first half of s_x2
+                self.pair_buffers(self.s_img, fg)                            # the real batch -> every first half of s_xbuf
                 self.s_codes = self.deng.pair_codes(self.s_ind2) if _PAIR_D else None
+            self.s_fakes = self.g_fakes(self.s_indg, self.s_zd, fg, nhwc=_NHWC_PAIR, pair_out=self.s_xbuf)
+
+        def d_iter(j):
+            if _NHWC_PAIR:
+                return self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2s[j], codes=self.s_codes, fuse=_FUSE_D_ADAM)
+            return self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2, fuse=_FUSE_D_ADAM)
+
+        self.g_all = None
+        if self.world == 1 and _ONE_GRAPH and fg == self.d_iters and self.g_iters == 1:
+            # Single rank: nothing sits between the replays (no collective), so the whole loop body is ONE graph -- input
+            # staging, the 5 N generator pass, the d_iters discriminator updates (compute, fused fix + Adam) and the
+            # generator update -- behind a small graph that redraws the latents (kept apart so that a parity run can inject
+            # them).  The ~15 graph launches per iteration of the bucketed form cost ~8.5 us of idle device time each.
+            self.g_draw, self.g_all = G(), G()
+            with torch.cuda.graph(self.g_all, capture_error_mode=_CAPTURE_MODE):
+                generator_pass()
+                for k in range(self.d_iters):
+                    if not _NHWC_PAIR:
+                        self.s_fake.copy_(self.s_fakes[k * n:(k + 1) * n])
+                    for _ in d_iter(k):
+                        pass
+                    self.d_apply()
+                for _ in self.g_compute_iter(self.s_ind, self.s_z):
+                    pass
+                self.g_apply()
+            with torch.cuda.graph(self.g_draw, pool=self.g_all.pool(), capture_error_mode=_CAPTURE_MODE):
+                self.s_zd.normal_()
+                self.s_z.normal_()
+            self._graphs = True
+            self._hyper_key = (self.opt_g.hyper(), self.opt_d.hyper())
+            return
+        self.g_zd, self.g_gf, self.g_z, self.g_ga = G(), G(), G(), G()
+        with torch.cuda.graph(self.g_gf, capture_error_mode=_CAPTURE_MODE):
+            generator_pass()
         pool = self.g_gf.pool()
 
         def capture_buckets(gen):
@@ -464,14 +518,19 @@ class GraphedGANTrainer(GANTrainer):
                     lo, hi, last = next(gen)
                 graphs.append((gk, (lo, hi)))
             return graphs
-        self.g_dc = capture_buckets(self.d_compute_iter(None, self.s_ind, None, self.s_ind2, x2=self.s_x2, codes=self.s_codes, fuse=_FUSE_D_ADAM)
-                                    if _NHWC_PAIR else self.d_compute_iter(self.s_img, self.s_ind, self.s_fake, self.s_ind2, fuse=_FUSE_D_ADAM))
+        # one set of compute graphs per paired batch of the generator pass (each reads its own slot of s_xbuf)
+        # (the apply graph of a set is captured right behind it: a fused single-rank update reads that set's raw gradients)
+        self.g_dc, self.g_da = [], []
+        for j in range(fg if _NHWC_PAIR else 1):
+            self.g_dc.append(capture_buckets(d_iter(j)))
+            ga = G()
+            with torch.cuda.graph(ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                self.d_apply()
+            self.g_da.append(ga)
         with torch.cuda.graph(self.g_zd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_zd.normal_()
         with torch.cuda.graph(self.g_z, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.s_z.normal_()
-        with torch.cuda.graph(self.g_da, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self.d_apply()
         self.g_gc = capture_buckets(self.g_compute_iter(self.s_ind, self.s_z))
         with torch.cuda.graph(self.g_ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.g_apply()
@@ -486,16 +545,22 @@ class GraphedGANTrainer(GANTrainer):
         if self._graphs is None:
             return super().train_iteration(img, label, zs)
         if self._hyper_key != (self.opt_g.hyper(), self.opt_d.hyper()):
-            # lr / betas / eps changed since the capture (a scheduler step, a resumed optimizer state): the apply graphs
-            # hold the old values as kernel arguments -- capture again (state is snapshotted and restored around it)
+            # betas / eps / weight decay changed since the capture (a resumed optimizer state): the apply graphs hold the
+            # old values as kernel arguments -- capture again (state is snapshotted and restored around it).  The learning
+            # rate is read from device memory when the kernels run: a scheduler step needs no re-capture.
             self.capture(img, label)
         self.s_img.copy_(img, non_blocking=True)
-        oh = F.one_hot(label, self.classes).float()
-        n, fg = oh.shape[0], self._fg
-        self.s_ind2[:n].copy_(oh, non_blocking=True); self.s_ind2[n:].copy_(oh, non_blocking=True)
-        if fg > 1:
-            self.s_indg.view(fg, n, -1).copy_(oh.unsqueeze(0).expand(fg, -1, -1), non_blocking=True)
+        self.s_label.copy_(label, non_blocking=True)
+        n, fg = img.shape[0], self._fg
         zi = iter(zs) if zs is not None else None
+        if self.g_all is not None:
+            if zi is None:
+                self.g_draw.replay()
+            else:
+                self.s_zd.copy_(torch.cat([next(zi) for _ in range(fg)]) if fg > 1 else next(zi), non_blocking=True)
+                self.s_z.copy_(next(zi), non_blocking=True)
+            self.g_all.replay()
+            return self.loss_d, self.loss_g
         for k in range(self.d_iters):
             if k % fg == 0:
                 if zi is None:
@@ -504,15 +569,14 @@ class GraphedGANTrainer(GANTrainer):
                     self.s_zd.copy_(torch.cat([next(zi) for _ in range(fg)]) if fg > 1 else next(zi), non_blocking=True)
                 self.g_gf.replay()
             j = k % fg
-            if _NHWC_PAIR:
-                self.pair_set_fake(self.s_x2, self.s_fakes, j)
-            else:
+            if not _NHWC_PAIR:
                 self.s_fake.copy_(self.s_fakes[j * n:(j + 1) * n], non_blocking=True)
-            for gk, (lo, hi) in self.g_dc:
+            js = j if _NHWC_PAIR else 0
+            for gk, (lo, hi) in self.g_dc[js]:
                 gk.replay()
                 self._reduce_bucket(self.grad_d, lo, hi)
             self._join_comm()
-            self.g_da.replay()
+            self.g_da[js].replay()
         for _ in range(self.g_iters):
             if zi is None:
                 self.g_z.replay()

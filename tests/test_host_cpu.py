@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.mcgen_abi_version() == 8
+    assert lib.mcgen_abi_version() == 9
     # struct sizes agree with the C side: weight image size query is pure host code
     assert lib.mcgen_weight_image_elems(128, 3, 3, 0) == 1 * 9 * 128 * 32
     assert lib.mcgen_weight_image_elems(128, 3, 3, 1) == 4 * 9 * 16 * 32
