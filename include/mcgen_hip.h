@@ -364,6 +364,16 @@ int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, const float* 
  * by ratio[0] (= sigma_1 / sigma_2 of the tail layer, which the second half's pooled features carry). */
 int mcgen_dtail_pair_wgrad(const float* dlogit, const float* pooled, const float* ratio, int N, int C,
                            float* dw1, float* db1, float* dw2, float* db2, void* stream);
+/* The tail's forward, the hinge loss's derivative and the tail's input gradient in ONE launch (a workgroup per sample):
+ * mcgen_dtail_fwd, then dlogit[n] from the sample's own logit -- mode 0: hinge_d over a paired batch (train_gan.py:154; samples
+ * [0, N/2) real: -1/(N/2) where 1 - logit > 0; [N/2, N) generated: +1/(N/2) where 1 + logit > 0), mode 1: hinge_g
+ * (train_gan.py:172; -1/N) -- then dx as mcgen_dtail_bwd writes it.  The loss value is mcgen_dtail_pair_wgrad_loss's /
+ * mcgen_hinge_g's to add.  C a multiple of 8, at most 2048. */
+int mcgen_dtail_hinge_fused(const void* x, int dtype, const float* code, const float* w, const float* b, const float* sigma,
+                            float* pooled, float* logit, float* dlogit, void* dx, int N, int HW, int C, int mode, void* stream);
+/* mcgen_dtail_pair_wgrad + the discriminator's hinge loss value from the 2N logits (mean relu(1 - real) + mean relu(1 + generated)) */
+int mcgen_dtail_pair_wgrad_loss(const float* dlogit, const float* pooled, const float* ratio, const float* logit, int N, int C,
+                                float* dw1, float* db1, float* dw2, float* db2, float* loss, void* stream);
 
 /* Hinge losses (train_gan.py:154,172).  d: loss = mean relu(1-real) + mean relu(1+fake);
  * g: loss = -mean(fake).  Writes the loss and d(loss)/d(logit). */

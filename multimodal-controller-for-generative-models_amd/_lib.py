@@ -190,6 +190,8 @@ SYMBOLS = {
     'mcgen_dtail_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_dtail_bwd': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_dtail_pair_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_dtail_pair_wgrad_loss': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mcgen_dtail_hinge_fused': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'mcgen_hinge_g': (_i, [_vp, _i, _vp, _vp, _vp]),
     'mcgen_tanh_bwd': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),

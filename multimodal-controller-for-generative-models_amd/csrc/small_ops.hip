@@ -890,6 +890,75 @@ void dtail_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ cod
     part = block_sum(part, red);
     if (threadIdx.x == 0) logit[n] = part + b[0];
 }
+// dtail_fwd_vec + the hinge loss's derivative + dtail_bwd_dx in ONE launch (a discriminator update used to run four
+// ~5 us launches here): the sample's logit decides its own d(loss)/d(logit) -- hinge_d (train_gan.py:154, paired batch:
+// samples [0, N/2) real, [N/2, N) generated): -1/(N/2) where 1 - logit > 0, +1/(N/2) where 1 + logit > 0; hinge_g
+// (train_gan.py:172): -1/N -- so the input gradient of the tail (mcgan.py:158-165: ReLU -> MC -> sum pool -> SN linear)
+// follows in the same workgroup.  The loss VALUE needs every sample: mcgen_dtail_pair_wgrad_loss / mcgen_hinge_g add it.
+template <typename T>
+__global__ __launch_bounds__(256)
+void dtail_fused_kernel(const T* __restrict__ x, const float* __restrict__ code, const float* __restrict__ w,
+                        const float* __restrict__ b, const float* __restrict__ sigma, float* pooled, float* logit,
+                        float* dlogit, T* __restrict__ dx, int N, int HW, int C, int mode) {
+    extern __shared__ float acc[];                       // [pixel lanes][C]
+    __shared__ float red[32];
+    __shared__ float s_dl;
+    const int n = blockIdx.x, cv = C / 8, pl = 256 / cv;
+    const int g = threadIdx.x % cv, lanep = threadIdx.x / cv;
+    if (lanep < pl) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int p = lanep; p < HW; p += pl) {
+            float v[8];
+            Elem<T>::load8(x + ((size_t)n * HW + p) * C + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += fmaxf(v[i], 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[lanep * C + g * 8 + i] = s[i];
+    }
+    __syncthreads();
+    const float isg = 1.f / sigma[0];
+    float part = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int l = 0; l < pl; ++l) t += acc[l * C + c];
+        t *= code ? code[(size_t)n * C + c] : 1.f;
+        pooled[(size_t)n * C + c] = t;
+        part = fmaf(t, w[c] / sigma[0], part);
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) {
+        const float lg = part + b[0];
+        logit[n] = lg;
+        float dl;
+        if (mode == 0) {
+            const int h = N / 2;
+            dl = (n < h) ? ((1.f - lg) > 0.f ? -1.f / (float)h : 0.f) : ((1.f + lg) > 0.f ? 1.f / (float)h : 0.f);
+        } else dl = -1.f / (float)N;
+        dlogit[n] = dl;
+        s_dl = dl;
+    }
+    __syncthreads();
+    const float dl = s_dl;
+    if (lanep < pl) {
+        // g[c] = dlogit * w[c] / sigma * code[n][c], exactly dtail_bwd_dx_kernel's product order
+        float gc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = g * 8 + i;
+            gc[i] = dl * w[c] * isg * (code ? code[(size_t)n * C + c] : 1.f);
+        }
+        for (int p = lanep; p < HW; p += pl) {
+            float v[8], o[8];
+            Elem<T>::load8(x + ((size_t)n * HW + p) * C + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = v[i] > 0.f ? gc[i] : 0.f;
+            Elem<T>::store8(dx + ((size_t)n * HW + p) * C + g * 8, o);
+        }
+    }
+}
 template <typename T>
 __global__ void dtail_bwd_dx_kernel(const float* __restrict__ dlogit, const T* __restrict__ x, const float* __restrict__ code,
                                     const float* __restrict__ w, const float* __restrict__ sigma, T* __restrict__ dx,
@@ -1427,8 +1496,22 @@ extern "C" int mcgen_dtail_bwd(const float* dlogit, const void* x, int dtype, co
 // half); the second half's pooled features carry sigma_1 / sigma_2, which `ratio` divides out of its weight gradient.
 __global__ __launch_bounds__(256)
 void dtail_pair_w_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled, const float* __restrict__ ratio,
-                         float* dw1, float* db1, float* dw2, float* db2, int N, int C) {
+                         float* dw1, float* db1, float* dw2, float* db2, int N, int C,
+                         const float* __restrict__ logit = nullptr, float* loss = nullptr) {
     __shared__ float sh[4][64];
+    if (loss && blockIdx.x == gridDim.x - 1) {
+        // the extra block of a launch that also owes the hinge loss (train_gan.py:154): hinge_d_kernel's sums, same order
+        if (blockIdx.y == 0) {
+            float* red = &sh[0][0];
+            const float* real = logit; const float* fake = logit + N;
+            float a = 0.f, f = 0.f;
+            for (int i = threadIdx.x; i < N; i += blockDim.x) { a += fmaxf(1.f - real[i], 0.f); f += fmaxf(1.f + fake[i], 0.f); }
+            a = block_sum(a, red); f = block_sum(f, red + 32);
+            const float inv = 1.f / (float)N;
+            if (threadIdx.x == 0) loss[0] = a * inv + f * inv;
+        }
+        return;
+    }
     const int half = blockIdx.y;
     const float* dl = dlogit + (size_t)half * N;
     const float* pl = pooled + (size_t)half * N * C;
@@ -1462,6 +1545,24 @@ extern "C" int mcgen_dtail_pair_wgrad(const float* dlogit, const float* pooled, 
     MCGEN_LAUNCH_CHECK("dtail_pair_wgrad"); return 0;
 }
 
+extern "C" int mcgen_dtail_pair_wgrad_loss(const float* dlogit, const float* pooled, const float* ratio, const float* logit, int N, int C,
+                                           float* dw1, float* db1, float* dw2, float* db2, float* loss, void* stream) {
+    MCGEN_CHECK(dlogit && pooled && ratio && logit && dw1 && db1 && dw2 && db2 && loss && N > 0 && C > 0, "dtail_pair_wgrad_loss: bad arguments");
+    hipLaunchKernelGGL(dtail_pair_w_kernel, dim3((C + 63) / 64 + 1, 2), dim3(256), 0, STREAM(stream), dlogit, pooled, ratio, dw1, db1, dw2, db2, N, C, logit, loss);
+    MCGEN_LAUNCH_CHECK("dtail_pair_wgrad_loss"); return 0;
+}
+extern "C" int mcgen_dtail_hinge_fused(const void* x, int dtype, const float* code, const float* w, const float* b, const float* sigma,
+                                       float* pooled, float* logit, float* dlogit, void* dx, int N, int HW, int C, int mode, void* stream) {
+    MCGEN_CHECK(x && w && b && sigma && pooled && logit && dlogit && dx && N > 0 && HW > 0, "dtail_hinge_fused: bad arguments");
+    MCGEN_CHECK(C % 8 == 0 && C / 8 <= 256, "dtail_hinge_fused: C must be a multiple of 8, at most 2048");
+    MCGEN_CHECK(mode == 1 || (mode == 0 && N % 2 == 0), "dtail_hinge_fused: mode 0 (hinge_d over a paired batch, N even) or 1 (hinge_g)");
+    const int pl = 256 / (C / 8);
+    const size_t lds = (size_t)pl * C * sizeof(float);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(dtail_fused_kernel<float>, dim3(N), dim3(256), lds, STREAM(stream), (const float*)x, code, w, b, sigma, pooled, logit, dlogit, (float*)dx, N, HW, C, mode),
+        hipLaunchKernelGGL(dtail_fused_kernel<bf16_t>, dim3(N), dim3(256), lds, STREAM(stream), (const bf16_t*)x, code, w, b, sigma, pooled, logit, dlogit, (bf16_t*)dx, N, HW, C, mode));
+    MCGEN_LAUNCH_CHECK("dtail_hinge_fused"); return 0;
+}
 extern "C" int mcgen_hinge_d(const float* real, const float* fake, int N, float* loss, float* dreal, float* dfake, void* stream) {
     MCGEN_CHECK(real && fake && loss && dreal && dfake && N > 0, "hinge_d: bad arguments");
     hipLaunchKernelGGL(hinge_d_kernel, dim3(1), dim3(256), 0, STREAM(stream), real, fake, N, loss, dreal, dfake);

@@ -690,11 +690,14 @@ class DiscriminatorEngine:
     def _power_iter(self, train: bool):
         return self._power_iters(1, train)[0]
 
-    def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool):
+    def forward(self, x_nchw: Tensor, indicator: Tensor, train: bool, tail_loss: Optional[str] = None):
+        """`tail_loss` 'g' (the generator update, train_gan.py:172): the tail's launch also forms d(hinge_g)/d(logit) and the
+        tail's input gradient (ops.dtail_hinge_fused); ctx['tail'] = (dlogit, d tail input) is what `backward_iter` then
+        starts from -- pass ctx['tail'][0] as its dlogit."""
         sigma, uv = self._power_iter(train)
         codes = self._codes.run(indicator)
         ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None, 'train': train}
-        return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None)
+        return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None, tail_loss)
 
     def pair_codes(self, ind2: Tensor):
         """The UNSCALED MultimodalController codes of a paired pass ([2N, C] per MC: what the weight gradients multiply their
@@ -702,14 +705,16 @@ class DiscriminatorEngine:
         return self._codes.run(ind2)
 
     def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None,
-                     x2: Optional[Nhwc] = None, codes=None):
+                     x2: Optional[Nhwc] = None, codes=None, tail_loss: Optional[str] = None):
         """D(real) and D(fake) of one discriminator update (train_gan.py:144-150) as ONE pass over the 2N batch.
         The two forwards of the reference differ only in the spectral-norm state (each runs its own power iteration,
         which depends on the weights alone): conv(x; W / sigma_2) = (sigma_1 / sigma_2) * conv(x; W / sigma_1), so the
         fake half runs on the first pass's weight images with sigma_1 / sigma_2 folded into its per-sample
         MultimodalController codes (the prologue multiply sits after the ReLU, i.e. directly on the conv input).
         `x2` (optional, then real / fake are ignored): the 2N batch real (+) fake already in the engine's layout.
-        `codes` (optional): `pair_codes(ind2)`, computed once for several updates on the same labels."""
+        `codes` (optional): `pair_codes(ind2)`, computed once for several updates on the same labels.
+        `tail_loss` 'd_pair': the tail's launch also forms d(hinge_d)/d(logit) of the 2N batch and the tail's input gradient
+        (ctx['tail']); `backward_iter` writes the loss value into ctx['loss'] (train_gan.py:154)."""
         n = x2.shape[0] // 2 if x2 is not None else real_nchw.shape[0]
         (sigma1, uv1), (sigma2, uv2) = self._power_iters(2, True)
         ratio = self._sn_ratio if getattr(self, '_sn_ratio', None) is not None else sigma1 / sigma2
@@ -733,7 +738,7 @@ class DiscriminatorEngine:
         x = x2 if x2 is not None else torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
-        return self._forward_body(x, ctx, lambda mc_i, sn_idx: scaled[(mc_i, sn_idx)])
+        return self._forward_body(x, ctx, lambda mc_i, sn_idx: scaled[(mc_i, sn_idx)], tail_loss)
 
     def _code_uses(self):
         """(MC index or None for the image, SN layer index) of every convolution input of the network."""
@@ -751,7 +756,7 @@ class DiscriminatorEngine:
             self._use_idx = {}
         return self._uses
 
-    def _forward_body(self, x_nchw: Tensor, ctx, code_of):
+    def _forward_body(self, x_nchw: Tensor, ctx, code_of, tail_loss: Optional[str] = None):
         dt = self.dtype
         n = x_nchw.shape[0]
         sigma = ctx['sigma']
@@ -803,8 +808,18 @@ class DiscriminatorEngine:
         # --- tail: ReLU -> MC -> global sum pool -> SN linear (mcgan.py:158-165)
         tl = self.sn_of[self.tail_lin]
         codet = code_of(len(self._codes.mcs) - 1, tl.idx)
-        logit, pooled_feat = ops.dtail_fwd(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
-                                           sigma[tl.idx:tl.idx + 1])
+        if tail_loss is not None and ops.dtail_hinge_ok(x):
+            if (tail_loss == 'd_pair') != (ctx['pair'] is not None):
+                raise McgenError("tail_loss: 'd_pair' goes with forward_pair, 'g' with forward")
+            logit, pooled_feat, dlogit, dxt = ops.dtail_hinge_fused(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
+                                                                    sigma[tl.idx:tl.idx + 1], tail_loss)
+            ctx['tail'] = (dlogit, dxt)
+            if tail_loss == 'd_pair':
+                ctx['loss'] = torch.empty(1, dtype=torch.float32, device=x.device)
+                ctx['logit'] = logit
+        else:
+            logit, pooled_feat = ops.dtail_fwd(x, codet, self.tail_lin.weight_orig.detach().view(-1), self.tail_lin.bias,
+                                               sigma[tl.idx:tl.idx + 1])
         ctx.update(xt=x, codet=codet, pooled=pooled_feat)
         return logit.view(n, 1), ctx
 
@@ -917,18 +932,27 @@ class DiscriminatorEngine:
         red = ops.deferred_reduces()           # the split-K reductions of one bucket: one launch, before its SN fix-up
         red.__enter__()
         try:
+            # a forward that ran the fused tail already holds the tail's input gradient for ITS dlogit (ctx['tail'])
+            tail = ctx.get('tail')
+            pre_dy = tail[1] if (tail is not None and dlogit is tail[0]) else None
             if pair is None:
                 gt = passes[0][1]
-                dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
-                                   self.flat_p.view_of(gt, wl).view(-1) if want_w else None,
-                                   self.flat_p.view_of(gt, self.tail_lin.bias) if want_w else None)
+                if pre_dy is not None and not want_w:
+                    dy = pre_dy
+                else:
+                    dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'],
+                                       self.flat_p.view_of(gt, wl).view(-1) if want_w else None,
+                                       self.flat_p.view_of(gt, self.tail_lin.bias) if want_w else None)
             else:
-                dy = ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'], None, None)
+                dy = pre_dy if pre_dy is not None else \
+                    ops.dtail_bwd(dlogit, ctx['xt'], ctx['codet'], wl.detach().view(-1), sg_t, ctx['pooled'], None, None)
                 # tail weight / bias gradients per half; the fake half's pooled features carry sigma_1 / sigma_2
                 (_, g_a), (_, g_b) = passes
+                with_loss = pre_dy is not None and 'loss' in ctx
                 ops.dtail_pair_wgrad(dlogit, ctx['pooled'], pair['ratio'][tl.idx:tl.idx + 1],
                                      self.flat_p.view_of(g_a, wl).view(-1), self.flat_p.view_of(g_a, self.tail_lin.bias).view(-1),
-                                     self.flat_p.view_of(g_b, wl).view(-1), self.flat_p.view_of(g_b, self.tail_lin.bias).view(-1))
+                                     self.flat_p.view_of(g_b, wl).view(-1), self.flat_p.view_of(g_b, self.tail_lin.bias).view(-1),
+                                     logit=ctx['logit'] if with_loss else None, loss=ctx['loss'] if with_loss else None)
             for bi in reversed(range(1, len(self.res))):
                 b, bc = self.res[bi], ctx['blocks'][bi]
                 x, c1, code1, code2, pooled, has_sc = bc['x'], bc['c1'], bc['code1'], bc['code2'], bc['pooled'], bc['has_sc']

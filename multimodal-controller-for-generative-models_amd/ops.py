@@ -766,12 +766,39 @@ def dtail_bwd(dlogit: Tensor, x: Tensor, code, w, sigma, pooled, dw: Optional[Te
     return dx
 
 
-def dtail_pair_wgrad(dlogit: Tensor, pooled: Tensor, ratio: Tensor, dw1: Tensor, db1: Tensor, dw2: Tensor, db2: Tensor):
-    """Tail weight / bias gradients of the two halves of a paired discriminator pass (dw2 divided by ratio[0])."""
+def dtail_hinge_ok(x: Tensor) -> bool:
+    c = x.shape[-1]
+    return c % 8 == 0 and c <= 2048
+
+
+def dtail_hinge_fused(x: Tensor, code: Optional[Tensor], w: Tensor, b: Tensor, sigma: Tensor, mode: str):
+    """Tail forward + d(hinge loss)/d(logit) + tail input gradient in one launch (mcgen_dtail_hinge_fused).
+    mode 'd_pair': x is a paired batch (real half, generated half), hinge_d; 'g': hinge_g.
+    -> (logit [N], pooled [N, C], dlogit [N], dx like x)"""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    pooled = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    both = torch.empty((2, n), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check(_lib.load().mcgen_dtail_hinge_fused(_p(x), _dt(x.dtype), _f32(code), _f32(w), _f32(b), _f32(sigma), _f32(pooled),
+                                              both[0].data_ptr(), both[1].data_ptr(), _p(dx), n, hw, c,
+                                              {'d_pair': 0, 'g': 1}[mode], _stream()), 'dtail_hinge_fused')
+    return both[0], pooled, both[1], dx
+
+
+def dtail_pair_wgrad(dlogit: Tensor, pooled: Tensor, ratio: Tensor, dw1: Tensor, db1: Tensor, dw2: Tensor, db2: Tensor,
+                     logit: Optional[Tensor] = None, loss: Optional[Tensor] = None):
+    """Tail weight / bias gradients of the two halves of a paired discriminator pass (dw2 divided by ratio[0]); with
+    `logit` [2N] and `loss` [1] the launch also writes the discriminator's hinge loss (train_gan.py:154)."""
     n2, c = pooled.shape
     for t in (dw1, db1, dw2, db2):
         if not t.is_contiguous() or t.dtype != torch.float32:
             raise _lib.McgenError('dtail_pair_wgrad: outputs must be contiguous fp32')
+    if loss is not None:
+        check(_lib.load().mcgen_dtail_pair_wgrad_loss(_f32(dlogit), _f32(pooled), _f32(ratio), _f32(logit.contiguous()), n2 // 2, c,
+                                                      _f32(dw1), _f32(db1), _f32(dw2), _f32(db2), _f32(loss), _stream()),
+              'dtail_pair_wgrad_loss')
+        return
     check(_lib.load().mcgen_dtail_pair_wgrad(_f32(dlogit), _f32(pooled), _f32(ratio), n2 // 2, c,
                                              _f32(dw1), _f32(db1), _f32(dw2), _f32(db2), _stream()), 'dtail_pair_wgrad')
 

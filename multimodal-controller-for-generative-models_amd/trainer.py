@@ -33,6 +33,7 @@ _NHWC_PAIR = _flag('MCGEN_NHWC_PAIR', '1') != '0'    # engine-to-engine images s
 _PAIR_D = _flag('MCGEN_PAIR_D', '1') != '0'      # real + fake discriminator passes batched (see d_compute)
 _GROUP_G = _flag('MCGEN_GROUP_G', '1') != '0'    # the d_iters generator forwards of an iteration as one pass (fake_groups)
 _FUSE_D_ADAM = _flag('MCGEN_FUSE_D_ADAM', '1') != '0'     # single rank: spectral-norm gradient fix + Adam of a paired D update in one launch
+_FUSE_TAIL = _flag('MCGEN_FUSE_TAIL', '1') != '0'        # D tail forward + hinge derivative + tail input gradient in one launch
 _ONE_GRAPH = _flag('MCGEN_ONE_GRAPH', '1') != '0'        # single rank: the whole loop body as one HIP graph (0: one graph per phase, as a multi-rank run)
 
 
@@ -285,10 +286,15 @@ class GANTrainer:
         if _PAIR_D:
             # D(real) and D(fake) as one pass over the 2N batch (DiscriminatorEngine.forward_pair): the spectral-norm
             # power iterations of the two reference forwards depend on the weights alone and run first, in order
-            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2, x2=x2, codes=codes)
+            logits, ctx = self.deng.forward_pair(img, fake, ind, ind2, x2=x2, codes=codes, tail_loss='d_pair' if _FUSE_TAIL else None)
             n = ind.shape[0]
             lg = logits.view(-1)
-            self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
+            if 'tail' in ctx:
+                # the tail's launch formed d(hinge_d)/d(logit) and the tail's input gradient; the loss value comes out of the
+                # backward pass's tail-gradient launch (two launches where there were four)
+                self.loss_d, dboth = ctx['loss'][0], ctx['tail'][0]
+            else:
+                self.loss_d, _, _, dboth = ops.hinge_d(lg[:n], lg[n:], both=True)      # d(real) and d(fake) side by side
             # `fuse` (single rank): the raw per-half gradients stay as they are -- d_apply turns them into the update in one
             # fused launch per layer table (spectral-norm fix + Adam) and self.grad_d is not written
             yield from self.deng.backward_iter(ctx, dboth, self.grad_d, False, False, split=self.world > 1,
@@ -315,8 +321,10 @@ class GANTrainer:
 
     def g_compute_iter(self, ind, z):
         fake, gctx = self.geng.forward(z, ind, True, nhwc=_NHWC_PAIR)  # (engine to engine: images and their gradient stay NHWC)
-        d_fake, dctx = self.deng.forward(fake, ind, True)
+        d_fake, dctx = self.deng.forward(fake, ind, True, tail_loss='g' if _FUSE_TAIL else None)
         self.loss_g, dfake = ops.hinge_g(d_fake.view(-1))
+        if 'tail' in dctx:
+            dfake = dctx['tail'][0]                      # (the same values; the tail's input gradient exists already)
         dimg = self.deng.backward(dctx, dfake, None, False, True)
         yield from self.geng.backward_iter(gctx, dimg, self.grad_g, False, split=self.world > 1)
 

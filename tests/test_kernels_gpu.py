@@ -286,6 +286,47 @@ def test_wgrad(case, dtype):
     _assert_close(bg2 - 3.0, 0.25 * dyf.sum((0, 2, 3)), dtype, 'fused bias grad (second output)')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('mode', ['d_pair', 'g'])
+def test_fused_tail_equals_the_separate_launches(dtype, mode):
+    """mcgen_dtail_hinge_fused (tail forward + d hinge / d logit + tail input gradient, mcgan.py:158-165 with
+    train_gan.py:154 / :172) against the three launches it replaces -- bit for bit -- and against plain torch; the loss
+    value that mcgen_dtail_pair_wgrad_loss adds equals mcgen_hinge_d's."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(53)
+    n2, c, hw = 48, 128, 8
+    x = _rnd(g, n2, c, hw, hw)
+    code = (torch.rand(n2, c, generator=g) < 0.5).float() * 1.25
+    w, b, sigma = _rnd(g, c) * 0.2, _rnd(g, 1), torch.tensor([1.7])
+    xt = _nhwc(ops, x, dtype)
+    logit0, pooled0 = ops.dtail_fwd(xt, code.cuda(), w.cuda(), b.cuda(), sigma.cuda())
+    if mode == 'd_pair':
+        loss0, _, _, dl0 = ops.hinge_d(logit0[:n2 // 2], logit0[n2 // 2:], both=True)
+    else:
+        loss0, dl0 = ops.hinge_g(logit0)
+    dx0 = ops.dtail_bwd(dl0.contiguous(), xt, code.cuda(), w.cuda(), sigma.cuda(), pooled0, None, None)
+    logit, pooled, dl, dx = ops.dtail_hinge_fused(xt, code.cuda(), w.cuda(), b.cuda(), sigma.cuda(), mode)
+    assert torch.equal(logit, logit0) and torch.equal(pooled, pooled0) and torch.equal(dl, dl0.contiguous()) and torch.equal(dx, dx0)
+    # against torch: pooled = code * sum relu(x); logit = pooled . w / sigma + b
+    xq = _q(x, dtype)
+    pref = torch.relu(xq).sum((2, 3)) * code
+    np.testing.assert_allclose(pooled.cpu().numpy(), pref.numpy(), rtol=2e-5, atol=2e-4)
+    lref = pref @ (w / sigma) + b
+    np.testing.assert_allclose(logit.cpu().numpy(), lref.numpy(), rtol=1e-4, atol=1e-4)
+    assert float(dx.float().abs().max()) > 0
+    if mode == 'd_pair':
+        outs = [torch.empty(c, device='cuda'), torch.empty(1, device='cuda'), torch.empty(c, device='cuda'), torch.empty(1, device='cuda')]
+        ref_outs = [torch.empty_like(t) for t in outs]
+        ratio = torch.tensor([1.25]).cuda()
+        loss = torch.full((1,), -1.0, device='cuda')
+        ops.dtail_pair_wgrad(dl, pooled, ratio, *outs, logit=logit, loss=loss)
+        ops.dtail_pair_wgrad(dl, pooled, ratio, *ref_outs)
+        assert all(torch.equal(a, r) for a, r in zip(outs, ref_outs))
+        assert torch.equal(loss[0], loss0)
+        href = torch.relu(1 - lref[:n2 // 2]).mean() + torch.relu(1 + lref[n2 // 2:]).mean()
+        assert abs(float(loss) - float(href)) < 1e-4
+
+
 def test_dtail_pair_wgrad_and_hinge_both():
     """Paired discriminator pass: tail weight / bias gradients of both halves in one launch (the second half divided by
     sigma_1 / sigma_2), and the hinge gradients as one [2N] tensor."""
