@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument); 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -157,6 +157,13 @@ typedef struct {
 
 int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p);          /* floats per split */
 int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream);
+/* 1 when mcgen_wgrad runs `p` on the image-layer kernel (wgrad_c8.hip: bf16, conv input = the 8-channel image tensor without
+ * prologue, 32x32 maps, 128 output channels, 3x3 or 1x1 -- FirstDisResBlock's convolution and shortcut, mcgan.py:76-86): a
+ * stream over dy with all 128 output channels per workgroup; it wants about two workgroups per CU (`splits` ~ 512, at most
+ * the number of 128-pixel steps) where the general kernels want ~128.  Its slabs are COMPACT ((tap, ci) pairs as the columns of
+ * a 1x1-shaped slab, mcgen_wgrad_c8_slab_elems floats per split): reduce them with tapcols = 1. */
+int mcgen_wgrad_c8_ok(const mcgen_wgrad_t* p, int dtype);
+int64_t mcgen_wgrad_c8_slab_elems(const mcgen_wgrad_t* p);      /* floats per split of those compact slabs: the stride between splits */
 /* The weight gradients of up to MCGEN_WGRAD_MULTI_MAX 3x3 layers of ONE backward pass in one launch (wgrad_multi.hip:
  * 128 co x 64 ci x 9 tap workgroup tiles, one accumulator set per workgroup): same operands, slab layout and `splits` /
  * `halves` meaning as mcgen_wgrad per layer, so mcgen_wgrad_reduce(_batch) finishes either.  The caller gives each layer
@@ -174,7 +181,9 @@ int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, void* strea
 int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
                        int Cout_w, int row_perm, float alpha, int accumulate,
                        const float* bias_slabs, float* bias_grad, float* bias_grad2,
-                       const float* row_scale /* optional [Cout] */, int cin_slab /* 0 = Cin */, void* stream);
+                       const float* row_scale /* optional [Cout] */, int cin_slab /* 0 = Cin */,
+                       int tapcols /* 1: the compact slabs of mcgen_wgrad_c8_ok layers: [chunk][Cout_w][32], column tap * 8 + ci */,
+                       void* stream);
 /* bias_slabs/bias_grad (optional): bias_grad[Cout] (+)= alpha * sum_s bias_slabs[s] (same row_perm);
  * bias_grad2 receives the same values (a second conv that shares dy, e.g. the 1x1 shortcut). */
 
@@ -448,7 +457,8 @@ typedef struct {
     float   alpha;
     const float* row_scale;   /* optional [Cout]: grad row co is scaled by row_scale[co] (output-side factors such as
                                * ActNorm's scale or ZeroConv2d's exp(3*scale) that follow the convolution)     */
-    int32_t cin_slab, _pad;   /* channel count the slabs were built for (the padded activation); 0 = Cin        */
+    int32_t cin_slab;         /* channel count the slabs were built for (the padded activation); 0 = Cin        */
+    int32_t tapcols;          /* 1: compact slabs of an image-layer launch (mcgen_wgrad_c8_ok): (tap, ci) pairs are columns */
 } mcgen_wreduce_t;
 int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void* stream);
 

@@ -19,6 +19,11 @@ int mcgen_conv_c8(const mcgen_conv_t* p, hipStream_t st);
 int mcgen_conv_head_ok(const mcgen_conv_t* p, int dtype);
 int mcgen_conv_head(const mcgen_conv_t* p, hipStream_t st);
 
+// wgrad_c8.hip: weight gradients of 3x3 / 1x1 convolutions whose input is the 8-channel image tensor (bf16, 32x32, 128 outputs)
+extern "C" int mcgen_wgrad_c8_ok(const mcgen_wgrad_t* p, int dtype);
+int mcgen_wgrad_c8(const mcgen_wgrad_t* p, hipStream_t st);
+extern "C" int64_t mcgen_wgrad_c8_slab_elems(const mcgen_wgrad_t* p);      // compact slabs: (tap, channel) pairs as columns
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     typedef bf16x8 frag;

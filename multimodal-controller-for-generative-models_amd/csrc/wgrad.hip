@@ -777,34 +777,55 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     }
 }
 
-// Sums the split slabs in slab order (coalesced 16-byte reads, 4 splits in flight) and scatters into
-// the master layout.
+// Sums the split slabs in a FIXED order and scatters into the master layout.  A weight-gradient launch with many splits (the
+// image-layer kernel: 256 per half) used to be the reduce launch's long pole -- one thread per element vector walked every
+// split, four loads in flight.  Now SL = 1, 2, 4, 8 or 16 adjacent lanes share an element vector: lane sl sums the splits
+// z = sl, sl + SL, ... in ascending order (groups of four independent loads), the lanes meet by a fixed xor butterfly and
+// lane 0 writes.  The order depends on `splits` alone: run-to-run bit-identical.
+__device__ __forceinline__ int reduce_lanes(int splits) {
+    return splits <= 8 ? 1 : splits <= 16 ? 2 : splits <= 32 ? 4 : splits <= 64 ? 8 : 16;
+}
 __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int splits, size_t slab_elems,
                                            float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                            int row_perm, float alpha, int accumulate,
                                            const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
-                                           const float* __restrict__ row_scale) {
+                                           const float* __restrict__ row_scale, int tapcols = 0) {
+    // tapcols (the image-layer kernel's compact slabs, wgrad_c8.hip): a slab is [chunk][Cout_w][32] and column tap * 8 + ci holds
+    // (tap, ci) -- the taps are columns, not a slab dimension
     const int ntap = KS * KS;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int stap = tapcols ? 1 : ntap;
+    const int SL = reduce_lanes(splits);
+    const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x / SL;
+    const int sl = (int)(gtid % SL);
     const int Cc = row_perm > 1 ? Cout / row_perm : Cout;
     const size_t nvec = slab_elems / 4;
-    for (size_t e4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e4 < nvec; e4 += stride) {
+    // (every lane of a vector's group runs the same trip count: the butterfly below needs all of them)
+    for (size_t e4 = gtid / SL; e4 < nvec; e4 += stride) {
         const size_t e = e4 * 4;
         const int cl = (int)(e % MCGEN_CK); size_t t = e / MCGEN_CK;
         const int co = (int)(t % Cout_w); t /= Cout_w;
-        const int tap = (int)(t % ntap); const int q = (int)(t / ntap);
-        const int ci = q * MCGEN_CK + cl;
-        if (co >= Cout || ci >= Cin) continue;
+        const int col = (int)(t / stap) * MCGEN_CK + cl;
+        const int tap = tapcols ? (col >> 3) : (int)(t % stap);
+        const int ci = tapcols ? (col & 7) : col;
+        const bool live = co < Cout && ci < Cin && tap < ntap;     // (uniform over the group: it depends on e4 alone)
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 4 <= splits; z += 4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 0) * slab_elems + e);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 1) * slab_elems + e);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 2) * slab_elems + e);
-            const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 3) * slab_elems + e);
-            s += (a0 + a1) + (a2 + a3);
+        if (live) {
+            int z = sl;
+            for (; z + 3 * SL < splits; z += 4 * SL) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 0 * SL) * slab_elems + e);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 1 * SL) * slab_elems + e);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 2 * SL) * slab_elems + e);
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(z + 3 * SL) * slab_elems + e);
+                s += (a0 + a1) + (a2 + a3);
+            }
+            for (; z < splits; z += SL) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_elems + e);
         }
-        for (; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_elems + e);
+        for (int o = 1; o < SL; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], o);
+        }
+        if (!live || sl != 0) continue;
         const int com = row_perm > 1 ? (co % Cc) * row_perm + co / Cc : co;      // image row -> master row
         const float ra = row_scale ? alpha * row_scale[com] : alpha;
 #pragma unroll
@@ -835,19 +856,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
                                     float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                     int row_perm, float alpha, int accumulate,
                                     const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
-                                    const float* __restrict__ row_scale) {
-    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2, row_scale);
+                                    const float* __restrict__ row_scale, int tapcols) {
+    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2, row_scale, tapcols);
+}
+// floats per split of a reduce job's slabs
+static __host__ __device__ inline size_t reduce_slab_elems(int Cin, int cin_slab, int ksize, int Cout_w, int tapcols) {
+    if (tapcols) return (size_t)((ksize * ksize * 8 + MCGEN_CK - 1) / MCGEN_CK) * Cout_w * MCGEN_CK;
+    const int cs = cin_slab > 0 ? cin_slab : Cin;
+    const int nchunk = ((cs + 7) / 8 * 8 + MCGEN_CK - 1) / MCGEN_CK;
+    return (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
 }
 // All reductions of one backward pass in ONE launch: blockIdx.y picks the job, the job table travels by value
 // in the kernel arguments (graph-capture safe: no host table to keep alive).
 struct ReduceJobs { mcgen_wreduce_t j[MCGEN_WREDUCE_MAX]; };
 __global__ void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
     const mcgen_wreduce_t& j = jobs.j[blockIdx.y];
-    const int cs = j.cin_slab > 0 ? j.cin_slab : j.Cin;
-    const int nchunk = ((cs + 7) / 8 * 8 + MCGEN_CK - 1) / MCGEN_CK;
-    const size_t slab_elems = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK;
+    const size_t slab_elems = reduce_slab_elems(j.Cin, j.cin_slab, j.ksize, j.Cout_w, j.tapcols);
     reduce_job(j.slabs, j.splits, slab_elems, j.grad, j.Cout, j.Cin, j.ksize, j.Cout_w, j.row_perm, j.alpha, j.accumulate,
-               j.bias_slabs, j.bias_grad, j.bias_grad2, j.row_scale);
+               j.bias_slabs, j.bias_grad, j.bias_grad2, j.row_scale, j.tapcols);
 }
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
@@ -998,6 +1024,7 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
                 "wgrad: halves needs even splits and a whole number of pixel tiles per half");
     MCGEN_CHECK(!p->dy_ups || (p->H >= 2 && p->W >= 2), "wgrad: dy_ups needs H, W >= 2");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mcgen_wgrad_c8_ok(p, dtype)) return mcgen_wgrad_c8(p, st);      // the image-side layers: a stream over dy (wgrad_c8.hip)
     if (dtype == MCGEN_F32) return launch_t<float>(p, st);
     if (dtype == MCGEN_BF16) return launch_t<bf16_t>(p, st);
     return mcgen_fail("wgrad: unknown dtype %d", dtype);
@@ -1006,16 +1033,17 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
 extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
                                   int Cout_w, int row_perm, float alpha, int accumulate,
                                   const float* bias_slabs, float* bias_grad, float* bias_grad2,
-                                  const float* row_scale, int cin_slab, void* stream) {
+                                  const float* row_scale, int cin_slab, int tapcols, void* stream) {
     MCGEN_CHECK(slabs && grad && splits >= 1, "wgrad_reduce: bad arguments");
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
     MCGEN_CHECK(cin_slab == 0 || cin_slab >= Cin, "wgrad_reduce: cin_slab is the (padded) channel count the slabs were built for");
-    const int nchunk = (round_up(cin_slab > 0 ? cin_slab : Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
-    const size_t slab_elems = (size_t)nchunk * ksize * ksize * Cout_w * MCGEN_CK;
-    int blocks = (int)((slab_elems / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    MCGEN_CHECK(!tapcols || (Cin <= 8 && (cin_slab == 0 || cin_slab == 8)), "wgrad_reduce: tapcols slabs hold 8-channel layers");
+    const size_t slab_elems = reduce_slab_elems(Cin, cin_slab, ksize, Cout_w, tapcols);
+    const int sl = splits <= 8 ? 1 : splits <= 16 ? 2 : splits <= 32 ? 4 : splits <= 64 ? 8 : 16;                     // reduce_lanes
+    int blocks = (int)((slab_elems / 4 * sl + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
-                       bias_slabs, bias_grad, bias_grad2, row_scale);
+                       bias_slabs, bias_grad, bias_grad2, row_scale, tapcols);
     MCGEN_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }
@@ -1031,8 +1059,9 @@ extern "C" int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void
             MCGEN_CHECK(j.slabs && j.grad && j.splits > 0 && j.Cout > 0 && j.Cin > 0 && (j.ksize == 1 || j.ksize == 3) && j.Cout_w >= j.Cout,
                         "wgrad_reduce_batch: bad job %d", base + i);
             t.j[i] = j;
-            const int nchunk = (round_up(j.cin_slab > 0 ? j.cin_slab : j.Cin, 8) + MCGEN_CK - 1) / MCGEN_CK;
-            const size_t v4 = (size_t)nchunk * j.ksize * j.ksize * j.Cout_w * MCGEN_CK / 4;
+            MCGEN_CHECK(!j.tapcols || (j.Cin <= 8 && (j.cin_slab == 0 || j.cin_slab == 8)), "wgrad_reduce_batch: job %d: tapcols slabs hold 8-channel layers", base + i);
+            const int sl = j.splits <= 8 ? 1 : j.splits <= 16 ? 2 : j.splits <= 32 ? 4 : j.splits <= 64 ? 8 : 16;   // reduce_lanes
+            const size_t v4 = reduce_slab_elems(j.Cin, j.cin_slab, j.ksize, j.Cout_w, j.tapcols) / 4 * sl;
             if (v4 > most) most = v4;
         }
         for (int i = m; i < MCGEN_WREDUCE_MAX; ++i) t.j[i] = t.j[0];

@@ -445,6 +445,10 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     m_tiles = (n * h * w + 127) // 128
     nchunk = (seg.x.shape[-1] + 31) // 32
     explicit_splits = splits
+    # the image-side layers (conv input = the 8-channel image tensor) have their own kernel and compact slabs (wgrad_c8.hip)
+    c8 = bool(_lib.load().mcgen_wgrad_c8_ok(C.byref(p), _dt(dtype)))
+    if WGRAD_LOG is not None:
+        WGRAD_LOG.append('c8' if c8 else 'general')
     if splits is None:
         # 1x1 gradients with >= 4 chunks run as chunk groups of 4 (wgrad.hip): a quarter of the workgroups per split
         # (wgrad.hip: the ring form -- bf16, tiles inside one image -- comes first; chunk groups are for the small maps)
@@ -455,6 +459,9 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         # 20 % with 16 instead of 64 splits)
         target = _WG_TARGET if m_tiles >= _WG_BIG_TILES else _WG_TARGET_SMALL
         splits = max(1, min(m_tiles, (target + blocks - 1) // blocks, _WG_MAX_SPLITS))
+        if c8:
+            # the image-layer kernel streams dy with every output channel in one workgroup (256-pixel steps): one per CU
+            splits = max(1, min(m_tiles // 2, _cu_count(dy.device)))
         if second is not None:
             splits = max(2, splits + (splits & 1))
     if second is not None and ((n * h * w) % 256 != 0 or splits % 2):
@@ -473,7 +480,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         _deferred.append(_PendingMulti(p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm,
                                        row_scale, m_tiles, (pad16(cout) // 128) * (seg.x.shape[-1] // 64)))
         return
-    elems = int(lib.mcgen_wgrad_slab_elems(C.byref(p)))
+    elems = int(lib.mcgen_wgrad_c8_slab_elems(C.byref(p)) if c8 else lib.mcgen_wgrad_slab_elems(C.byref(p)))
     # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
     # already exist, and nothing reads its slabs before the pass's batched reduce, so it overlaps the
     # input-gradient chain that continues on the main stream.
@@ -506,15 +513,16 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
             if not gr.is_contiguous():
                 raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
             _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha),
-                              row_scale, seg.x.shape[-1]))
+                              row_scale, seg.x.shape[-1], int(c8)))
         else:
             _timed(lambda: 'wgrad_reduce', 0.0,
                    lambda: check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
                                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _f32(row_scale),
-                                                        seg.x.shape[-1], _stream()), 'wgrad_reduce'),
+                                                        seg.x.shape[-1], int(c8), _stream()), 'wgrad_reduce'),
                    lambda: _nbytes(gr), lambda: _nbytes(sl, bs))
 
 
+WGRAD_LOG = None         # tests: a list that receives which weight-gradient kernel family a call with default splits takes
 _deferred = None
 _MULTI = _flag('MCGEN_WGRAD_MULTI', '1') != '0'        # eligible 3x3 weight gradients of a pass as one mcgen_wgrad_multi launch
 _CU_COUNT = {}
@@ -541,7 +549,7 @@ class _PendingMulti:
     def jobs(self):
         """The slab-reduce job(s) of the layer, in deferred_reduces' tuple form."""
         cw, ks, cs = pad16(self.cout), self.seg.ksize, self.seg.x.shape[-1]
-        tail = (self.cout, self.cin, ks, cw, self.row_perm, int(self.accumulate), float(self.alpha), self.row_scale, cs)
+        tail = (self.cout, self.cin, ks, cw, self.row_perm, int(self.accumulate), float(self.alpha), self.row_scale, cs, 0)
         if self.second is None:
             return [(self.slabs, self.grad, self.bias_slabs, self.bias_grad, self.bias_grad2, self.splits) + tail]
         hs = self.splits // 2
@@ -652,12 +660,12 @@ class deferred_reduces:
                 _side_keep.clear()
         if et is None and jobs:
             arr = (_lib.WReduce * len(jobs))()
-            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha, rscale, cin_slab) in zip(arr, jobs):
+            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha, rscale, cin_slab, tapcols) in zip(arr, jobs):
                 a.slabs, a.grad, a.bias_slabs = _p(slabs), _f32(grad), _p(bs)
                 a.bias_grad, a.bias_grad2 = _f32(bg) if bs is not None else None, _f32(bg2) if bs is not None else None
                 a.splits, a.Cout, a.Cin, a.ksize, a.Cout_w = splits, cout, cin, ks, cout_w
                 a.row_perm, a.accumulate, a.alpha = row_perm, acc, alpha
-                a.row_scale, a.cin_slab = _f32(rscale), cin_slab
+                a.row_scale, a.cin_slab, a.tapcols = _f32(rscale), cin_slab, tapcols
             _timed(lambda: 'wgrad_reduce', 0.0,
                    lambda: check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch'),
                    lambda: sum(_nbytes(j[1]) for j in jobs), lambda: sum(_nbytes(j[0], j[2]) for j in jobs))

@@ -865,6 +865,46 @@ def test_big_wgrad_bf16(case):
     _assert_close(bg, dyf.sum((0, 2, 3)), dtype, 'big wgrad bias')
 
 
+@pytest.mark.parametrize('probe', PROBES)
+@pytest.mark.parametrize('n,ks,dy_ups,halves', [(256, 3, False, True), (256, 1, True, True), (128, 3, False, False),
+                                                (128, 1, True, False), (6, 3, False, True), (2, 1, False, False)])
+def test_image_layer_wgrad_bf16(n, ks, dy_ups, halves, probe):
+    """wgrad_c8.hip: the weight / bias gradients of FirstDisResBlock's image-side layers (mcgan.py:76-86: Conv3x3(3, 128) and the
+    1x1 shortcut, whose gradient arrives 2x2-pooled) -- conv input = the raw image (pitch 8, no prologue), 128 outputs, 32x32 --
+    per half of a paired batch, against torch.nn.grad.conv2d_weight on the CPU; run twice: bit-identical."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1801 + n + ks)
+    x = _rnd(g, n, 3, 32, 32)
+    hd = 16 if dy_ups else 32
+    dy = _rnd(g, n, 128, hd, hd) * 0.1
+    if probe:
+        x, dy = _hot(x), _hot(dy, 8.0)
+    xq, dyf = _q(x, dtype), _q(dy, dtype)
+    if dy_ups:
+        dyf = dyf.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    parts = (slice(0, n // 2), slice(n // 2, n)) if halves else (slice(None),)
+    refs = [(torch.nn.grad.conv2d_weight(xq[sl], (128, 3, ks, ks), dyf[sl], padding=ks // 2), dyf[sl].sum((0, 2, 3))) for sl in parts]
+
+    def run():
+        gs = [torch.zeros((128, 3, ks, ks), device='cuda') for _ in parts]
+        bs = [torch.zeros((128,), device='cuda') for _ in parts]
+        ops.WGRAD_LOG = []
+        try:
+            ops.wgrad(ops.Seg(_nhwc(ops, x, dtype), ksize=ks), _nhwc(ops, dy, dtype), 128, 3, gs[0], dy_ups=dy_ups, bias_grad=bs[0],
+                      second=(gs[1], bs[1], None) if halves else None)
+            assert ops.WGRAD_LOG == ['c8'], ops.WGRAD_LOG
+        finally:
+            ops.WGRAD_LOG = None
+        return gs, bs
+    gs, bs = run()
+    for hi, ((gr, br), gt, bt) in enumerate(zip(refs, gs, bs)):
+        _assert_close(gt, gr, dtype, f'image-layer wgrad half {hi}')
+        _assert_close(bt, br, dtype, f'image-layer bias grad half {hi}')
+    gs2, bs2 = run()
+    assert all(torch.equal(a, b) for a, b in zip(gs + bs, gs2 + bs2))
+
+
 def test_big_wgrad_two_halves_bf16():
     """The paired discriminator pass: one launch over 2N images, one slab set (and one gradient) per half."""
     ops = _ops()
