@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument); 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half); 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -271,9 +271,13 @@ typedef struct { const float* codebook; int64_t out_off; int32_t M, C; int32_t s
  * scale[descs[j].scale_idx] (scale_idx < 0 or scale == NULL: no scaling) */
 int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
                         const float* scale, int n_half, void* stream);
-/* the same for one-hot indicators given as int64 labels: code_j[n, :] = codebook_j[label[n], :] (every C a multiple of 4;
- * labels outside 0 .. M-1 are clamped) */
-int mcgen_mc_gather_batch(const int64_t* label, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream);
+/* the same for one-hot indicators given as int64 labels: code_j[n, :] = codebook_j[label[n % n_label], :] (every C a multiple
+ * of 4; labels outside 0 .. M-1 are clamped).  N a multiple of n_label: the label vector repeats (the indicator of a paired
+ * discriminator batch is the batch's twice, of the grouped generator pass d_iters times); scale / n_half as in
+ * mcgen_mc_code_batch.  With one-hot rows this IS indicator @ codebook (modules.py:73) -- a row gather instead of M
+ * multiply-adds per output, which is what COIL100's 100 and Omniglot's 1623 modes need. */
+int mcgen_mc_gather_batch(const int64_t* label, int n_label, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
+                          const float* scale, int n_half, void* stream);
 /* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);

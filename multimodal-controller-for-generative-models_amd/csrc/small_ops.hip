@@ -221,16 +221,19 @@ __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_
 }
 // the same for one-hot indicators given as labels: code_j[n] = codebook_j[label[n]] (one_hot(label) @ codebook exactly,
 // modules.py:73) -- a row gather per MultimodalController, all of them in one launch
-__global__ void mc_gather_batch_kernel(const int64_t* __restrict__ label, const mcgen_code_t* __restrict__ descs,
-                                       float* __restrict__ code_base, int N) {
+__global__ void mc_gather_batch_kernel(const int64_t* __restrict__ label, int n_label, const mcgen_code_t* __restrict__ descs,
+                                       float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
     const mcgen_code_t d = descs[blockIdx.y];
+    const float tail_scale = (scale && d.scale_idx >= 0) ? scale[d.scale_idx] : 1.f;
     const int cv = d.C >> 2;                                // (C a multiple of 4: host check)
     const size_t total = (size_t)N * cv;
     float* code = code_base + d.out_off;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / cv), c = (int)(i % cv) * 4;
-        long m = label[n]; m = m < 0 ? 0 : (m >= d.M ? d.M - 1 : m);
-        *reinterpret_cast<f32x4*>(code + (size_t)n * d.C + c) = *reinterpret_cast<const f32x4*>(d.codebook + (size_t)m * d.C + c);
+        long m = label[n % n_label]; m = m < 0 ? 0 : (m >= d.M ? d.M - 1 : m);
+        f32x4 v = *reinterpret_cast<const f32x4*>(d.codebook + (size_t)m * d.C + c);
+        if (n >= n_half) v *= tail_scale;                   // (mc_code_batch's product order: code * scale)
+        *reinterpret_cast<f32x4*>(code + (size_t)n * d.C + c) = v;
     }
 }
 __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __restrict__ cb, float* __restrict__ code,
@@ -1277,9 +1280,10 @@ extern "C" int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* d
     MCGEN_LAUNCH_CHECK("mc_code_batch"); return 0;
 }
 
-extern "C" int mcgen_mc_gather_batch(const int64_t* label, const mcgen_code_t* descs_dev, int n, float* code_base, int N, void* stream) {
-    MCGEN_CHECK(label && descs_dev && code_base && n > 0 && N > 0, "mc_gather_batch: bad arguments");
-    hipLaunchKernelGGL(mc_gather_batch_kernel, dim3(8, n), dim3(256), 0, STREAM(stream), label, descs_dev, code_base, N);
+extern "C" int mcgen_mc_gather_batch(const int64_t* label, int n_label, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
+                                     const float* scale, int n_half, void* stream) {
+    MCGEN_CHECK(label && descs_dev && code_base && n > 0 && N > 0 && n_label > 0 && N % n_label == 0, "mc_gather_batch: bad arguments (N a multiple of n_label)");
+    hipLaunchKernelGGL(mc_gather_batch_kernel, dim3(8, n), dim3(256), 0, STREAM(stream), label, n_label, descs_dev, code_base, N, scale, scale ? n_half : N);
     MCGEN_LAUNCH_CHECK("mc_gather_batch"); return 0;
 }
 

@@ -362,7 +362,7 @@ class GeneratorEngine:
         fold = 16                              # Linear output column p*C0+c belongs to channel c
         ctx['zt'] = zt
         blocks_ctx = []
-        codes = self._codes.run(indicator)
+        codes = self._codes.run_any(indicator)
         # Forward-only grouped pass: activations between the launches stay COMPACTED -- the producer stores, per image, only
         # the channels the consumer's MultimodalController keeps (ycmap), the consumer gathers the matching weight rows.
         gk = groups > 1 and one_hot and self._gk_enabled()
@@ -695,14 +695,14 @@ class DiscriminatorEngine:
         tail's input gradient (ops.dtail_hinge_fused); ctx['tail'] = (dlogit, d tail input) is what `backward_iter` then
         starts from -- pass ctx['tail'][0] as its dlogit."""
         sigma, uv = self._power_iter(train)
-        codes = self._codes.run(indicator)
+        codes = self._codes.run_any(indicator)
         ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None, 'train': train}
         return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None, tail_loss)
 
     def pair_codes(self, ind2: Tensor):
         """The UNSCALED MultimodalController codes of a paired pass ([2N, C] per MC: what the weight gradients multiply their
         conv inputs with).  They depend on the labels alone, so the d_iters updates of one iteration can share them."""
-        return self._codes.run(ind2)
+        return self._codes.run_any(ind2)
 
     def forward_pair(self, real_nchw: Tensor, fake_nchw: Tensor, indicator: Tensor, ind2: Optional[Tensor] = None,
                      x2: Optional[Nhwc] = None, codes=None, tail_loss: Optional[str] = None):
@@ -731,10 +731,10 @@ class DiscriminatorEngine:
             self._ones_mc = ones
             self._codes_pair = ops.CodeBatch([self._codes.mcs[u[0]] if u[0] is not None else ones for u in uses],
                                              [u[1] for u in uses])
-        outs = self._codes_pair.run(ind2, ratio, n)            # all scaled codes of the pass: one launch
+        outs = self._codes_pair.run_any(ind2, ratio, n)            # all scaled codes of the pass: one launch
         scaled = dict(zip(uses, outs))
         if codes is None:
-            codes = self._codes.run(ind2)                      # unscaled [2N, C] codes: the weight gradients' conv inputs
+            codes = self._codes.run_any(ind2)                      # unscaled [2N, C] codes: the weight gradients' conv inputs
         x = x2 if x2 is not None else torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}

@@ -268,6 +268,13 @@ def onehot_rep(label: Tensor, classes: int, reps: int, out: Optional[Tensor] = N
     return out
 
 
+def onehot_hint(indicator: Tensor, label: Tensor, reps: int = 1) -> Tensor:
+    """Marks `indicator` ([reps * N, modes]) as F.one_hot(label) repeated `reps` times: CodeBatch.run_any then gathers codebook
+    rows by label instead of multiplying through every mode (the tensor is returned; the mark does not survive slicing)."""
+    indicator._mcgen_onehot = (label, int(reps))
+    return indicator
+
+
 def mc_cmap(code: Tensor) -> Tensor:
     """Per-sample compaction map of a code tensor [N, C] (mcgen_mc_cmap): int16 [N, cmap_stride(C)]."""
     n, c = code.shape
@@ -990,22 +997,32 @@ class CodeBatch:
             self._key = key
             self._n_cached = None
 
-    def run_labels(self, label: Tensor):
+    def run_labels(self, label: Tensor, reps: int = 1, scale: Optional[Tensor] = None, n_half: int = 0):
         """The same for one-hot indicators given as int64 labels: code_i = codebook_i[label] (a row gather per module, all in
-        one launch: mcgen_mc_gather_batch)."""
+        one launch: mcgen_mc_gather_batch).  `reps`: the batch is the label vector `reps` times back to back; `scale` /
+        `n_half` as in run()."""
         self._ensure()
-        n = label.shape[0]
+        n = label.shape[0] * reps
         self._tables_for(n, label.device)
         if label.dtype != torch.int64 or any(d.C % 4 for d in self._arr):
             raise _lib.McgenError('run_labels: int64 labels and channel counts that are multiples of 4')
         buf = torch.empty(self._total, dtype=torch.float32, device=label.device)
-        check(_lib.load().mcgen_mc_gather_batch(_p(label.contiguous()), _p(self._table), len(self.mcs), _f32(buf), n, _stream()),
-              'mc_gather_batch')
+        check(_lib.load().mcgen_mc_gather_batch(_p(label.contiguous()), label.shape[0], _p(self._table), len(self.mcs), _f32(buf), n,
+                                                _f32(scale), n_half, _stream()), 'mc_gather_batch')
         out, off = [], 0
         for d in self._arr:
             out.append(buf[off:off + n * d.C].view(n, d.C))
             off += n * d.C
         return out
+
+    def run_any(self, indicator: Tensor, scale: Optional[Tensor] = None, n_half: int = 0):
+        """run(), or run_labels() when the indicator carries its labels (`onehot_hint`): the caller built it with
+        F.one_hot / ops.onehot_rep, so a row gather gives indicator @ codebook exactly."""
+        hint = getattr(indicator, '_mcgen_onehot', None)
+        if hint is not None and hint[0].shape[0] * hint[1] == indicator.shape[0] and hint[0].is_cuda \
+                and all(d.C % 4 == 0 for d in (self._ensure() or self._arr)):
+            return self.run_labels(hint[0], hint[1], scale, n_half)
+        return self.run(indicator, scale, n_half)
 
     def _tables_for(self, n: int, device):
         if self._n_cached != n:

@@ -272,7 +272,9 @@ class GANTrainer:
             allr = ops.onehot_rep(label, self.classes, reps, out=out)
         else:
             allr = F.one_hot(label, self.classes).float().repeat(reps, 1)
-        return allr[:n], allr[:2 * n], allr[:groups * n]
+        # the engines may gather codebook rows by label instead of multiplying through every mode (ops.onehot_hint)
+        return (ops.onehot_hint(allr[:n], label, 1), ops.onehot_hint(allr[:2 * n], label, 2),
+                ops.onehot_hint(allr[:groups * n], label, groups))
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).

@@ -393,6 +393,35 @@ def test_mc_code_and_apply():
     np.testing.assert_allclose(ops.to_nchw(ops.mc_apply(x, soft), 32).cpu().numpy(), d['out_soft'], rtol=1e-6, atol=1e-6)
 
 
+def test_label_gather_equals_indicator_product():
+    """CodeBatch.run_labels (mcgen_mc_gather_batch: codebook rows gathered by label, the label vector repeating `reps` times,
+    the second half of the batch scaled per job) is bit for bit CodeBatch.run on the one-hot indicator (modules.py:73:
+    indicator @ codebook) -- with 100 modes (COIL100) as with 10; run_any picks it when the indicator carries the hint."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+
+    class MC:
+        pass
+    for modes in (10, 100):
+        mcs = []
+        for c in (8, 64, 128, 512):
+            m = MC(); m.codebook = (torch.rand(modes, c, generator=g) < 0.5).float().cuda(); mcs.append(m)
+        n, reps = 24, 2
+        label = torch.randint(0, modes, (n,), generator=g).cuda()
+        ind = F.one_hot(label, modes).float().repeat(reps, 1)
+        scale = (torch.rand(3, generator=g) + 0.5).cuda()
+        cb = ops.CodeBatch(mcs, [0, -1, 2, 1])
+        a = cb.run(ind, scale, n)
+        b = cb.run_labels(label, reps, scale, n)
+        hinted = ops.onehot_hint(ind.clone(), label, reps)
+        c_ = cb.run_any(hinted, scale, n)
+        for x, y, z in zip(a, b, c_):
+            assert torch.equal(x, y) and torch.equal(x, z)
+        assert float((a[0][n:] / a[0][:n].clamp_min(1e-9)).max()) > 1.0 or float(scale[0]) <= 1.0
+        plain = cb.run_any(ind, scale, n)                   # no hint: the product path
+        assert all(torch.equal(x, y) for x, y in zip(a, plain))
+
+
 def test_bn_finalize_and_backward():
     ops = _ops()
     g = torch.Generator().manual_seed(31)

@@ -219,8 +219,10 @@ def test_pixelcnn_bf16_tracks_fp32():
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_mcpixelcnn_full_size_digest(dtype):
     """BASELINE configs[4] as the reference runs it (utils.py:139-143: 15 layers, hidden 128, 512 codes, 10 modes --
-    6,367,616 parameters) on the HIP path against the reference-generated mcpixelcnn_full_digest.npz (procedural weights,
-    B=8): loss, logits digest and sample of the first training forward, then two train_pixelcnn.py steps."""
+    6,367,616 parameters) at its batch 128 on the HIP path against the reference-generated mcpixelcnn_full_digest.npz
+    (procedural weights): loss, logits digest and sample of the first training forward, the digest of EVERY parameter's
+    gradient of that step (autograd through the module surface; the two parameters the reference leaves without a gradient
+    get none here either), then two train_pixelcnn.py steps and digests of final tensors."""
     import ast
     from mcgen_amd import models
     from mcgen_amd.config import cfg
@@ -239,25 +241,47 @@ def test_mcpixelcnn_full_size_digest(dtype):
     assert sum(p.numel() for p in m.parameters()) == 6367616
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
     codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
+    assert codes.shape == (128, 8, 8)
     m.train(True)
-    with torch.no_grad():
-        out = m({'img': codes, 'label': lab})
+    out = m({'img': codes, 'label': lab})
     print('first training-mode loss', float(out['loss']), 'reference', float(d['losses'][0]))
     assert abs(float(out['loss']) - float(d['losses'][0])) < (2e-4 if f32 else 5e-2)
-    lg = out['logits'].float()
-    assert _rel(lg[:, ::16, ::2, ::2], d['logits0_sample']) < (1e-3 if f32 else 6e-2)
+    lg = out['logits'].float().detach()
+    assert _rel(lg[::16, ::16, ::2, ::2], d['logits0_sample']) < (1e-3 if f32 else 6e-2)
     got, ref = gu.checksum(lg.cpu()), d['logits0_digest']
     assert np.abs(got - ref).max() < (1e-3 if f32 else 3e-2) * ref[1], (got, ref)
+    # every parameter gradient of the step against the reference's (sum, sum |.|, ramp-weighted sum) digests
+    out['loss'].backward()
+    named = dict(m.named_parameters())
+    assert set(map(str, d['grad_keys'])) | set(map(str, d['nograd_keys'])) == set(named)
+    worst = (0.0, None)
+    for k in map(str, d['grad_keys']):
+        gp = named[k].grad
+        assert gp is not None, k
+        got, ref = gu.checksum(gp.float().cpu()), d['grad0_digest/' + k]
+        # the digests are sums over the tensor: compare against sum |g| (ref[1]).  A bias in front of a BatchNorm has an
+        # exactly-zero gradient in exact arithmetic: the reference's own value is rounding residue (mean |g| ~ 1e-9 where
+        # the live gradients are 1e-4 .. 1e-2) -- such a tensor only has to stay residue-sized here as well
+        numel = gp.numel()
+        if float(ref[1]) / numel < 1e-7:
+            assert float(got[1]) / numel < (1e-6 if f32 else 1e-4), (k, got, ref)
+            continue
+        err = float(np.abs(got - ref).max()) / float(ref[1])
+        if err > worst[0]:
+            worst = (err, k)
+        assert err < (2e-3 if f32 else 6e-2), (k, got, ref)
+    print('worst gradient digest error (relative to sum |g|):', worst)
+    for k in map(str, d['nograd_keys']):
+        assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
     tr = PixelCNNTrainer(build())
     losses = [float(tr.train_iteration(codes, lab)) for _ in range(2)]
     print('train losses', losses, 'reference', d['losses'])
     assert abs(losses[0] - d['losses'][0]) < (2e-4 if f32 else 5e-2)
-    assert abs(losses[1] - d['losses'][1]) < (2e-2 if f32 else 1.5e-1)
+    assert abs(losses[1] - d['losses'][1]) < (5e-3 if f32 else 1.5e-1)
     if f32:
         fin = tr.model.state_dict()
-        for k in d['final_keys']:
-            name = str(k)[len('final_digest/'):]
-            got, ref = gu.checksum(fin[name].float().cpu()), d[str(k)]
+        for name in map(str, d['final_keys']):
+            got, ref = gu.checksum(fin[name].float().cpu()), d['final_digest/' + name]
             assert np.abs(got - ref).max() < 2e-3 * ref[1], (name, got, ref)
 
 

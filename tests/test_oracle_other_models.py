@@ -101,7 +101,7 @@ def test_mcpixelcnn_small():
 def test_mcpixelcnn_full_size_digest():
     """BASELINE configs[4] at its real size (15 layers, hidden 128, 512 codes: utils.py:139-143): the oracle on the
     procedural weights against the reference-generated mcpixelcnn_full_digest.npz (loss, logits digest + sample of the
-    first training forward; the second loss after one clip + Adam step)."""
+    first training forward at the config's batch 128; the second loss after one clip + Adam step)."""
     import ast
     d = gu.load_npz('mcpixelcnn_full_digest.npz')
     shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(d['shape_keys'], d['shape_vals'])}
@@ -111,7 +111,7 @@ def test_mcpixelcnn_full_size_digest():
     np.testing.assert_allclose(losses[0], d['losses'][0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(losses[1], d['losses'][1], rtol=0, atol=5e-3)
     np.testing.assert_allclose(gu.checksum(first['logits']), d['logits0_digest'], rtol=2e-4, atol=2e-2)
-    _close(first['logits'][:, ::16, ::2, ::2], d['logits0_sample'], rtol=1e-3, atol=1e-3, what='logits sample')
+    _close(first['logits'][::16, ::16, ::2, ::2], d['logits0_sample'], rtol=1e-3, atol=1e-3, what='logits sample')
 
 
 def test_mcglow_small():

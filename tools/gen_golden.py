@@ -584,9 +584,10 @@ def fx_mcglow_full():
 
 def fx_mcpixelcnn_full():
     """BASELINE configs[4] as the reference runs it (utils.py:139-143): MCGatedPixelCNN with 15 layers, hidden 128,
-    512 codes, 10 modes (6,367,616 parameters) on 8x8 code maps; procedural weights (golden_util.
-    procedural_state_generic), B=8: logits digest + loss of the first training forward, two train_pixelcnn.py steps,
-    digests of a few final tensors."""
+    512 codes, 10 modes (6,367,616 parameters) on 8x8 code maps at the config's batch 128; procedural weights
+    (golden_util.procedural_state_generic).  Loss + logits digest of the first training forward, the digest of EVERY
+    parameter's gradient of that step (before clip_grad_norm_), two train_pixelcnn.py steps (losses), digests of a few
+    final tensors -- a key that is absent from the state dict is an error, not a silent skip."""
     import models
     cfg['model_name'] = 'mcpixelcnn'; cfg['device'] = 'cpu'; cfg['classes_size'] = 10; cfg['controller_rate'] = 0.5
     cfg['pixelcnn'] = {'num_layer': 15, 'hidden_size': 128, 'num_embedding': 512}
@@ -599,17 +600,40 @@ def fx_mcpixelcnn_full():
     model.load_state_dict(gu.procedural_state_generic(shapes, seed=4242))
     arrays = {'shape_keys': np.array(keys), 'shape_vals': np.array([str(shapes[k]) for k in keys])}
     g = torch.Generator().manual_seed(43)
-    codes = torch.randint(0, 512, (8, 8, 8), generator=g)
-    lab = torch.randint(0, 10, (8,), generator=g)
+    B = 128
+    codes = torch.randint(0, 512, (B, 8, 8), generator=g)
+    lab = torch.randint(0, 10, (B,), generator=g)
     arrays['codes'] = codes.numpy(); arrays['label'] = lab.numpy()
-    first = _single_opt_steps(model, {'img': codes, 'label': lab}, 300, 2, arrays)
-    arrays['logits0_digest'] = gu.checksum(first['logits'].detach())
-    arrays['logits0_sample'] = first['logits'].detach().numpy()[:, ::16, ::2, ::2].copy()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)                           # train_pixelcnn.py:33,108-121
+    losses = []
+    for step in range(2):
+        opt.zero_grad()
+        out = model({'img': codes.clone(), 'label': lab})
+        out['loss'].backward()
+        if step == 0:
+            arrays['logits0_digest'] = gu.checksum(out['logits'].detach())
+            arrays['logits0_sample'] = out['logits'].detach().numpy()[::16, ::16, ::2, ::2].copy()
+            names, dead = [], []
+            for k, p in model.named_parameters():
+                if p.grad is None:                       # (the last layer's vertical stream feeds nothing: mcpixelcnn.py:56-61)
+                    dead.append(k)
+                    continue
+                names.append(k)
+                arrays['grad0_digest/' + k] = gu.checksum(p.grad)
+                arrays['grad0_absmax/' + k] = np.array(float(p.grad.abs().max()))
+            arrays['grad_keys'] = np.array(names)
+            arrays['nograd_keys'] = np.array(dead)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+        opt.step()
+        losses.append(out['loss'].item())
+    arrays['losses'] = np.array(losses, dtype=np.float64)
     fin = model.state_dict()
-    for k in ['layers.0.vert_stack.weight', 'layers.7.horiz_resid.weight', 'layers.14.gate_h.bn.running_var', 'output_conv.3.weight']:
-        if k in fin:
-            arrays['final_digest/' + k] = gu.checksum(fin[k].float())
-    arrays['final_keys'] = np.array([k for k in arrays if k.startswith('final_digest/')])
+    final = ['layers.0.vert_stack.weight', 'layers.7.horiz_resid.0.module.weight', 'layers.14.gate_h.bn.running_var', 'output_conv.4.module.weight']
+    for k in final:
+        if k not in fin:
+            raise KeyError(f'{k} is not a key of the reference state dict (have e.g. {[x for x in fin if x.startswith(k.split(".")[0])][:8]})')
+        arrays['final_digest/' + k] = gu.checksum(fin[k].float())
+    arrays['final_keys'] = np.array(final)
     save('mcpixelcnn_full_digest.npz', **arrays)
 
 
