@@ -183,7 +183,7 @@ int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, in
                        const float* bias_slabs, float* bias_grad, float* bias_grad2,
                        const float* row_scale /* optional [Cout] */, int cin_slab /* 0 = Cin */,
                        int tapcols /* 1: the compact slabs of mcgen_wgrad_c8_ok layers: [chunk][Cout_w][32], column tap * 8 + ci */,
-                       void* stream);
+                       int tap0, int ntap_out /* as mcgen_wreduce_t; 0, 0: every tap */, void* stream);
 /* bias_slabs/bias_grad (optional): bias_grad[Cout] (+)= alpha * sum_s bias_slabs[s] (same row_perm);
  * bias_grad2 receives the same values (a second conv that shares dy, e.g. the 1x1 shortcut). */
 
@@ -463,6 +463,9 @@ typedef struct {
                                * ActNorm's scale or ZeroConv2d's exp(3*scale) that follow the convolution)     */
     int32_t cin_slab;         /* channel count the slabs were built for (the padded activation); 0 = Cin        */
     int32_t tapcols;          /* 1: compact slabs of an image-layer launch (mcgen_wgrad_c8_ok): (tap, ci) pairs are columns */
+    int32_t tap0, ntap_out;   /* ntap_out > 0: grad is [Cout][Cin][ntap_out] and receives taps tap0 .. tap0 + ntap_out - 1 of the
+                               * k x k slab only -- a (rows x cols) sub-kernel embedded in the 3x3 image, e.g. MCGatedMaskedConv2d's
+                               * (2 x 3) vertical / (1 x 2) horizontal stacks (mcpixelcnn.py:29-35): taps 0-5 / 3-4.  0: all k * k */
 } mcgen_wreduce_t;
 int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void* stream);
 

@@ -44,7 +44,7 @@ class WReduce(C.Structure):
                 ('bias_grad2', C.c_void_p),
                 ('splits', C.c_int32), ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('Cout_w', C.c_int32),
                 ('row_perm', C.c_int32), ('accumulate', C.c_int32), ('alpha', C.c_float),
-                ('row_scale', C.c_void_p), ('cin_slab', C.c_int32), ('tapcols', C.c_int32)]
+                ('row_scale', C.c_void_p), ('cin_slab', C.c_int32), ('tapcols', C.c_int32), ('tap0', C.c_int32), ('ntap_out', C.c_int32)]
 
 
 class PrepEx(C.Structure):
@@ -122,7 +122,7 @@ SYMBOLS = {
     'mcgen_wgrad_c8_ok': (_i, [_vp, _i]),
     'mcgen_wgrad_c8_slab_elems': (_i64, [_vp]),
     'mcgen_wgrad_multi': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
-    'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     'mcgen_prep_weight_rows': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

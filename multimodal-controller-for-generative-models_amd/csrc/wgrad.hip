@@ -789,11 +789,12 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
                                            float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                            int row_perm, float alpha, int accumulate,
                                            const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
-                                           const float* __restrict__ row_scale, int tapcols = 0) {
+                                           const float* __restrict__ row_scale, int tapcols = 0, int tap0 = 0, int ntap_out = 0) {
     // tapcols (the image-layer kernel's compact slabs, wgrad_c8.hip): a slab is [chunk][Cout_w][32] and column tap * 8 + ci holds
     // (tap, ci) -- the taps are columns, not a slab dimension
     const int ntap = KS * KS;
     const int stap = tapcols ? 1 : ntap;
+    const int nout = ntap_out > 0 ? ntap_out : ntap;              // taps the master-layout gradient holds: [tap0, tap0 + nout)
     const int SL = reduce_lanes(splits);
     const size_t gtid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x / SL;
@@ -808,7 +809,7 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
         const int col = (int)(t / stap) * MCGEN_CK + cl;
         const int tap = tapcols ? (col >> 3) : (int)(t % stap);
         const int ci = tapcols ? (col & 7) : col;
-        const bool live = co < Cout && ci < Cin && tap < ntap;     // (uniform over the group: it depends on e4 alone)
+        const bool live = co < Cout && ci < Cin && tap >= tap0 && tap < tap0 + nout && tap < ntap;     // (uniform over the group: it depends on e4 alone)
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (live) {
             int z = sl;
@@ -831,7 +832,7 @@ __device__ __forceinline__ void reduce_job(const float* __restrict__ slabs, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ci + j >= Cin) break;
-            const size_t i = ((size_t)com * Cin + ci + j) * ntap + tap;
+            const size_t i = ((size_t)com * Cin + ci + j) * nout + (tap - tap0);
             const float v = s[j] * ra;
             grad[i] = accumulate ? grad[i] + v : v;
         }
@@ -856,8 +857,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
                                     float* __restrict__ grad, int Cout, int Cin, int KS, int Cout_w,
                                     int row_perm, float alpha, int accumulate,
                                     const float* __restrict__ bias_slabs, float* bias_grad, float* bias_grad2,
-                                    const float* __restrict__ row_scale, int tapcols) {
-    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2, row_scale, tapcols);
+                                    const float* __restrict__ row_scale, int tapcols, int tap0, int ntap_out) {
+    reduce_job(slabs, splits, slab_elems, grad, Cout, Cin, KS, Cout_w, row_perm, alpha, accumulate, bias_slabs, bias_grad, bias_grad2, row_scale, tapcols, tap0, ntap_out);
 }
 // floats per split of a reduce job's slabs
 static __host__ __device__ inline size_t reduce_slab_elems(int Cin, int cin_slab, int ksize, int Cout_w, int tapcols) {
@@ -873,7 +874,7 @@ __global__ void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
     const mcgen_wreduce_t& j = jobs.j[blockIdx.y];
     const size_t slab_elems = reduce_slab_elems(j.Cin, j.cin_slab, j.ksize, j.Cout_w, j.tapcols);
     reduce_job(j.slabs, j.splits, slab_elems, j.grad, j.Cout, j.Cin, j.ksize, j.Cout_w, j.row_perm, j.alpha, j.accumulate,
-               j.bias_slabs, j.bias_grad, j.bias_grad2, j.row_scale, j.tapcols);
+               j.bias_slabs, j.bias_grad, j.bias_grad2, j.row_scale, j.tapcols, j.tap0, j.ntap_out);
 }
 
 static int wgrad_chunks(const mcgen_wgrad_t* p) { return (p->seg.C + MCGEN_CK - 1) / MCGEN_CK; }
@@ -1033,7 +1034,8 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
 extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,
                                   int Cout_w, int row_perm, float alpha, int accumulate,
                                   const float* bias_slabs, float* bias_grad, float* bias_grad2,
-                                  const float* row_scale, int cin_slab, int tapcols, void* stream) {
+                                  const float* row_scale, int cin_slab, int tapcols, int tap0, int ntap_out, void* stream) {
+    MCGEN_CHECK(ntap_out == 0 || (tap0 >= 0 && ntap_out > 0 && tap0 + ntap_out <= ksize * ksize), "wgrad_reduce: bad tap window");
     MCGEN_CHECK(slabs && grad && splits >= 1, "wgrad_reduce: bad arguments");
     MCGEN_CHECK(row_perm <= 1 || Cout % row_perm == 0, "wgrad_reduce: row_perm must divide Cout");
     MCGEN_CHECK(cin_slab == 0 || cin_slab >= Cin, "wgrad_reduce: cin_slab is the (padded) channel count the slabs were built for");
@@ -1043,7 +1045,7 @@ extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, i
     int blocks = (int)((slab_elems / 4 * sl + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        slabs, splits, slab_elems, grad, Cout, Cin, ksize, Cout_w, row_perm, alpha, accumulate,
-                       bias_slabs, bias_grad, bias_grad2, row_scale, tapcols);
+                       bias_slabs, bias_grad, bias_grad2, row_scale, tapcols, tap0, ntap_out);
     MCGEN_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }
@@ -1059,6 +1061,7 @@ extern "C" int mcgen_wgrad_reduce_batch(const mcgen_wreduce_t* jobs, int n, void
             MCGEN_CHECK(j.slabs && j.grad && j.splits > 0 && j.Cout > 0 && j.Cin > 0 && (j.ksize == 1 || j.ksize == 3) && j.Cout_w >= j.Cout,
                         "wgrad_reduce_batch: bad job %d", base + i);
             t.j[i] = j;
+            MCGEN_CHECK(j.ntap_out == 0 || (j.tap0 >= 0 && j.ntap_out > 0 && j.tap0 + j.ntap_out <= j.ksize * j.ksize), "wgrad_reduce_batch: job %d: bad tap window", base + i);
             MCGEN_CHECK(!j.tapcols || (j.Cin <= 8 && (j.cin_slab == 0 || j.cin_slab == 8)), "wgrad_reduce_batch: job %d: tapcols slabs hold 8-channel layers", base + i);
             const int sl = j.splits <= 8 ? 1 : j.splits <= 16 ? 2 : j.splits <= 32 ? 4 : j.splits <= 64 ? 8 : 16;   // reduce_lanes
             const size_t v4 = reduce_slab_elems(j.Cin, j.cin_slab, j.ksize, j.Cout_w, j.tapcols) / 4 * sl;

@@ -39,13 +39,22 @@ def allreduce_mean_(flat: torch.Tensor, world: int, group=None, wire_dtype: Opti
     reference's nn.DataParallel sums fp32 gradients, train_gan.py:96-98)."""
     if world > 1:
         if wire_dtype is not None and wire_dtype != flat.dtype:
-            wire = (flat * (1.0 / world)).to(wire_dtype)
+            # persistent wire buffer per bucket (keyed by the bucket's storage offset and length): no allocation on the
+            # communication stream per step, one fused scale + cast into it
+            key = (flat.data_ptr(), flat.numel(), wire_dtype)
+            wire = _WIRE.get(key)
+            if wire is None:
+                wire = _WIRE[key] = torch.empty(flat.numel(), dtype=wire_dtype, device=flat.device)
+            torch.mul(flat, 1.0 / world, out=wire)
             dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
             flat.copy_(wire)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
             flat.mul_(1.0 / world)
     return flat
+
+
+_WIRE: dict = {}
 
 
 def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, group=None):

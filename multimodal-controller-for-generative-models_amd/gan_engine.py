@@ -141,15 +141,16 @@ def _bn_forward(bn: nn.BatchNorm2d, stats: Optional[Tensor], count: int, train: 
     s.count = count
     if train:
         mom = 0.1 if bn.momentum is None else bn.momentum
-        if groups > 1 and _BN_PAR:
+        if groups > 1 and _BN_PAR and bn.running_mean is not None:      # (track_running_stats=False: the serial path takes NULL)
             # the groups in parallel; the running statistics of all layers of the pass in one launch at its end (_flush_counters)
             s.scale, s.shift, s.mean, s.rstd, unb = ops.bn_finalize_par(stats, count, bn.weight, bn.bias, bn.eps, fold=fold, groups=groups)
             _pending_running.append((bn.running_mean, bn.running_var, s.mean, unb, mom))
         else:
             s.scale, s.shift, s.mean, s.rstd = ops.bn_finalize(stats, count, bn.weight, bn.bias, bn.running_mean,
                                                                bn.running_var, mom, bn.eps, fold=fold, groups=groups)
-        _bump(bn.running_mean); _bump(bn.running_var)
-        _pending_counters.setdefault(groups, []).append(bn.num_batches_tracked)   # bumped together at the end of the forward
+        if bn.running_mean is not None:
+            _bump(bn.running_mean); _bump(bn.running_var)
+            _pending_counters.setdefault(groups, []).append(bn.num_batches_tracked)   # bumped together at the end of the forward
     else:
         s.scale, s.shift = ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         s.mean, s.rstd = None, None
@@ -343,6 +344,9 @@ class GeneratorEngine:
         `pair_out` ([groups * 2 * (N / groups), H, W, 8] in the compute dtype: GANTrainer.pair_buffers): the images go
         into the second halves of its `groups` paired [real (+) generated] batches -- written there by the image head itself
         (mcgen_conv_t.y_group) when the launch qualifies, by one strided copy otherwise."""
+        # (a forward that raised part-way -- an McgenError, an out-of-memory, a failed capture -- leaves its queued running-
+        # statistic updates behind: they belong to that pass, not to this one)
+        _pending_counters.clear(); _pending_running.clear()
         self.flat_p.ensure()
         lin, res, head_bn, head_mc, head_conv = self._layers()
         dt = self.dtype

@@ -429,13 +429,15 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
 def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bool = False,
           alpha: float = 1.0, accumulate: bool = False, row_perm: int = 1, splits: Optional[int] = None,
           bias_grad: Optional[Tensor] = None, bias_grad2: Optional[Tensor] = None, second=None,
-          row_scale: Optional[Tensor] = None):
+          row_scale: Optional[Tensor] = None, taps: Optional[Tuple[int, int]] = None):
     """grad[Cout, Cin, k, k] (+)= alpha * dW of one fused-conv segment; optionally also the bias
     gradient bias_grad[Cout] (+)= alpha * sum_pixels dy (and a copy into bias_grad2).
     `cin` may be smaller than the (padded) channel count of seg.x: only the first cin input channels are written.
     `row_scale[Cout]` (optional) multiplies row co of the weight gradient and entry co of the bias gradients.
     `second` = (grad_b, bias_grad_b, bias_grad2_b): the batch is two halves (paired discriminator pass) and the
-    second half's gradient goes to these tensors instead -- one launch, one slab set per half."""
+    second half's gradient goes to these tensors instead -- one launch, one slab set per half.
+    `taps` = (tap0, n): grad is [Cout, Cin, n] and receives taps tap0 .. tap0 + n - 1 of the k x k gradient only (a sub-kernel
+    embedded in the 3x3 image: MCGatedMaskedConv2d's (2 x 3) / (1 x 2) stacks) -- no scratch tensor + slice copy."""
     n = seg.x.shape[0]
     h = seg.x.shape[1] * (2 if seg.ups else 1)
     w = seg.x.shape[2] * (2 if seg.ups else 1)
@@ -476,8 +478,11 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
     p.splits = splits
     p.halves = int(second is not None)
     lib = _lib.load()
-    if grad.numel() != cout * cin * seg.ksize * seg.ksize:
-        raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * seg.ksize ** 2}')
+    tap0, ntap_out = taps if taps is not None else (0, 0)
+    if taps is not None and (second is not None or not (0 <= tap0 and 0 < ntap_out and tap0 + ntap_out <= seg.ksize ** 2)):
+        raise _lib.McgenError('wgrad: bad tap window (and tap windows do not combine with two-half launches)')
+    if grad.numel() != cout * cin * (ntap_out or seg.ksize * seg.ksize):
+        raise _lib.McgenError(f'grad has {grad.numel()} elements, expected {cout * cin * (ntap_out or seg.ksize ** 2)}')
     if (_deferred is not None and _MULTI and explicit_splits is None and dtype == torch.bfloat16
             and lib.mcgen_wgrad_multi_ok(C.byref(p), _dt(dtype))):
         # The 3x3 layers of a backward pass share ONE launch (mcgen_wgrad_multi): queued here, launched when the pass's
@@ -485,7 +490,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         if not grad.is_contiguous():
             raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
         _deferred.append(_PendingMulti(p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm,
-                                       row_scale, m_tiles, (pad16(cout) // 128) * (seg.x.shape[-1] // 64)))
+                                       row_scale, m_tiles, (pad16(cout) // 128) * (seg.x.shape[-1] // 64), (tap0, ntap_out)))
         return
     elems = int(lib.mcgen_wgrad_c8_slab_elems(C.byref(p)) if c8 else lib.mcgen_wgrad_slab_elems(C.byref(p)))
     # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
@@ -520,12 +525,12 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
             if not gr.is_contiguous():
                 raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
             _deferred.append((sl, gr, bs, bg, bg2, ns, cout, cin, seg.ksize, pad16(cout), row_perm, int(accumulate), float(alpha),
-                              row_scale, seg.x.shape[-1], int(c8)))
+                              row_scale, seg.x.shape[-1], int(c8), tap0, ntap_out))
         else:
             _timed(lambda: 'wgrad_reduce', 0.0,
                    lambda: check(lib.mcgen_wgrad_reduce(_p(sl), ns, _f32(gr), cout, cin, seg.ksize, pad16(cout), row_perm,
                                                         float(alpha), int(accumulate), _p(bs), _f32(bg), _f32(bg2), _f32(row_scale),
-                                                        seg.x.shape[-1], int(c8), _stream()), 'wgrad_reduce'),
+                                                        seg.x.shape[-1], int(c8), tap0, ntap_out, _stream()), 'wgrad_reduce'),
                    lambda: _nbytes(gr), lambda: _nbytes(sl, bs))
 
 
@@ -545,9 +550,11 @@ def _cu_count(device) -> int:
 class _PendingMulti:
     """One queued layer of a mcgen_wgrad_multi launch (see ops.wgrad)."""
     __slots__ = ('p', 'seg', 'dy', 'cout', 'cin', 'grad', 'bias_grad', 'bias_grad2', 'second', 'alpha', 'accumulate', 'row_perm',
-                 'row_scale', 'm_tiles', 'blocks', 'splits', 'slabs', 'bias_slabs')
+                 'row_scale', 'm_tiles', 'blocks', 'splits', 'slabs', 'bias_slabs', 'taps')
 
-    def __init__(self, p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm, row_scale, m_tiles, blocks):
+    def __init__(self, p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm, row_scale, m_tiles, blocks,
+                 taps=(0, 0)):
+        self.taps = taps
         self.p, self.seg, self.dy, self.cout, self.cin = p, seg, dy, cout, cin
         self.grad, self.bias_grad, self.bias_grad2, self.second = grad, bias_grad, bias_grad2, second
         self.alpha, self.accumulate, self.row_perm, self.row_scale = alpha, accumulate, row_perm, row_scale
@@ -556,7 +563,7 @@ class _PendingMulti:
     def jobs(self):
         """The slab-reduce job(s) of the layer, in deferred_reduces' tuple form."""
         cw, ks, cs = pad16(self.cout), self.seg.ksize, self.seg.x.shape[-1]
-        tail = (self.cout, self.cin, ks, cw, self.row_perm, int(self.accumulate), float(self.alpha), self.row_scale, cs, 0)
+        tail = (self.cout, self.cin, ks, cw, self.row_perm, int(self.accumulate), float(self.alpha), self.row_scale, cs, 0) + tuple(self.taps)
         if self.second is None:
             return [(self.slabs, self.grad, self.bias_slabs, self.bias_grad, self.bias_grad2, self.splits) + tail]
         hs = self.splits // 2
@@ -667,12 +674,12 @@ class deferred_reduces:
                 _side_keep.clear()
         if et is None and jobs:
             arr = (_lib.WReduce * len(jobs))()
-            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha, rscale, cin_slab, tapcols) in zip(arr, jobs):
+            for a, (slabs, grad, bs, bg, bg2, splits, cout, cin, ks, cout_w, row_perm, acc, alpha, rscale, cin_slab, tapcols, tap0, ntap_out) in zip(arr, jobs):
                 a.slabs, a.grad, a.bias_slabs = _p(slabs), _f32(grad), _p(bs)
                 a.bias_grad, a.bias_grad2 = _f32(bg) if bs is not None else None, _f32(bg2) if bs is not None else None
                 a.splits, a.Cout, a.Cin, a.ksize, a.Cout_w = splits, cout, cin, ks, cout_w
                 a.row_perm, a.accumulate, a.alpha = row_perm, acc, alpha
-                a.row_scale, a.cin_slab, a.tapcols = _f32(rscale), cin_slab, tapcols
+                a.row_scale, a.cin_slab, a.tapcols, a.tap0, a.ntap_out = _f32(rscale), cin_slab, tapcols, tap0, ntap_out
             _timed(lambda: 'wgrad_reduce', 0.0,
                    lambda: check(_lib.load().mcgen_wgrad_reduce_batch(arr, len(jobs), _stream()), 'wgrad_reduce_batch'),
                    lambda: sum(_nbytes(j[1]) for j in jobs), lambda: sum(_nbytes(j[0], j[2]) for j in jobs))

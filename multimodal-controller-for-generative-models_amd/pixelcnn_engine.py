@@ -49,12 +49,11 @@ class PixelCNNEngine:
             p.grad = torch.zeros_like(p)
         return p.grad
 
-    @staticmethod
-    def _bn(bn, stats: Optional[Tensor], count: int, train: bool):
+    def _bn(self, bn, stats: Optional[Tensor], count: int, train: bool):
         if train:
             sc, sh, mean, rstd = ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                  bn.running_var, bn.momentum, bn.eps)
-            bn.num_batches_tracked += 1
+            self._nbt.append(bn.num_batches_tracked)       # bumped together at the end of the forward (46 launches -> 1)
             return sc, sh, mean, rstd
         sc, sh = ops.bn_eval_affine(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         return sc, sh, None, None
@@ -154,6 +153,7 @@ class PixelCNNEngine:
         x = F.embedding(codes, m.embedding.weight.detach()).to(dt).contiguous()           # [N, H, W, C] is already NHWC
         x_v = x_h = x
         layers = [] if tape is not None else None
+        self._nbt = []
         I = self._images(False)
         # every MultimodalController's code rows of this batch in one launch (a row gather per module: one_hot(label) @ codebook)
         mcs = [mc for L in m.layers for mc in (L.gate_v.mc, L.gate_h.mc, L.horiz_resid[2])] + [m.output_conv[3]]
@@ -172,6 +172,9 @@ class PixelCNNEngine:
         logits, _ = ops.conv_fused([Seg(h0, ksize=1, scale=bn[0], shift=bn[1], relu=True, code=code0)],
                                    I[('head', 4)], conv4.out_channels, bias=conv4.bias.detach())
         self._codes = None
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+        self._nbt = []
         rows, dlogits = ops.cross_entropy(logits, codes.reshape(-1), conv4.out_channels, want_grad)
         if tape is not None:
             tape.update(layers=layers, codes=codes, x_h=x_h, h0=h0, bn0=bn, code0=code0, dlogits=dlogits)
@@ -207,12 +210,13 @@ class PixelCNNEngine:
         k2 = L.kernel // 2
         in_h = r['in_h']
         cin_h = in_h.x.shape[-1]
-        gwh = torch.empty((c2, cin_h, in_h.ksize, in_h.ksize), dtype=torch.float32, device=ds.device)
-        ops.wgrad(in_h, ds, c2, cin_h, gwh)
         gh = self._grad(L.horiz_stack.weight)
         if L.kernel == 3:
-            self._post.append(lambda: gh.copy_(gwh[:, :, 1:2, 0:2]))
+            # the (1 x 2) stack sits at taps (1, 0), (1, 1) of the 3x3 image (mcpixelcnn.py:32-35): the reduce writes that window
+            ops.wgrad(in_h, ds, c2, cin_h, gh, taps=(3, 2))
         else:
+            gwh = torch.empty((c2, cin_h, in_h.ksize, in_h.ksize), dtype=torch.float32, device=ds.device)
+            ops.wgrad(in_h, ds, c2, cin_h, gwh)
             self._post.append(lambda: gh.copy_(gwh.reshape(c2, 1, k2 + 1, c).permute(0, 3, 1, 2)))
         # gate_v and the vertical stack
         d_hv = None
@@ -223,12 +227,13 @@ class PixelCNNEngine:
         d_hv, _ = ops.conv_fused([Seg(ds, ksize=1)], I[(li, 'v2h')], c2, res=d_hv)
         in_v = r['in_v']
         cin_v = in_v.x.shape[-1]
-        gwv = torch.empty((c2, cin_v, in_v.ksize, in_v.ksize), dtype=torch.float32, device=ds.device)
-        ops.wgrad(in_v, d_hv, c2, cin_v, gwv, bias_grad=self._grad(L.vert_stack.bias))
         gv = self._grad(L.vert_stack.weight)
         if L.kernel == 3:
-            self._post.append(lambda: gv.copy_(gwv[:, :, 0:2, :]))
+            # the (2 x 3) stack = rows 0, 1 of the 3x3 image (mcpixelcnn.py:29-31): taps 0 .. 5
+            ops.wgrad(in_v, d_hv, c2, cin_v, gv, bias_grad=self._grad(L.vert_stack.bias), taps=(0, 6))
         else:
+            gwv = torch.empty((c2, cin_v, in_v.ksize, in_v.ksize), dtype=torch.float32, device=ds.device)
+            ops.wgrad(in_v, d_hv, c2, cin_v, gwv, bias_grad=self._grad(L.vert_stack.bias))
             self._post.append(lambda: gv.copy_(gwv.reshape(c2, k2 + 1, L.kernel, c).permute(0, 3, 1, 2)))
         if not need_dx:
             return None, None

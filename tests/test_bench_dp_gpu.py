@@ -14,23 +14,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('workload', ['mcpixelcnn', 'cifar10'])
-def test_bench_two_ranks_one_card(workload):
+@pytest.mark.parametrize('workload,batch,extra', [('mcpixelcnn', 16, []), ('cifar10', 16, []),
+                                                  # BASELINE configs[2]'s per-GPU shard (global 512 over 8 GPUs = 64 / GPU), bf16 gradient wire
+                                                  ('coil100', 64, ['--grad-bf16'])])
+def test_bench_two_ranks_one_card(workload, batch, extra):
     env = dict(os.environ, MCGEN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', workload, '--steps', '2',
-           '--warmup', '1', '--batch', '16', '--sustain-steps', '0']
+           '--warmup', '1', '--batch', str(batch), '--sustain-steps', '0'] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
-    assert out['config']['global_batch'] == 32 and out['value'] > 0
-    if workload == 'cifar10':
+    assert out['config']['global_batch'] == 2 * batch and out['value'] > 0
+    if workload in ('cifar10', 'coil100'):
         # N > 1 line: the gradient exchange's own time per iteration and the part of it hidden under the backward pass
         assert out['comm'] is not None and out['comm']['comm_us'] > 0
-        assert 0 <= out['overlap_us'] <= out['comm']['comm_us'] + 1e-6 and out['grad_wire_dtype'] == 'f32'
+        assert 0 <= out['overlap_us'] <= out['comm']['comm_us'] + 1e-6 and out['grad_wire_dtype'] == ('bf16' if extra else 'f32')
 
 
 @pytest.mark.parametrize('workload', ['cifar10', 'coil100'])
