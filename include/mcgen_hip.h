@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half); 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order + mcgen_prep_t.kmap (per-mode dense weight sets), mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -122,6 +122,15 @@ typedef struct {
                             * the caller's.  The image head (form 5) only; every other form requires 0.             */
     const float* bias2;    /* [Cout] or NULL: added to `bias` (a fused shortcut segment's own bias: the sum is formed in
                             * fp32 before it meets the accumulator, as bias + bias2 on the host would be)   */
+    /* Per-mode dense weight sets (the software-pipelined bf16 form only; tiles inside one image):                       */
+    const int32_t* wsel;   /* [N] or NULL: the image processed at POSITION i (see `order`) reads the weight image
+                            * w + wsel[i] * wsel_stride -- one dense image per MultimodalController mode, its input channels the
+                            * mode's active ones in order (mcgen_prep_t.kmap), for activations the producing launch stored compacted
+                            * (ycmap): the K loop is DENSE over the compacted pitch, no per-sample row gather (w_layout 2's) */
+    int64_t wsel_stride;   /* elements of the weight dtype between two weight sets                                       */
+    const int32_t* order;  /* [N] or NULL: a permutation of the images -- workgroups walk images order[0], order[1], ...; images of
+                            * one mode made adjacent keep that mode's weight set in L2 while they run.  Outputs, statistics rows
+                            * and every per-image input keep their true image index.                                     */
 } mcgen_conv_t;
 
 /* number of M tiles (rows of `stats`) the launch of `p` will use.  Depends on the shape / mode fields only -- callers ask
@@ -225,6 +234,9 @@ typedef struct {
     const float* w; void* image;
     int32_t Cout, Cin, ksize, transpose, row_perm, sigma_idx;
     float wscale; int32_t layout;   /* 0: chunked image (mcgen_prep_weight); 1: K-major (mcgen_prep_weight_k, transpose = 0) */
+    const int16_t* kmap;            /* layout 0, transpose 0: NULL, or the image's input channel k is source channel kmap[k]    */
+    int32_t kcount, _pad;           /* (k < kcount; kmap[k] >= Cin: a zero column) -- a mode's compacted weight image: kmap =
+                                     * the cidx part of that mode's mcgen_mc_cmap record, kcount = the compacted pitch       */
 } mcgen_prep_t;
 int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream);
 
@@ -256,7 +268,7 @@ int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int
 /* out[r][i][m] = (label[i] == m) for r < reps: F.one_hot(label, classes).float() (mcgan.py:196,201) written `reps` times back to
  * back -- the indicator of a paired discriminator batch (2 N rows) and of the grouped generator pass (d_iters * N rows) are
  * prefixes of one such buffer.  Labels outside [0, classes) fail the launch's precondition (the row stays all zero). */
-int mcgen_onehot_rep(const int64_t* label, float* out, int N, int classes, int reps, void* stream);
+int mcgen_onehot_rep(const int64_t* label, float* out, int* lab32, int N, int classes, int reps, void* stream);
 int mcgen_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 /* y[N, Ho, Wo, C] = 2x2 sums of x[N, 2 Ho, 2 Wo, C] (NHWC, C a multiple of 8): the adjoint of the nearest x2 upsample.
  * The generator's shortcut conv1x1(Up(x)) (mcgan.py:26-30,42) commutes with the upsample, so its weight gradient and

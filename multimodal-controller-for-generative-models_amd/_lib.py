@@ -25,7 +25,8 @@ class Conv(C.Structure):
                 ('res', C.c_void_p), ('ocode', C.c_void_p), ('gate_x', C.c_void_p),
                 ('gscale', C.c_void_p), ('gshift', C.c_void_p), ('gmean', C.c_void_p), ('grstd', C.c_void_p),
                 ('tanh_out', C.c_int32), ('stats', C.c_void_p), ('stats_mode', C.c_int32), ('w_layout', C.c_int32),
-                ('ycmap', C.c_void_p), ('ycmap_stride', C.c_int32), ('y_group', C.c_int32), ('bias2', C.c_void_p)]
+                ('ycmap', C.c_void_p), ('ycmap_stride', C.c_int32), ('y_group', C.c_int32), ('bias2', C.c_void_p),
+                ('wsel', C.c_void_p), ('wsel_stride', C.c_int64), ('order', C.c_void_p)]
 
 
 class Wgrad(C.Structure):
@@ -57,7 +58,8 @@ class PrepEx(C.Structure):
 class Prep(C.Structure):
     _fields_ = [('w', C.c_void_p), ('image', C.c_void_p),
                 ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('transpose', C.c_int32),
-                ('row_perm', C.c_int32), ('sigma_idx', C.c_int32), ('wscale', C.c_float), ('layout', C.c_int32)]
+                ('row_perm', C.c_int32), ('sigma_idx', C.c_int32), ('wscale', C.c_float), ('layout', C.c_int32),
+                ('kmap', C.c_void_p), ('kcount', C.c_int32), ('_pad', C.c_int32)]
 
 
 class Code(C.Structure):
@@ -197,7 +199,7 @@ SYMBOLS = {
     'mcgen_hinge_d': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'mcgen_hinge_g': (_i, [_vp, _i, _vp, _vp, _vp]),
     'mcgen_tanh_bwd': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
-    'mcgen_onehot_rep': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'mcgen_onehot_rep': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_adam': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _vp, _f, _f, _f, _f, _vp, _vp]),
     'mcgen_sn_fix_pair_adam': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _f, _f, _f, _f, _vp, _i, _vp]),
 }

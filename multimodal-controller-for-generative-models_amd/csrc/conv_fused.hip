@@ -1789,9 +1789,16 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, N = p.N;
-    const int tile_m = blockIdx.x;
+    int tile_m = blockIdx.x;
+    int wset = 0;
+    if (p.order || p.wsel) {
+        // per-mode weight sets: position i of the walk = image order[i]; its weights = set wsel[i] (both loads go out together)
+        const int tpi = (H * W) / BM, pos = tile_m / tpi;
+        if (p.wsel) wset = p.wsel[pos];
+        if (p.order) tile_m = p.order[pos] * tpi + (tile_m - pos * tpi);
+    }
     const int cout0 = blockIdx.y * BN;
-    const Geo g = make_geo(BM, blockIdx.x, H, W);          // host guarantees TI == 1 and p.W == W
+    const Geo g = make_geo(BM, tile_m, H, W);              // host guarantees TI == 1 and p.W == W
     const int n_img = g.n0 < N ? g.n0 : N - 1;
 
     f32x4 acc[FN][FM];
@@ -1802,7 +1809,7 @@ void conv_pp_kernel(const mcgen_conv_t p, const int a_bytes) {
 
     const mcgen_seg_t sg0 = seg_for_tile(p.seg[0], g);
     const int C0 = sg0.C;
-    const char* wimg = reinterpret_cast<const char*>(p.w);
+    const char* wimg = reinterpret_cast<const char*>(p.w) + (size_t)wset * (size_t)p.wsel_stride * 2;
     const size_t wblock_bytes = (size_t)p.Cout_w * BROW;
     // gathered-K bookkeeping of a segment (wave-uniform): weight rows of the image, its active count
     auto seg_info = [&](int si, const int16_t*& cidx, int& cw, int& cnt) {
@@ -2582,6 +2589,10 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->stats_mode != 2 || (p->gate_x && p->gmean && p->grstd), "conv_fused: stats_mode 2 needs gate_x, gmean, grstd");
     MCGEN_CHECK(p->stats_mode == 0 || p->stats, "conv_fused: stats_mode set without a stats buffer");
     MCGEN_CHECK(p->w_layout >= 0 && p->w_layout <= 2, "conv_fused: unknown weight layout %d", p->w_layout);
+    if (p->wsel || p->order) {
+        MCGEN_CHECK(p->w_layout == 0 && p->y_group == 0, "conv_fused: per-mode weight sets (wsel / order) go with the chunked weight image (w_layout 0)");
+        MCGEN_CHECK(!p->wsel || p->wsel_stride > 0, "conv_fused: wsel needs wsel_stride");
+    }
     if (p->ycmap) {
         MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out && !p->bias2, "conv_fused: a compacted output takes bias and statistics only");
         MCGEN_CHECK(p->Cy % 32 == 0 && p->Cy <= round_up(p->Cout, 8) + 32 && p->ycmap_stride >= 2 * round_up(p->Cout, 8) + 32,
@@ -2621,7 +2632,7 @@ extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* b
 }
 
 extern "C" int mcgen_conv_form(const mcgen_conv_t* p, int dtype) {
-    if (!p || p->w_layout != 0) return 0;
+    if (!p || p->w_layout != 0 || p->wsel || p->order) return 0;
     if (mcgen_conv_skinny_ok(p, dtype)) return 1;
     if (mcgen_conv_smap_ok(p, dtype)) return 2;
     if (mcgen_conv_px1_bm(p, dtype)) return 3;
@@ -2640,6 +2651,13 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (p->w_layout == 1) return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
     if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
+    if (p->wsel || p->order) {
+        const TilePick tw = pick_tile(p, dtype);
+        MCGEN_CHECK(dtype == MCGEN_BF16 && tw.pipe == 20, "conv_fused: per-mode weight sets need the software-pipelined bf16 form "
+                    "(3x3 first segment of 64 .. 512 channels in whole chunks, 16x16 / 32x32 maps, >= 65536 pixels)");
+        if (p->ycmap) MCGEN_CHECK(tw.BM <= p->H * p->W && p->Cout_w <= tw.BN, "conv_fused: compacted output: the %dx%d tile must hold all %d channels", tw.BM, tw.BN, p->Cout_w);
+        return dispatch(p, dtype, tw, reinterpret_cast<hipStream_t>(stream));
+    }
     if (mcgen_conv_skinny_ok(p, dtype)) return mcgen_conv_skinny(p, reinterpret_cast<hipStream_t>(stream));
     if (mcgen_conv_smap_ok(p, dtype)) return mcgen_conv_smap(p, reinterpret_cast<hipStream_t>(stream));
     if (mcgen_conv_px1_bm(p, dtype)) return mcgen_conv_px1(p, reinterpret_cast<hipStream_t>(stream));

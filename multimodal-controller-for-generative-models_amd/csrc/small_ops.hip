@@ -154,7 +154,8 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
         }
         return;
     }
-    const int rows = transpose ? Cin : Cout, kdim = transpose ? Cout : Cin;
+    const int16_t* __restrict__ kmap = transpose ? nullptr : d.kmap;        // (compacted input channels: forward orientation only)
+    const int rows = transpose ? Cin : Cout, kdim = kmap ? d.kcount : (transpose ? Cout : Cin);
     const int rows_w = (rows + 15) / 16 * 16;
     const int nchunk = (((kdim + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
     const float sc = (d.sigma_idx >= 0) ? d.wscale / sigma_base[d.sigma_idx] : d.wscale;
@@ -166,9 +167,10 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
         const int col = (int)(i % MCGEN_CK); size_t t = i / MCGEN_CK;
         const int row = (int)(t % rows_w); const int q = (int)(t / rows_w);
         const int k = q * MCGEN_CK + col;
-        const bool live = row < rows && k < kdim;
+        bool live = row < rows && k < kdim;
         int co = transpose ? k : row;
-        const int ci = transpose ? row : k;
+        int ci = transpose ? row : k;
+        if (kmap && live) { ci = kmap[k]; live = ci >= 0 && ci < Cin; }
         if (row_perm > 1) { const int Cc = Cout / row_perm; co = (co % Cc) * row_perm + co / Cc; }
         const float* src = live ? w + ((size_t)co * Cin + ci) * ntap : w;          // (padding rows / columns: zeros, no read)
         T* dst = img + ((size_t)q * ntap * rows_w + row) * MCGEN_CK + col;
@@ -1133,18 +1135,19 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
     else return mcgen_fail("unknown dtype %d", dtype)
 
 namespace {
-__global__ void onehot_rep_kernel(const int64_t* __restrict__ label, float* __restrict__ out, int n, int classes, int reps) {
+__global__ void onehot_rep_kernel(const int64_t* __restrict__ label, float* __restrict__ out, int* __restrict__ lab32, int n, int classes, int reps) {
     const int per = n * classes, total = per * reps;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int e = i % per, row = e / classes, m = e - row * classes;
         out[i] = (label[row] == (int64_t)m) ? 1.f : 0.f;
+        if (lab32 && m == 0) lab32[(i / per) * n + row] = (int)label[row];
     }
 }
 }  // namespace
-extern "C" int mcgen_onehot_rep(const int64_t* label, float* out, int N, int classes, int reps, void* stream) {
+extern "C" int mcgen_onehot_rep(const int64_t* label, float* out, int* lab32, int N, int classes, int reps, void* stream) {
     MCGEN_CHECK(label && out && N > 0 && classes > 0 && reps > 0 && (long)N * classes * reps < (1L << 31), "onehot_rep: bad arguments");
     const int total = N * classes * reps;
-    hipLaunchKernelGGL(onehot_rep_kernel, dim3(grid_for((size_t)total, 256, 256)), dim3(256), 0, STREAM(stream), label, out, N, classes, reps);
+    hipLaunchKernelGGL(onehot_rep_kernel, dim3(grid_for((size_t)total, 256, 256)), dim3(256), 0, STREAM(stream), label, out, lab32, N, classes, reps);
     MCGEN_LAUNCH_CHECK("onehot_rep"); return 0;
 }
 extern "C" int mcgen_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int Cp, void* stream) {

@@ -100,6 +100,11 @@ _MC = _flag('MCGEN_MC', '0') == '1'
 # gathered-K consumer, conv_fused.hip "gk"): tools/bench_mc.py gk measured x1.24-1.31 on the consumer launches
 _GK = _flag('MCGEN_GK', '1') != '0'
 _LOWRES_SC_BWD = _flag('MCGEN_LOWRES_SC_BWD', '1') != '0'
+# per-mode DENSE weight images for the launches that read compacted activations (instead of the gathered-K form's per-sample
+# row gather): needs one-hot indicators (the mode of an image is its label) and few modes (10 x 0.8 MB per layer at CIFAR-10)
+_PM = _flag('MCGEN_PM', '1') != '0'
+_PM_ORDER = _flag('MCGEN_PM_ORDER', '0') == '1'      # walk the images mode by mode (their weight set stays in L2): measured neutral, opt-in
+_PM_MAX_MODES = 16
 class Nhwc:
     """An image batch in the engines' own layout ([N, H, W, C padded to 8] of the compute dtype, padding channels zero) with
     its true channel count: what the trainer hands from one engine to the other, instead of converting to the module
@@ -188,9 +193,14 @@ class GeneratorEngine:
         for b in res:
             ws += [b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight,
                    b.conv[8].module.bias, b.shortcut[2].module.bias]
-        key = (self.dtype, tuple((w.data_ptr(), w._version) for w in ws))
+        cbs = [m.codebook for b in res for m in (b.mc_1, b.mc_2)] if self._pm_enabled() else []
+        pm_key = tuple((c.data_ptr(), tuple(c.shape), c._version) for c in cbs)
+        key = (self.dtype, tuple((w.data_ptr(), w._version) for w in ws), pm_key)
         if not force and key == self._img_key:
             return
+        if getattr(self, '_pm_key', None) != pm_key:            # a codebook changed (create / transit): the per-mode jobs are stale
+            self._prep_fwd = None
+            self._pm_key = pm_key
         dt = self.dtype
         dev = lin.weight.device
         c0 = lin.out_features // 16
@@ -229,6 +239,36 @@ class GeneratorEngine:
                     jobs.append((wsc, catk[n2:], False, 1, -1, 1.0, True))
                     if i > 0 and self._gk_block(i - 1):
                         jobs.append((w1, buf(f'b{i}.w1g', ops.weight_image_k_elems(w1.shape[0], w1.shape[1], 3), dt), False, 1, -1, 1.0, True))
+            if self._pm_enabled():
+                # per-mode dense images of the same launches: for every mode m, the chunked image whose input channels are the
+                # mode's active ones in order (PrepBatch kmap = the cidx part of the mode's compaction record), padded with
+                # zero columns to the compacted pitch -- conv_b ++ shortcut as two jobs into one slot, conv_a where x arrives
+                # compacted.  img['b{i}.w2sm'] / ['b{i}.w1m'] hold the M sets back to back.
+                self._pm_maps = {}
+                for i, b in enumerate(res):
+                    if not self._gk_block(i):
+                        continue
+                    w1, w2, wsc = b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight
+                    cap_h, cm2 = self._cap(b.mc_2), self._mode_maps(b.mc_2)
+                    x_compact = i > 0 and self._gk_block(i - 1)
+                    cap_x, cm1 = (self._cap(b.mc_1), self._mode_maps(b.mc_1)) if x_compact else (None, None)
+                    if cap_h is None or (x_compact and cap_x is None):
+                        continue
+                    modes = b.mc_2.codebook.shape[0]
+                    n2 = ops.weight_image_elems(w2.shape[0], cap_h, 3)
+                    ns = ops.weight_image_elems(wsc.shape[0], cap_x if x_compact else wsc.shape[1], 1)
+                    slot = buf(f'b{i}.w2sm', modes * (n2 + ns), dt).view(modes, n2 + ns)
+                    for m in range(modes):
+                        jobs.append((w2, slot[m, :n2], False, 1, -1, 1.0, False, cm2[m, w2.shape[1]:], cap_h))
+                        if x_compact:
+                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0, False, cm1[m, wsc.shape[1]:], cap_x))
+                        else:
+                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0))
+                    if x_compact:
+                        n1 = ops.weight_image_elems(w1.shape[0], cap_x, 3)
+                        slot1 = buf(f'b{i}.w1m', modes * n1, dt).view(modes, n1)
+                        for m in range(modes):
+                            jobs.append((w1, slot1[m], False, 1, -1, 1.0, False, cm1[m, w1.shape[1]:], cap_x))
             if self._mc_enabled():
                 # K-major images of the blocks whose maps are large enough for a tile to lie inside one image (the
                 # mode-compacted kernel gathers the active channels' rows from them): conv_a, and conv_b ++ shortcut
@@ -289,6 +329,20 @@ class GeneratorEngine:
         return (self._gk_enabled() and (8 << i) >= 16 and 64 <= c1.out_channels <= 256 and c1.out_channels % 32 == 0
                 and c1.in_channels % 8 == 0)
 
+    def _pm_enabled(self) -> bool:
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        return _PM and self._gk_enabled() and res[0].mc_1.codebook.shape[0] <= _PM_MAX_MODES
+
+    def _mode_maps(self, mc):
+        """Compaction records of the codebook's ROWS (ops.mc_cmap: int16 [modes, stride]; the cidx part starts at column C):
+        the map of a one-hot sample is its mode's.  Cached per codebook version."""
+        cb = mc.codebook
+        key = (cb.data_ptr(), tuple(cb.shape), cb._version)
+        cache = self.__dict__.setdefault('_mm_cache', {})
+        if cache.get(id(mc), (None,))[0] != key:
+            cache[id(mc)] = (key, ops.mc_cmap(cb.detach().contiguous()))
+        return cache[id(mc)][1]
+
     def _cap(self, mc):
         """Compacted channel pitch for activations masked by `mc`: the largest number of active channels any mode keeps,
         rounded up to 32 (None when compaction would not pay, or a code is negative).  Read from the codebook on the
@@ -313,6 +367,8 @@ class GeneratorEngine:
             lin, res, head_bn, head_mc, head_conv = self._layers()
             for b in res:
                 self._cap(b.mc_1); self._cap(b.mc_2)
+                if self._pm_enabled():
+                    self._mode_maps(b.mc_1); self._mode_maps(b.mc_2)
 
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:
@@ -370,6 +426,18 @@ class GeneratorEngine:
         # Forward-only grouped pass: activations between the launches stay COMPACTED -- the producer stores, per image, only
         # the channels the consumer's MultimodalController keeps (ycmap), the consumer gathers the matching weight rows.
         gk = groups > 1 and one_hot and self._gk_enabled()
+        # per-mode dense weight sets for the launches that read compacted activations: the mode of an image is its label
+        hint = getattr(indicator, '_mcgen_onehot', None)
+        pm = gk and self._pm_enabled() and hint is not None and hint[0].shape[0] * hint[1] == n
+        wsel = order = None
+        if pm:
+            lab = hint[2] if len(hint) > 2 and hint[2] is not None else hint[0].to(torch.int32).repeat(hint[1])
+            if _PM_ORDER:
+                # stable: images keep their relative order inside a mode (tiles of one BatchNorm group stay together)
+                srt, oi = torch.sort(lab, stable=True)
+                wsel, order = srt.contiguous(), oi.to(torch.int32)
+            else:
+                wsel = lab
         x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
         caps_h = [self._cap(b.mc_2) if (gk and self._gk_block(i)) else None for i, b in enumerate(res)]
         for i, b in enumerate(res):
@@ -388,9 +456,15 @@ class GeneratorEngine:
             # ---- conv_a: BN -> ReLU -> Up -> MC1 -> conv3x3 (mcgan.py:15-19)
             if x_cm is not None:
                 sa, ta = ops.mc_affine(code1, x_cm[0], x_cm[1], bn1.scale, bn1.shift, group_n=gn)
-                seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1, cmap=x_cm[0], cw=ci)
-                h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1g'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
-                                         kmajor=2, ycmap=cm_h, cy=cap_h)
+                if pm and f'b{i}.w1m' in self.img:
+                    # dense K loop over the compacted pitch on the image's mode's own weight image
+                    seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1)
+                    h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1m'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
+                                             ycmap=cm_h, cy=cap_h, wsel=wsel, order=order)
+                else:
+                    seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1, cmap=x_cm[0], cw=ci)
+                    h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1g'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
+                                             kmajor=2, ycmap=cm_h, cy=cap_h)
             else:
                 # large maps: the K loop visits only each sample's active channels (mode-compacted kernel, K-major images)
                 mc = self._mc_block(i) and f'b{i}.w1k' in self.img
@@ -402,14 +476,21 @@ class GeneratorEngine:
             # ---- conv_b ++ shortcut: conv3x3(MC2(ReLU(BN(h)))) + conv1x1(MC1(Up(x))) (mcgan.py:20-30,42)
             if cm_h is not None:
                 sb, tb = ops.mc_affine(code2, cm_h, cap_h, bn2.scale, bn2.shift, group_n=gn)
-                seg_b = Seg(h, scale=sb, shift=tb, relu=True, group_n=1, cmap=cm_h, cw=co)
+                use_pm = pm and f'b{i}.w2sm' in self.img
+                seg_b = Seg(h, scale=sb, shift=tb, relu=True, group_n=1) if use_pm else \
+                    Seg(h, scale=sb, shift=tb, relu=True, group_n=1, cmap=cm_h, cw=co)
                 if x_cm is not None:
                     ss, ts = ops.mc_affine(code1, x_cm[0], x_cm[1])
-                    seg_s = Seg(x, ksize=1, scale=ss, shift=ts, ups=True, group_n=1, cmap=x_cm[0], cw=ci)
+                    seg_s = Seg(x, ksize=1, scale=ss, shift=ts, ups=True, group_n=1) if use_pm else \
+                        Seg(x, ksize=1, scale=ss, shift=ts, ups=True, group_n=1, cmap=x_cm[0], cw=ci)
                 else:
                     seg_s = Seg(x, ksize=1, code=code1, ups=True)
-                y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co, bias=self.img[f'b{i}.bias2s'],
-                                       stats_mode=st_mode, kmajor=2, ycmap=cm_y, cy=cap_y)
+                if use_pm:
+                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sm'].view(-1), co, bias=self.img[f'b{i}.bias2s'],
+                                           stats_mode=st_mode, ycmap=cm_y, cy=cap_y, wsel=wsel, order=order)
+                else:
+                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co, bias=self.img[f'b{i}.bias2s'],
+                                           stats_mode=st_mode, kmajor=2, ycmap=cm_y, cy=cap_y)
             else:
                 # (conv_b ++ 1x1 shortcut stays dense in the mode-compacted form: one-tap K steps cost more than they save)
                 seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)

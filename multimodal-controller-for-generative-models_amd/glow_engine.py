@@ -57,6 +57,8 @@ class GlowEngine:
         if not backward:
             rs = torch._foreach_exp(torch._foreach_mul([z.scale.detach().reshape(-1) for z in zcs], 3.0))
             self._rs = {id(z): r for z, r in zip(zcs, rs)}
+            # ... and their biases times it (mcglow.py:127-130: (conv(x) + b) * exp(3 scale)): one launch, not one per flow
+            self._bz = {id(z): b for z, b in zip(zcs, torch._foreach_mul([z.conv.bias.detach() for z in zcs], rs))}
             self._wmat = {}
         jobs, keys = [], []
         if not backward:
@@ -115,7 +117,8 @@ class GlowEngine:
         if rs is None:
             rs = torch.exp(zc.scale.detach().reshape(-1) * 3)
         img = self._img((id(zc), 'f'), lambda: ops.prep_weight_ex(zc.conv.weight.detach(), self.dtype, row_scale=rs, k_img=cin_pad))
-        return img, zc.conv.bias.detach() * rs
+        bz = getattr(self, '_bz', {}).get(id(zc)) if getattr(self, '_I', None) else None
+        return img, (bz if bz is not None else zc.conv.bias.detach() * rs)
 
     def _coupling_net(self, cp_net, x: Tensor, c: int, codes, train: bool, saved=None):
         """AffineCoupling.net on the first c/2 channels of x -> [log_s | t] (c channels)."""

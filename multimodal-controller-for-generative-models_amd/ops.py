@@ -256,22 +256,25 @@ def cmap_stride(c: int) -> int:
     return int(_lib.load().mcgen_cmap_stride(c))
 
 
-def onehot_rep(label: Tensor, classes: int, reps: int, out: Optional[Tensor] = None) -> Tensor:
-    """[reps * N, classes] fp32: F.one_hot(label, classes).float() (mcgan.py:196,201) `reps` times back to back, one launch."""
+def onehot_rep(label: Tensor, classes: int, reps: int, out: Optional[Tensor] = None, lab32: Optional[Tensor] = None) -> Tensor:
+    """[reps * N, classes] fp32: F.one_hot(label, classes).float() (mcgan.py:196,201) `reps` times back to back, one launch.
+    `lab32` (optional, int32 [reps * N]) receives the labels themselves, repeated (the per-image weight-set index of conv_fused)."""
     n = label.shape[0]
     if label.dtype != torch.int64 or not label.is_cuda:
         raise _lib.McgenError('onehot_rep: int64 labels on the GPU')
     if out is None:
         out = torch.empty((reps * n, classes), dtype=torch.float32, device=label.device)
     assert tuple(out.shape) == (reps * n, classes) and out.dtype == torch.float32 and out.is_contiguous()
-    check(_lib.load().mcgen_onehot_rep(_p(label.contiguous()), _f32(out), n, classes, reps, _stream()), 'onehot_rep')
+    if lab32 is not None:
+        assert lab32.dtype == torch.int32 and lab32.numel() == reps * n and lab32.is_contiguous()
+    check(_lib.load().mcgen_onehot_rep(_p(label.contiguous()), _f32(out), _p(lab32), n, classes, reps, _stream()), 'onehot_rep')
     return out
 
 
-def onehot_hint(indicator: Tensor, label: Tensor, reps: int = 1) -> Tensor:
+def onehot_hint(indicator: Tensor, label: Tensor, reps: int = 1, lab32: Optional[Tensor] = None) -> Tensor:
     """Marks `indicator` ([reps * N, modes]) as F.one_hot(label) repeated `reps` times: CodeBatch.run_any then gathers codebook
     rows by label instead of multiplying through every mode (the tensor is returned; the mark does not survive slicing)."""
-    indicator._mcgen_onehot = (label, int(reps))
+    indicator._mcgen_onehot = (label, int(reps), lab32)
     return indicator
 
 
@@ -337,13 +340,16 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
                gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
                tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
                out: Optional[Tensor] = None, kmajor: int = 0, ycmap: Optional[Tensor] = None,
-               y_group: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
+               y_group: int = 0, wsel: Optional[Tensor] = None, order: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None).  `kmajor`: `wimg` is the K-major image
     (prep_weight_k, segments concatenated); 1: every segment carries a compaction map and is compacted while staged;
     2: segments hold ALREADY compacted channels (Seg.cw, cmap) or are dense.  `ycmap` (+ `cy` = compacted pitch): the
     output keeps, per image, only the channels of that map, compacted (forward-only passes).  `y_group` (image head only):
     `out` holds 2 N images and output image n lands in slot (n // y_group) * 2 * y_group + y_group + n % y_group -- the
-    second halves of N / y_group paired [real (+) generated] batches (mcgen_conv_t.y_group)."""
+    second halves of N / y_group paired [real (+) generated] batches (mcgen_conv_t.y_group).
+    `wsel` (int32 [N]) + `order` (int32 [N], a permutation; optional): per-mode dense weight sets -- `wimg` holds S images of
+    the segments' (compacted) shapes back to back, the image walked at position i is order[i] and multiplies weight set
+    wsel[i] (mcgen_conv_t.wsel: bf16, software-pipelined form only)."""
     s0 = segs[0]
     n = s0.x.shape[0]
     h = s0.x.shape[1] * (2 if s0.ups else 1)
@@ -366,7 +372,14 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
         need = sum(s.ksize * s.ksize * ((s.cw or s.x.shape[-1]) + 1) for s in segs) * pad16(cout)
     else:
         need = sum(((s.x.shape[-1] + 31) // 32) * s.ksize * s.ksize for s in segs) * pad16(cout) * 32
-    if wimg.numel() != need:
+    if wsel is not None:
+        if wsel.dtype != torch.int32 or wsel.numel() != n or (order is not None and (order.dtype != torch.int32 or order.numel() != n)):
+            raise _lib.McgenError('wsel / order must be int32 [N]')
+        if wimg.numel() % need:
+            raise _lib.McgenError(f'weight sets: {wimg.numel()} elements are not a multiple of one image ({need})')
+    elif order is not None:
+        raise _lib.McgenError('order comes with wsel')
+    elif wimg.numel() != need:
         raise _lib.McgenError(f'weight image has {wimg.numel()} elements, the segments need {need}')
     y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=dtype, device=s0.x.device)
     if y_group:
@@ -389,6 +402,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     p.tanh_out, p.stats_mode = int(tanh), stats_mode
     p.w_layout = int(kmajor)
     p.y_group = int(y_group)
+    p.wsel, p.wsel_stride, p.order = _p(wsel), (need if wsel is not None else 0), _p(order)
     p.ycmap, p.ycmap_stride = None, 0
     if ycmap is not None:
         if ycmap.dtype != torch.int16 or tuple(ycmap.shape) != (n, cmap_stride(pad8(cout))):
@@ -956,13 +970,19 @@ class PrepBatch:
         for d, job in zip(arr, jobs):
             w, img, transpose, row_perm, sidx, wscale = job[:6]
             kmajor = bool(job[6]) if len(job) > 6 else False          # K-major image (mode-compacted launches)
+            kmap, kcount = (job[7], int(job[8])) if len(job) > 8 and job[7] is not None else (None, 0)
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
-            want = weight_image_k_elems(cout, cin, ks) if kmajor else weight_image_elems(cout, cin, ks, transpose)
+            if kmap is not None:                                      # a mode's compacted image: input channel k <- kmap[k], k < kcount
+                assert not kmajor and not transpose and row_perm == 1 and kmap.dtype == torch.int16 and kmap.numel() >= kcount
+                want = weight_image_elems(cout, kcount, ks, False)
+            else:
+                want = weight_image_k_elems(cout, cin, ks) if kmajor else weight_image_elems(cout, cin, ks, transpose)
             assert img.numel() == want and img.dtype == dtype and not (kmajor and (transpose or row_perm != 1))
             d.w, d.image = _f32(w), _p(img)
             d.Cout, d.Cin, d.ksize, d.transpose, d.row_perm, d.sigma_idx = cout, cin, ks, int(transpose), row_perm, sidx
             d.wscale, d.layout = float(wscale), int(kmajor)
+            d.kmap, d.kcount = _p(kmap), kcount
         self.key = tuple((w.data_ptr(), img.data_ptr()) for w, img, *_ in jobs)
         self.table = _struct_table(arr, jobs[0][0].device)
         self.n = len(jobs)

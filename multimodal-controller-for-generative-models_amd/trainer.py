@@ -262,19 +262,21 @@ class GANTrainer:
         n = x2.t.shape[0] // 2
         x2.t[n:].copy_(fakes.t[j * n:(j + 1) * n])
 
-    def indicators(self, label: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None):
+    def indicators(self, label: torch.Tensor, groups: int, out: Optional[torch.Tensor] = None, lab32: Optional[torch.Tensor] = None):
         """F.one_hot(label, classes).float() (mcgan.py:196,201) max(2, groups) times back to back, ONE launch: the
         indicator of the batch, of the paired 2N batch and of the grouped generator pass are prefixes of it.
         -> (ind [N], ind2 [2N], ind_rep [groups * N])"""
         n = label.shape[0]
         reps = max(2, groups)
         if label.is_cuda:
-            allr = ops.onehot_rep(label, self.classes, reps, out=out)
+            if lab32 is None:
+                lab32 = torch.empty(reps * n, dtype=torch.int32, device=label.device)
+            allr = ops.onehot_rep(label, self.classes, reps, out=out, lab32=lab32)
         else:
-            allr = F.one_hot(label, self.classes).float().repeat(reps, 1)
+            allr, lab32 = F.one_hot(label, self.classes).float().repeat(reps, 1), None
         # the engines may gather codebook rows by label instead of multiplying through every mode (ops.onehot_hint)
         return (ops.onehot_hint(allr[:n], label, 1), ops.onehot_hint(allr[:2 * n], label, 2),
-                ops.onehot_hint(allr[:groups * n], label, groups))
+                ops.onehot_hint(allr[:groups * n], label, groups, None if lab32 is None else lab32[:groups * n]))
 
     # compute = forward + backward into the flat gradient buffer; apply = Adam (+ weight images).
     # The *_iter forms are generators: they yield (lo, hi, last) whenever grad[lo:hi] is final (see _reduce_bucket).
@@ -449,7 +451,8 @@ class GraphedGANTrainer(GANTrainer):
         self.s_label = label.clone()
         self.s_indall = torch.empty((max(2, fg) * n, self.classes), dtype=torch.float32, device=dev)
         # indicator of the batch / of the paired 2N batch / of the generator pass(es): prefixes of one buffer
-        self.s_ind, self.s_ind2, self.s_indg = self.indicators(self.s_label, fg, out=self.s_indall)
+        self.s_lab32 = torch.empty(max(2, fg) * n, dtype=torch.int32, device=dev)
+        self.s_ind, self.s_ind2, self.s_indg = self.indicators(self.s_label, fg, out=self.s_indall, lab32=self.s_lab32)
         self.s_z = torch.randn(n, self.latent, device=dev)                  # latent of the generator update
         self.s_zd = torch.randn(fg * n, self.latent, device=dev)            # latents of fg discriminator updates
         # real (+) generated batches of the fg discriminator updates that share a generator pass
@@ -477,7 +480,7 @@ class GraphedGANTrainer(GANTrainer):
 
         def generator_pass():
             """The iteration's inputs in the engines' layouts, then the fg generator forwards of the D updates."""
-            self.indicators(self.s_label, fg, out=self.s_indall)
+            self.indicators(self.s_label, fg, out=self.s_indall, lab32=self.s_lab32)
             if _NHWC_PAIR:
                 self.pair_buffers(self.s_img, fg)                            # the real batch -> every first half of s_xbuf
                 self.s_codes = self.deng.pair_codes(self.s_ind2) if _PAIR_D else None

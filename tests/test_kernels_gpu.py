@@ -420,6 +420,10 @@ def test_label_gather_equals_indicator_product():
         assert float((a[0][n:] / a[0][:n].clamp_min(1e-9)).max()) > 1.0 or float(scale[0]) <= 1.0
         plain = cb.run_any(ind, scale, n)                   # no hint: the product path
         assert all(torch.equal(x, y) for x, y in zip(a, plain))
+        # the one launch that builds the repeated indicator also hands out the labels as int32 (conv_fused's wsel)
+        lab32 = torch.full((3 * n,), -1, dtype=torch.int32, device='cuda')
+        rep3 = ops.onehot_rep(label, modes, 3, lab32=lab32)
+        assert torch.equal(rep3, F.one_hot(label, modes).float().repeat(3, 1)) and torch.equal(lab32, label.int().repeat(3))
 
 
 def test_bn_finalize_and_backward():
@@ -1492,6 +1496,75 @@ def test_mode_compacted_conv_b_two_segments(n, h, t):
     a1 = _q(ref_prologue(_q(x, dtype), None, None, False, code1, True), dtype)
     ref = F.conv2d(a2, _q(w2, dtype), b, padding=1) + F.conv2d(a1, _q(ws, dtype))
     _assert_close(ops.to_nchw(yc, c), ref, dtype, 'compacted conv_b vs fp32 reference')
+
+
+@pytest.mark.parametrize('ordered', [False, True])
+@pytest.mark.parametrize('two_seg', [False, True])
+def test_per_mode_weight_sets_match_the_masked_convolution(two_seg, ordered):
+    """mcgen_conv_t.wsel / order + mcgen_prep_t.kmap: activations stored compacted per image (the channels the image's mode
+    keeps, in order, zero-padded to the pitch), ONE dense weight image per mode whose input channels are that mode's active
+    ones -- the software-pipelined form with a dense K loop over the pitch -- against F.conv2d on the masked dense tensors
+    (modules.py:71-76: x * code in front of the convolution), with and without the mode-sorted walk, one 3x3 segment and
+    3x3 ++ 1x1(Up(x)) (GenResBlock's conv_b ++ shortcut, mcgan.py:20-30)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(2101 + int(two_seg))
+    n, h, c, co, modes = 64, 32, 256, 256, 5
+    cb = (torch.rand(modes, c, generator=g) < 0.5).float()
+    cb[0, c - 1] = 1.0; cb[1, 0] = 1.0
+    cap = (int(cb.sum(1).max()) + 31) // 32 * 32
+    label = torch.randint(0, modes, (n,), generator=g)
+    cmaps = ops.mc_cmap(cb.cuda())                                   # records of the codebook rows = of the modes
+
+    def compact(x):                                                  # [N, C, H, W] -> NHWC [N, H, W, cap]: active channels first
+        out = torch.zeros(x.shape[0], x.shape[2], x.shape[3], cap)
+        for i in range(x.shape[0]):
+            idx = torch.nonzero(cb[label[i]]).flatten()
+            out[i, :, :, :idx.numel()] = x[i, idx].permute(1, 2, 0)
+        return out.to(dtype).cuda().contiguous()
+
+    def mode_sets(w, ks):
+        per = ops.weight_image_elems(w.shape[0], cap, ks)
+        return per, [(w.cuda(), None, False, 1, -1, 1.0, False, cmaps[m, c:], cap) for m in range(modes)]
+    x = _hot(_rnd(g, n, c, h, h))
+    w3, b = _rnd(g, co, c, 3, 3) * 0.03, _rnd(g, co)
+    code = cb[label]
+    ref = F.conv2d(_q(_q(x, dtype) * code[:, :, None, None], dtype), _q(w3, dtype), b, padding=1)
+    segs = [ops.Seg(compact(x))]
+    per3, jobs3 = mode_sets(w3, 3)
+    per = per3
+    if two_seg:
+        xl = _rnd(g, n, c, h // 2, h // 2)
+        w1 = _rnd(g, co, c, 1, 1) * 0.08
+        ref = ref + F.conv2d(_q(_q(xl, dtype) * code[:, :, None, None], dtype).repeat_interleave(2, 2).repeat_interleave(2, 3), _q(w1, dtype))
+        segs.append(ops.Seg(compact(xl), ksize=1, ups=True))
+        per1, jobs1 = mode_sets(w1, 1)
+        per = per3 + per1
+    sets = torch.empty(modes, per, dtype=dtype, device='cuda')
+    jobs = []
+    for m in range(modes):
+        j = list(jobs3[m]); j[1] = sets[m, :per3]; jobs.append(tuple(j))
+        if two_seg:
+            j = list(jobs1[m]); j[1] = sets[m, per3:]; jobs.append(tuple(j))
+    ops.PrepBatch(jobs, dtype).run()
+    lab32 = label.to(torch.int32).cuda()
+    if ordered:
+        srt, oi = torch.sort(lab32, stable=True)
+        wsel, order = srt.contiguous(), oi.to(torch.int32)
+    else:
+        wsel, order = lab32, None
+    (y, st), tiles = _conv_logged(ops, segs, sets.view(-1), co, bias=b.cuda(), stats_mode=1, wsel=wsel, order=order)
+    assert tiles == [(256, 256)], tiles
+    got = ops.to_nchw(y, co)
+    _assert_close(got, ref, dtype, 'per-mode weight sets')
+    # the statistics rows keep their true tile index whatever the walk
+    s = st.double().sum(0).cpu()
+    np.testing.assert_allclose(s[0, :co], ref.double().sum((0, 2, 3)), rtol=2e-2, atol=4e-3 * float(ref.abs().sum((0, 2, 3)).max()))
+    tile_sum = st[:, 0, :co].double().cpu().view(n, 4, co).sum(1)                # four 256-pixel tiles per 32x32 image
+    np.testing.assert_allclose(tile_sum, got.double().sum((2, 3)).cpu(), rtol=2e-2, atol=0.5)
+    # what the form refuses: fp32, small launches (no software-pipelined tile)
+    with pytest.raises(Exception):
+        ops.conv_fused([ops.Seg(compact(x)[:8])], sets.view(-1), co, bias=b.cuda(), wsel=lab32[:8].contiguous())
 
 
 def test_mode_compacted_conv_rejects_what_it_cannot_run():
