@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order + mcgen_prep_t.kmap (per-mode dense weight sets), mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -131,6 +131,15 @@ typedef struct {
     const int32_t* order;  /* [N] or NULL: a permutation of the images -- workgroups walk images order[0], order[1], ...; images of
                             * one mode made adjacent keep that mode's weight set in L2 while they run.  Outputs, statistics rows
                             * and every per-image input keep their true image index.                                     */
+    const int16_t* yperm;  /* [sets][yperm_stride] or NULL (with wsel, no order): the weight ROWS of set s were permuted at prep
+                            * time (mcgen_prep_t.rmap = yperm + s * yperm_stride: image row r holds true output channel
+                            * yperm[s][r] -- the consumer's active channels first, in order, then the others), so the accumulators
+                            * come out in COMPACTED order: y (pitch Cy < Cout_w, a multiple of 8) receives columns 0 .. Cy - 1 with
+                            * plain 16-byte stores -- the compacted output of `ycmap` without its gather pass.  bias and the
+                            * statistics (pitch Cout_w) are indexed through the permutation, i.e. stay in true channel order.
+                            * Columns between an image's active count and Cy hold channels its consumer masks: the consumer's
+                            * weight image has zero columns there (mcgen_prep_t.kmap).  Same restrictions as ycmap.       */
+    int32_t yperm_stride, reserved_;
 } mcgen_conv_t;
 
 /* number of M tiles (rows of `stats`) the launch of `p` will use.  Depends on the shape / mode fields only -- callers ask
@@ -237,6 +246,8 @@ typedef struct {
     const int16_t* kmap;            /* layout 0, transpose 0: NULL, or the image's input channel k is source channel kmap[k]    */
     int32_t kcount, _pad;           /* (k < kcount; kmap[k] >= Cin: a zero column) -- a mode's compacted weight image: kmap =
                                      * the cidx part of that mode's mcgen_mc_cmap record, kcount = the compacted pitch       */
+    const int16_t* rmap;            /* layout 0, transpose 0: NULL, or image row r is weight row rmap[r] (a permutation of the
+                                     * output channels: mcgen_conv_t.yperm)                                                    */
 } mcgen_prep_t;
 int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream);
 

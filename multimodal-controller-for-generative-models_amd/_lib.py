@@ -26,7 +26,8 @@ class Conv(C.Structure):
                 ('gscale', C.c_void_p), ('gshift', C.c_void_p), ('gmean', C.c_void_p), ('grstd', C.c_void_p),
                 ('tanh_out', C.c_int32), ('stats', C.c_void_p), ('stats_mode', C.c_int32), ('w_layout', C.c_int32),
                 ('ycmap', C.c_void_p), ('ycmap_stride', C.c_int32), ('y_group', C.c_int32), ('bias2', C.c_void_p),
-                ('wsel', C.c_void_p), ('wsel_stride', C.c_int64), ('order', C.c_void_p)]
+                ('wsel', C.c_void_p), ('wsel_stride', C.c_int64), ('order', C.c_void_p),
+                ('yperm', C.c_void_p), ('yperm_stride', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class Wgrad(C.Structure):
@@ -59,7 +60,7 @@ class Prep(C.Structure):
     _fields_ = [('w', C.c_void_p), ('image', C.c_void_p),
                 ('Cout', C.c_int32), ('Cin', C.c_int32), ('ksize', C.c_int32), ('transpose', C.c_int32),
                 ('row_perm', C.c_int32), ('sigma_idx', C.c_int32), ('wscale', C.c_float), ('layout', C.c_int32),
-                ('kmap', C.c_void_p), ('kcount', C.c_int32), ('_pad', C.c_int32)]
+                ('kmap', C.c_void_p), ('kcount', C.c_int32), ('_pad', C.c_int32), ('rmap', C.c_void_p)]
 
 
 class Code(C.Structure):

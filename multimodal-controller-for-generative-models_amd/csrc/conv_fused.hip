@@ -63,7 +63,10 @@ constexpr int YTAB_COLS = 320, YTAB_BYTES = YTAB_COLS * 2 + YTAB_COLS * 4;
 // faster than 0 on the step: not dispatched.)
 // YC (with MODE 1): compacted output -- the loop accumulates the statistics only, a gather pass per round stores, per pixel,
 // the channels of the image's map (the table sits behind the accumulator rows).
-template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0, int MODE = 0, bool YC = false>
+// YC == 2 (with MODE 1; mcgen_conv_t.yperm): the weight rows of the image's set were permuted at prep time, the tile's columns
+// ARE the compacted order -- the plain loop with the store limited to the first Cy columns, bias and the statistics rows
+// indexed through the permutation.
+template <typename T, typename C, int BM, int BN, int WM, int WN, bool POOL, int NP = 0, int MODE = 0, int YC = 0>
 __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const Geo& g, f32x4 (&acc)[C::FN][C::FM],
                                                    float* epi, int tid, int wm, int wn, int l15, int lg,
                                                    int tile_m, int cout0, float alpha) {
@@ -102,8 +105,20 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
         }
     };
     f32x2 bias[4], oc[4], gsc[4], gsh[4], gme[4], grs[4];
+    const int16_t* yperm = nullptr;
+    if constexpr (YC == 2) {
+        yperm = p.yperm + (size_t)p.wsel[g.n0] * p.yperm_stride;
+        const u32x4 c4 = *reinterpret_cast<const u32x4*>(yperm + co);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c0 = (int)(c4[i] & 0xffffu), c1 = (int)(c4[i] >> 16);
+            bias[i] = p.bias ? f32x2{p.bias[c0], p.bias[c1]} : f32x2{0.f, 0.f};
+            if (p.bias2) bias[i] += f32x2{p.bias2[c0], p.bias2[c1]};
+        }
+    } else {
     ld4(p.bias, 0.f, bias);
-    if (p.bias2) {
+    }
+    if (YC != 2 && p.bias2) {
         f32x2 b2[4];
         ld4(p.bias2, 0.f, b2);
 #pragma unroll
@@ -120,11 +135,11 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
     for (int i = 0; i < 4; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     const int lgWo = POOL ? g.lgW - 1 : g.lgW, lgTHWo = POOL ? g.lgTHW - 2 : g.lgTHW;
 
-    static_assert(!YC || (MODE == 1 && !POOL), "a compacted output takes bias and statistics only");
+    static_assert(YC == 0 || (MODE == 1 && !POOL), "a compacted output takes bias and statistics only");
     int16_t* ycol = reinterpret_cast<int16_t*>(epi + PPX * EP);       // tile column (or -1) and bias of every output slot
     float* ybias = reinterpret_cast<float*>(ycol + YTAB_COLS);
     const int ycgrp = Cy >> 3;
-    if constexpr (YC) {
+    if constexpr (YC == 1) {
         const int16_t* cidx = p.ycmap + (size_t)g.n0 * p.ycmap_stride + ((p.Cout + 7) & ~7);   // record: [cpos: C][cidx: C + 32]...
         for (int j = tid; j < Cy; j += NT) {
             const int ct = (int)(uint16_t)cidx[j];                     // true channel (the zero row's index beyond the image's count)
@@ -234,10 +249,11 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
                 for (int i = 0; i < 4; ++i) { s1[i] += v[i]; s2[i] = __builtin_elementwise_fma(v[i], v[i], s2[i]); }
             }
             const float vo[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
-            if constexpr (!YC) E::store8(yb + mt * Cy, vo);
+            if constexpr (YC == 0) E::store8(yb + mt * Cy, vo);
+            if constexpr (YC == 2) { if (ch * 8 < Cy) E::store8(yb + mt * Cy, vo); }
             if constexpr (!PLAIN) if ((it + 1) % PB == 0 && it + 1 < ITERS) request(it + 1);        // the next batch's rows
         }
-        if constexpr (YC) {
+        if constexpr (YC == 1) {
             // gather: output slot group jg of local row mo <- tile columns ycol[8 jg ..] (zeros beyond the image's count); reads
             // the accumulator rows only, like the loop above: no barrier between them
             T* y0 = reinterpret_cast<T*>(p.y) + opix0 * Cy;
@@ -270,8 +286,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const mcgen_conv_t& p, const 
             float a = 0.f, b = 0.f;
             for (int r = 0; r < PROWS; ++r) { const f32x2 t = red[r * BN + c]; a += t[0]; b += t[1]; }
             const int spitch = YC ? p.Cout_w : Cy;                    // (compacted output: statistics over the true channels)
-            p.stats[((size_t)tile_m * 2 + 0) * spitch + cout0 + c] = a;
-            p.stats[((size_t)tile_m * 2 + 1) * spitch + cout0 + c] = b;
+            const int ct = YC == 2 ? (int)yperm[c] : cout0 + c;
+            p.stats[((size_t)tile_m * 2 + 0) * spitch + ct] = a;
+            p.stats[((size_t)tile_m * 2 + 1) * spitch + ct] = b;
         }
     }
 }
@@ -296,8 +313,15 @@ __device__ __forceinline__ void conv_epilogue(const mcgen_conv_t& p, const Geo& 
     if constexpr (sizeof(T) == 2) {
         // compacted output of a whole tile (validated: bf16, one image, every channel in this tile, bias and statistics only)
         if (p.ycmap && cout0 == 0 && BN == p.Cout && g.n0 < N && p.Cy <= YTAB_COLS) {
-            conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP, 1, true>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+            conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP, 1, 1>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
             return;
+        }
+        if constexpr (NP > 0) {
+            // weight rows permuted per set (validated: bf16 pp form, one image per tile, every channel in this tile, bias and statistics only)
+            if (p.yperm) {
+                conv_epilogue_fast<T, C, BM, BN, WM, WN, false, NP, 1, 2>(p, g, acc, epi, tid, wm, wn, l15, lg, tile_m, cout0, alpha);
+                return;
+            }
         }
     }
     if (!p.ycmap && !p.tanh_out && (p.Cout & 7) == 0 && cout0 + BN <= p.Cout && g.n0 + g.TI <= N && (!p.ocode || g.TI == 1)) {
@@ -752,7 +776,9 @@ void conv_dma1_kernel(const mcgen_conv_t p, const int a_bytes) {
 #define MCGEN_BIG_WAVES 0
 #endif
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BM * BN >= 256 * 128) ? 2 : ((MCGEN_BIG_WAVES && BM * BN >= 256 * 256) ? MCGEN_BIG_WAVES : 0))
+// (the 64 x 64 tile of 8 waves: two workgroups per CU = 4 waves per SIMD, i.e. at most 128 registers -- the allocator sits at
+//  110 .. 131 depending on unrelated code; at 131 the 8x8 input-gradient launches of the generator ran 25 -> 44 us)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BM * BN >= 256 * 128) ? 2 : ((BM * BN <= 64 * 64 && WM * WN == 8) ? 4 : ((MCGEN_BIG_WAVES && BM * BN >= 256 * 256) ? MCGEN_BIG_WAVES : 0)))
 void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
     using C = ConvCfg<T, BM, BN, WM, WN>;
     using M = Mma<T>;
@@ -915,7 +941,7 @@ void conv_dma3_kernel(const mcgen_conv_t p, const int a_bytes) {
 // step; here the windows of three consecutive chunks are staged side by side and their three weight tiles (which are
 // consecutive in the image) form one DMA group.  A separate kernel: sharing dma3's code cost the 3x3 launches 1-3 %.
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN)
+__global__ __launch_bounds__(64 * WM * WN, (BM * BN <= 64 * 64 && WM * WN == 8) ? 4 : 0)
 void conv_dma3g_kernel(const mcgen_conv_t p, const int a_bytes) {
     constexpr bool G3 = true;
     constexpr int g1 = 3;
@@ -2590,15 +2616,21 @@ static int validate(const mcgen_conv_t* p) {
     MCGEN_CHECK(p->stats_mode == 0 || p->stats, "conv_fused: stats_mode set without a stats buffer");
     MCGEN_CHECK(p->w_layout >= 0 && p->w_layout <= 2, "conv_fused: unknown weight layout %d", p->w_layout);
     if (p->wsel || p->order) {
-        MCGEN_CHECK(p->w_layout == 0 && p->y_group == 0, "conv_fused: per-mode weight sets (wsel / order) go with the chunked weight image (w_layout 0)");
+        MCGEN_CHECK(p->w_layout == 0 && (p->y_group == 0 || !p->order), "conv_fused: per-mode weight sets (wsel / order) go with the chunked weight image (w_layout 0)");
         MCGEN_CHECK(!p->wsel || p->wsel_stride > 0, "conv_fused: wsel needs wsel_stride");
+    }
+    if (p->yperm) {
+        MCGEN_CHECK(p->wsel && !p->order && !p->ycmap, "conv_fused: permuted weight rows (yperm) come with wsel, without order / ycmap");
+        MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out, "conv_fused: a compacted output takes bias and statistics only");
+        MCGEN_CHECK(p->Cy % 8 == 0 && p->Cy <= p->Cout && p->Cout % 8 == 0 && p->Cout_w == p->Cout && p->Cout_w <= 256 && p->yperm_stride >= p->Cout && p->yperm_stride % 8 == 0,
+                    "conv_fused: yperm: bad pitch %d / stride %d for %d channels", p->Cy, p->yperm_stride, p->Cout);
     }
     if (p->ycmap) {
         MCGEN_CHECK(!p->pool && !p->res && !p->gate_x && !p->ocode && !p->tanh_out && !p->bias2, "conv_fused: a compacted output takes bias and statistics only");
         MCGEN_CHECK(p->Cy % 32 == 0 && p->Cy <= round_up(p->Cout, 8) + 32 && p->ycmap_stride >= 2 * round_up(p->Cout, 8) + 32,
                     "conv_fused: compacted output: bad pitch %d / map stride %d", p->Cy, p->ycmap_stride);
         MCGEN_CHECK(p->Cout_w <= 256, "conv_fused: a compacted output needs all channels in one tile");
-    } else {
+    } else if (!p->yperm) {
         MCGEN_CHECK(p->Cy >= p->Cout, "conv_fused: Cy must be >= Cout");
     }
     return 0;
@@ -2632,7 +2664,8 @@ extern "C" int mcgen_conv_tile(const mcgen_conv_t* p, int dtype, int* bm, int* b
 }
 
 extern "C" int mcgen_conv_form(const mcgen_conv_t* p, int dtype) {
-    if (!p || p->w_layout != 0 || p->wsel || p->order) return 0;
+    if (!p || p->w_layout != 0 || p->order) return 0;
+    if (p->wsel) return mcgen_conv_head_ok(p, dtype) ? 5 : 0;
     if (mcgen_conv_skinny_ok(p, dtype)) return 1;
     if (mcgen_conv_smap_ok(p, dtype)) return 2;
     if (mcgen_conv_px1_bm(p, dtype)) return 3;
@@ -2651,11 +2684,13 @@ extern "C" int mcgen_conv_fused(const mcgen_conv_t* p, int dtype, void* stream) 
     if (p->w_layout == 1) return dispatch_mc(p, dtype, reinterpret_cast<hipStream_t>(stream));
     if (p->w_layout == 2) return dispatch_gk(p, dtype, reinterpret_cast<hipStream_t>(stream));
     for (int s = 0; s < p->nseg; ++s) MCGEN_CHECK(p->seg[s].cmap == nullptr, "conv_fused: a compaction map needs a K-major launch (w_layout 1 or 2)");
+    if (p->wsel && mcgen_conv_head_ok(p, dtype)) return mcgen_conv_head(p, reinterpret_cast<hipStream_t>(stream));
     if (p->wsel || p->order) {
         const TilePick tw = pick_tile(p, dtype);
         MCGEN_CHECK(dtype == MCGEN_BF16 && tw.pipe == 20, "conv_fused: per-mode weight sets need the software-pipelined bf16 form "
                     "(3x3 first segment of 64 .. 512 channels in whole chunks, 16x16 / 32x32 maps, >= 65536 pixels)");
         if (p->ycmap) MCGEN_CHECK(tw.BM <= p->H * p->W && p->Cout_w <= tw.BN, "conv_fused: compacted output: the %dx%d tile must hold all %d channels", tw.BM, tw.BN, p->Cout_w);
+        if (p->yperm) MCGEN_CHECK(tw.BM <= p->H * p->W && p->Cout_w == tw.BN, "conv_fused: yperm: the %dx%d tile must hold exactly the %d channels", tw.BM, tw.BN, p->Cout_w);
         return dispatch(p, dtype, tw, reinterpret_cast<hipStream_t>(stream));
     }
     if (mcgen_conv_skinny_ok(p, dtype)) return mcgen_conv_skinny(p, reinterpret_cast<hipStream_t>(stream));

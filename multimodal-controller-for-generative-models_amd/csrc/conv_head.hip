@@ -11,6 +11,8 @@
 //   * 54 KB of LDS and 116 registers: two workgroups per CU;
 //   * the chunk's nine 16 x 32 weight fragments come straight from the [chunk][tap][16][32] image into registers;
 //   * the epilogue stores 8 bytes per lane straight from the accumulators (channels 0 .. 3 | 4 .. 7 of the 8-channel pitch).
+// In the grouped forward-only pass the input arrives COMPACTED (160 of 256 channels, per-image affine rows from mcgen_mc_affine,
+// the image's mode's own weight image: mcgen_conv_t.wsel): 5 chunks instead of 8.
 // Measured 151-178 us at N = 640 (2.0-2.3 TB/s of input; same-box 3 % under the general tile's step).  What did NOT move it
 // (same-box, tools/so_shapes.sh): pixels of two chunks in flight, weight fragments a chunk ahead (192 registers: one
 // workgroup per CU, 201 us), one workgroup per CU with the shallow pipeline, 64-channel steps (whole 128-byte lines per
@@ -81,7 +83,8 @@ void conv_head_kernel(const mcgen_conv_t p) {
 
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     // weight fragment (chunk q, tap j): rows l15 (16 channels), elements 8 lg .. of [chunk][tap][16][32]
-    const bf16_t* wimg = reinterpret_cast<const bf16_t*>(p.w) + (size_t)l15 * MCGEN_CK + lg * 8;
+    // (per-mode weight sets, mcgen_conv_t.wsel: the image's own dense image over its compacted channels)
+    const bf16_t* wimg = reinterpret_cast<const bf16_t*>(p.w) + (p.wsel ? (size_t)p.wsel[n] * (size_t)p.wsel_stride : 0) + (size_t)l15 * MCGEN_CK + lg * 8;
     load_chunk(0);
     write_chunk(smem);
 #pragma unroll 1
@@ -136,7 +139,7 @@ int mcgen_conv_head_ok(const mcgen_conv_t* p, int dtype) {
     const mcgen_seg_t& g = p->seg[0];
     if (g.ksize != 3 || g.ups || g.cmap || g.C % 32 || g.C < 64 || g.group_n < 0 || (g.group_n > 0 && p->N % g.group_n)) return 0;
     if (p->H != HD_W || p->W != HD_W || p->Cout > 8 || p->Cout_w != 16 || p->Cy != 8) return 0;
-    if (p->pool || p->res || p->ocode || p->gate_x || p->stats_mode || p->ycmap) return 0;
+    if (p->pool || p->res || p->ocode || p->gate_x || p->stats_mode || p->ycmap || p->order) return 0;
     if ((long)p->N * HD_W * HD_W * g.C >= (1L << 31)) return 0;          // (32-bit element offsets)
     if (p->y_group < 0 || (p->y_group > 0 && p->N % p->y_group)) return 0;
     return 1;

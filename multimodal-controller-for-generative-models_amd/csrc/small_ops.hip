@@ -159,26 +159,38 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
     const int rows_w = (rows + 15) / 16 * 16;
     const int nchunk = (((kdim + 7) / 8 * 8) + MCGEN_CK - 1) / MCGEN_CK;
     const float sc = (d.sigma_idx >= 0) ? d.wscale / sigma_base[d.sigma_idx] : d.wscale;
-    // One thread per (row, k) pair of the image: it reads the pair's ntap master weights -- contiguous floats -- once and
-    // writes them to the ntap tap planes; threads run along k, so every plane receives 64-byte runs.  (The element-per-
-    // thread form did a stride-ntap gather and five integer divisions per element: 11 us per launch for 1 M weights.)
-    const size_t pairs = (size_t)nchunk * rows_w * MCGEN_CK;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % MCGEN_CK); size_t t = i / MCGEN_CK;
-        const int row = (int)(t % rows_w); const int q = (int)(t / rows_w);
-        const int k = q * MCGEN_CK + col;
+    // A block step = 8 rows x 32 k of one chunk: thread (row, k) reads the pair's ntap master weights -- contiguous floats,
+    // lanes along k -- once, the step's ntap planes meet in LDS, and each plane's 8 rows (contiguous in the image: 512 bytes
+    // of bf16) leave as 16-byte stores.  (History: element-per-thread -- a stride-ntap gather and five integer divisions
+    // per element, 11 us per launch for 1 M weights; (row, k)-per-thread with 2-byte stores -- 45 us for the 70 images of
+    // the generator's pass; 8 k per thread -- 64 cache lines per load instruction, 3x slower still.)
+    const int16_t* __restrict__ rmap = transpose ? nullptr : d.rmap;        // (permuted output channels: forward orientation only)
+    __shared__ __attribute__((aligned(16))) T stage[9][8 * MCGEN_CK];
+    const int rgroups = rows_w / 8;
+    const int groups = nchunk * rgroups;
+    const int r8 = threadIdx.x >> 5, col = threadIdx.x & 31;
+    constexpr int UPT = 8 * MCGEN_CK * (int)sizeof(T) / 16;                 // 16-byte units per plane of a step
+    for (int gi = blockIdx.x; gi < groups; gi += gridDim.x) {
+        const int rg = gi % rgroups, q = gi / rgroups;
+        const int row = rg * 8 + r8, k = q * MCGEN_CK + col;
         bool live = row < rows && k < kdim;
         int co = transpose ? k : row;
         int ci = transpose ? row : k;
         if (kmap && live) { ci = kmap[k]; live = ci >= 0 && ci < Cin; }
+        if (rmap && live) co = rmap[co];
         if (row_perm > 1) { const int Cc = Cout / row_perm; co = (co % Cc) * row_perm + co / Cc; }
         const float* src = live ? w + ((size_t)co * Cin + ci) * ntap : w;          // (padding rows / columns: zeros, no read)
-        T* dst = img + ((size_t)q * ntap * rows_w + row) * MCGEN_CK + col;
         for (int tap = 0; tap < ntap; ++tap) {
             const int mtap = transpose ? (ntap - 1 - tap) : tap;                // (the flipped filter: tap (kh, kw) <- (KS-1-kh, KS-1-kw))
-            const float v = live ? src[mtap] * sc : 0.f;
-            dst[(size_t)tap * rows_w * MCGEN_CK] = Elem<T>::from_f(v);
+            stage[tap][r8 * MCGEN_CK + col] = Elem<T>::from_f(live ? src[mtap] * sc : 0.f);
         }
+        __syncthreads();
+        for (int u = threadIdx.x; u < ntap * UPT; u += blockDim.x) {
+            const int tap = u / UPT, wv = u - tap * UPT;
+            char* dst = reinterpret_cast<char*>(img + ((size_t)(q * ntap + tap) * rows_w + rg * 8) * MCGEN_CK) + wv * 16;
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(stage[tap]) + wv * 16);
+        }
+        __syncthreads();
     }
 }
 

@@ -103,7 +103,7 @@ _LOWRES_SC_BWD = _flag('MCGEN_LOWRES_SC_BWD', '1') != '0'
 # per-mode DENSE weight images for the launches that read compacted activations (instead of the gathered-K form's per-sample
 # row gather): needs one-hot indicators (the mode of an image is its label) and few modes (10 x 0.8 MB per layer at CIFAR-10)
 _PM = _flag('MCGEN_PM', '1') != '0'
-_PM_ORDER = _flag('MCGEN_PM_ORDER', '0') == '1'      # walk the images mode by mode (their weight set stays in L2): measured neutral, opt-in
+_PM_HEAD = _flag('MCGEN_PM_HEAD', '1') != '0'         # the last block stores its output compacted for the image head
 _PM_MAX_MODES = 16
 class Nhwc:
     """An image batch in the engines' own layout ([N, H, W, C padded to 8] of the compute dtype, padding channels zero) with
@@ -193,7 +193,7 @@ class GeneratorEngine:
         for b in res:
             ws += [b.conv[4].module.weight, b.conv[8].module.weight, b.shortcut[2].module.weight,
                    b.conv[8].module.bias, b.shortcut[2].module.bias]
-        cbs = [m.codebook for b in res for m in (b.mc_1, b.mc_2)] if self._pm_enabled() else []
+        cbs = ([m.codebook for b in res for m in (b.mc_1, b.mc_2)] + [head_mc.codebook]) if self._pm_enabled() else []
         pm_key = tuple((c.data_ptr(), tuple(c.shape), c._version) for c in cbs)
         key = (self.dtype, tuple((w.data_ptr(), w._version) for w in ws), pm_key)
         if not force and key == self._img_key:
@@ -258,17 +258,30 @@ class GeneratorEngine:
                     n2 = ops.weight_image_elems(w2.shape[0], cap_h, 3)
                     ns = ops.weight_image_elems(wsc.shape[0], cap_x if x_compact else wsc.shape[1], 1)
                     slot = buf(f'b{i}.w2sm', modes * (n2 + ns), dt).view(modes, n2 + ns)
+                    # output channels in the order their consumer keeps them (mcgen_conv_t.yperm): h by mc_2, y by the next mask
+                    ymc = self._y_mc(i, True)
+                    py = self._mode_perms(ymc) if ymc is not None else None
+                    ph = self._mode_perms(b.mc_2)
                     for m in range(modes):
-                        jobs.append((w2, slot[m, :n2], False, 1, -1, 1.0, False, cm2[m, w2.shape[1]:], cap_h))
+                        ry = None if py is None else py[m]
+                        jobs.append((w2, slot[m, :n2], False, 1, -1, 1.0, False, cm2[m, w2.shape[1]:], cap_h, ry))
                         if x_compact:
-                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0, False, cm1[m, wsc.shape[1]:], cap_x))
+                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0, False, cm1[m, wsc.shape[1]:], cap_x, ry))
                         else:
-                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0))
+                            jobs.append((wsc, slot[m, n2:], False, 1, -1, 1.0, False, None, 0, ry))
                     if x_compact:
                         n1 = ops.weight_image_elems(w1.shape[0], cap_x, 3)
                         slot1 = buf(f'b{i}.w1m', modes * n1, dt).view(modes, n1)
                         for m in range(modes):
-                            jobs.append((w1, slot1[m], False, 1, -1, 1.0, False, cm1[m, w1.shape[1]:], cap_x))
+                            jobs.append((w1, slot1[m], False, 1, -1, 1.0, False, cm1[m, w1.shape[1]:], cap_x, ph[m]))
+                # the image head behind a compacting last block (conv_head.hip reads 5 chunks instead of 8)
+                if res and self._y_mc(len(res) - 1, True) is head_mc and f'b{len(res) - 1}.w2sm' in self.img:
+                    cap_o, cmo = self._cap(head_mc), self._mode_maps(head_mc)
+                    modes = head_mc.codebook.shape[0]
+                    nh = ops.weight_image_elems(head_conv.out_channels, cap_o, 3)
+                    sloth = buf('headm', modes * nh, dt).view(modes, nh)
+                    for m in range(modes):
+                        jobs.append((head_conv.weight, sloth[m], False, 1, -1, 1.0, False, cmo[m, head_conv.in_channels:], cap_o))
             if self._mc_enabled():
                 # K-major images of the blocks whose maps are large enough for a tile to lie inside one image (the
                 # mode-compacted kernel gathers the active channels' rows from them): conv_a, and conv_b ++ shortcut
@@ -333,6 +346,32 @@ class GeneratorEngine:
         lin, res, head_bn, head_mc, head_conv = self._layers()
         return _PM and self._gk_enabled() and res[0].mc_1.codebook.shape[0] <= _PM_MAX_MODES
 
+    def _y_mc(self, i: int, pm: bool):
+        """The MultimodalController that masks block i's OUTPUT in front of its next convolutions, when those read it compacted
+        (the next block's mc_1, or -- per-mode weight sets only -- the image head's), else None."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        if not self._gk_block(i) or self._cap(res[i].mc_2) is None:
+            return None
+        if i + 1 < len(res):
+            nxt = res[i + 1]
+            ok = self._gk_block(i + 1) and self._cap(nxt.mc_2) is not None and self._cap(nxt.mc_1) is not None
+            return nxt.mc_1 if ok else None
+        # what conv_head.hip takes: 32x32 maps, <= 8 output channels, whole 32-channel chunks
+        ok = pm and _PM_HEAD and self._pm_enabled() and (8 << i) == 32 and head_conv.out_channels <= 8 \
+            and head_conv.in_channels % 32 == 0 and self._cap(head_mc) is not None and self._cap(head_mc) >= 64
+        return head_mc if ok else None
+
+    def _mode_perms(self, mc):
+        """int16 [modes, C]: per codebook row, its active channels in order, then the others (mcgen_conv_t.yperm /
+        mcgen_prep_t.rmap).  Cached per codebook version."""
+        cb = mc.codebook
+        key = (cb.data_ptr(), tuple(cb.shape), cb._version)
+        cache = self.__dict__.setdefault('_perm_cache', {})
+        if cache.get(id(mc), (None,))[0] != key:
+            perm = torch.argsort((cb == 0).to(torch.int8), dim=1, stable=True).to(torch.int16).contiguous()
+            cache[id(mc)] = (key, perm)
+        return cache[id(mc)][1]
+
     def _mode_maps(self, mc):
         """Compaction records of the codebook's ROWS (ops.mc_cmap: int16 [modes, stride]; the cidx part starts at column C):
         the map of a one-hot sample is its mode's.  Cached per codebook version."""
@@ -369,6 +408,11 @@ class GeneratorEngine:
                 self._cap(b.mc_1); self._cap(b.mc_2)
                 if self._pm_enabled():
                     self._mode_maps(b.mc_1); self._mode_maps(b.mc_2)
+            self._cap(head_mc)
+            if self._pm_enabled():
+                self._mode_maps(head_mc); self._mode_perms(head_mc)
+                for b in res:
+                    self._mode_perms(b.mc_1); self._mode_perms(b.mc_2)
 
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:
@@ -429,15 +473,10 @@ class GeneratorEngine:
         # per-mode dense weight sets for the launches that read compacted activations: the mode of an image is its label
         hint = getattr(indicator, '_mcgen_onehot', None)
         pm = gk and self._pm_enabled() and hint is not None and hint[0].shape[0] * hint[1] == n
-        wsel = order = None
+        # (walking the images mode by mode -- mcgen_conv_t.order -- measured neutral: 7.249 vs 7.256 ms/step; not used)
+        wsel = None
         if pm:
-            lab = hint[2] if len(hint) > 2 and hint[2] is not None else hint[0].to(torch.int32).repeat(hint[1])
-            if _PM_ORDER:
-                # stable: images keep their relative order inside a mode (tiles of one BatchNorm group stay together)
-                srt, oi = torch.sort(lab, stable=True)
-                wsel, order = srt.contiguous(), oi.to(torch.int32)
-            else:
-                wsel = lab
+            wsel = hint[2] if len(hint) > 2 and hint[2] is not None else hint[0].to(torch.int32).repeat(hint[1])
         x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
         caps_h = [self._cap(b.mc_2) if (gk and self._gk_block(i)) else None for i, b in enumerate(res)]
         for i, b in enumerate(res):
@@ -450,7 +489,10 @@ class GeneratorEngine:
             cap_h = caps_h[i]                                                            # h of this block, masked by mc_2
             nxt = res[i + 1] if i + 1 < len(res) else None
             # the block's output x stays compacted only if the NEXT block reads it compacted in both of its launches
-            cap_y = self._cap(nxt.mc_1) if (nxt is not None and cap_h is not None and caps_h[i + 1] is not None) else None
+            # the block's output x stays compacted only if its consumers read it compacted (the next block's two launches; the
+            # image head through its own per-mode images)
+            ymc = self._y_mc(i, pm and 'headm' in self.img) if cap_h is not None else None
+            cap_y = self._cap(ymc) if ymc is not None else None
             cm_h = ops.mc_cmap(code2) if cap_h else None
             cm_y = ops.mc_cmap(codes[2 * (i + 1)]) if cap_y else None
             # ---- conv_a: BN -> ReLU -> Up -> MC1 -> conv3x3 (mcgan.py:15-19)
@@ -460,7 +502,7 @@ class GeneratorEngine:
                     # dense K loop over the compacted pitch on the image's mode's own weight image
                     seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1)
                     h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1m'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
-                                             ycmap=cm_h, cy=cap_h, wsel=wsel, order=order)
+                                             cy=cap_h, wsel=wsel, yperm=self._mode_perms(b.mc_2))
                 else:
                     seg_a = Seg(x, scale=sa, shift=ta, ups=True, relu=True, group_n=1, cmap=x_cm[0], cw=ci)
                     h, st_h = ops.conv_fused([seg_a], self.img[f'b{i}.w1g'], co, bias=b.conv[4].module.bias, stats_mode=st_mode,
@@ -487,7 +529,8 @@ class GeneratorEngine:
                     seg_s = Seg(x, ksize=1, code=code1, ups=True)
                 if use_pm:
                     y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sm'].view(-1), co, bias=self.img[f'b{i}.bias2s'],
-                                           stats_mode=st_mode, ycmap=cm_y, cy=cap_y, wsel=wsel, order=order)
+                                           stats_mode=st_mode, cy=cap_y, wsel=wsel,
+                                           yperm=self._mode_perms(ymc) if ymc is not None else None)
                 else:
                     y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co, bias=self.img[f'b{i}.bias2s'],
                                            stats_mode=st_mode, kmajor=2, ycmap=cm_y, cy=cap_y)
@@ -503,7 +546,13 @@ class GeneratorEngine:
         s = x.shape[1]
         bnh = _bn_forward(head_bn, st, ng * s * s, train, fold, groups)
         codeh = codes[-1]
-        seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True, group_n=gn)
+        hw, hsel = self.img['head'], None
+        if x_cm is not None:
+            sh_, th_ = ops.mc_affine(codeh, x_cm[0], x_cm[1], bnh.scale, bnh.shift, group_n=gn)
+            seg_h = Seg(x, scale=sh_, shift=th_, relu=True, group_n=1)
+            hw, hsel = self.img['headm'], wsel
+        else:
+            seg_h = Seg(x, scale=bnh.scale, shift=bnh.shift, code=codeh, relu=True, group_n=gn)
         cimg = head_conv.out_channels
         if pair_out is not None:
             if tuple(pair_out.shape) != (2 * n, x.shape[1], x.shape[2], ops.pad8(cimg)) or pair_out.dtype != dt:
@@ -512,14 +561,14 @@ class GeneratorEngine:
             direct = (dt == torch.bfloat16 and x.shape[1] == 32 and x.shape[2] == 32 and cimg <= 8 and x.shape[-1] % 32 == 0
                       and x.shape[-1] >= 64 and n * 32 * 32 * x.shape[-1] < (1 << 31))
             if direct:
-                ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True, out=pair_out, y_group=ng)
+                ops.conv_fused([seg_h], hw, cimg, bias=head_conv.bias, tanh=True, out=pair_out, y_group=ng, wsel=hsel)
                 out = None
             else:
-                out, _ = ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True)
+                out, _ = ops.conv_fused([seg_h], hw, cimg, bias=head_conv.bias, tanh=True, wsel=hsel)
                 pv = pair_out.view(groups, 2 * ng, *pair_out.shape[1:])
                 pv[:, ng:].copy_(out.view(groups, ng, *out.shape[1:]))
         else:
-            out, _ = ops.conv_fused([seg_h], self.img['head'], cimg, bias=head_conv.bias, tanh=True)
+            out, _ = ops.conv_fused([seg_h], hw, cimg, bias=head_conv.bias, tanh=True, wsel=hsel)
         ctx.update(blocks=blocks_ctx, y=x, bnh=bnh, codeh=codeh, out=out)
         _flush_counters()
         if pair_out is not None:

@@ -340,7 +340,8 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
                gmean: Optional[Tensor] = None, grstd: Optional[Tensor] = None,
                tanh: bool = False, stats_mode: int = 0, cy: Optional[int] = None,
                out: Optional[Tensor] = None, kmajor: int = 0, ycmap: Optional[Tensor] = None,
-               y_group: int = 0, wsel: Optional[Tensor] = None, order: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               y_group: int = 0, wsel: Optional[Tensor] = None, order: Optional[Tensor] = None,
+               yperm: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Launch mcgen_conv_fused; returns (y, per-tile stats partials or None).  `kmajor`: `wimg` is the K-major image
     (prep_weight_k, segments concatenated); 1: every segment carries a compaction map and is compacted while staged;
     2: segments hold ALREADY compacted channels (Seg.cw, cmap) or are dense.  `ycmap` (+ `cy` = compacted pitch): the
@@ -349,7 +350,9 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     second halves of N / y_group paired [real (+) generated] batches (mcgen_conv_t.y_group).
     `wsel` (int32 [N]) + `order` (int32 [N], a permutation; optional): per-mode dense weight sets -- `wimg` holds S images of
     the segments' (compacted) shapes back to back, the image walked at position i is order[i] and multiplies weight set
-    wsel[i] (mcgen_conv_t.wsel: bf16, software-pipelined form only)."""
+    wsel[i] (mcgen_conv_t.wsel: bf16, software-pipelined form only).  `yperm` (int16 [S, stride], with wsel and `cy`): the sets'
+    weight ROWS were permuted at prep time (PrepBatch rmap = yperm[s]): the output comes out compacted (pitch cy) without a
+    gather pass; bias and statistics stay in true channel order (mcgen_conv_t.yperm)."""
     s0 = segs[0]
     n = s0.x.shape[0]
     h = s0.x.shape[1] * (2 if s0.ups else 1)
@@ -403,6 +406,11 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     p.w_layout = int(kmajor)
     p.y_group = int(y_group)
     p.wsel, p.wsel_stride, p.order = _p(wsel), (need if wsel is not None else 0), _p(order)
+    p.yperm, p.yperm_stride = None, 0
+    if yperm is not None:
+        if wsel is None or yperm.dtype != torch.int16 or yperm.dim() != 2 or yperm.shape[0] * need != wimg.numel() or not yperm.is_contiguous():
+            raise _lib.McgenError('yperm must be a contiguous int16 [sets, stride] table that comes with wsel')
+        p.yperm, p.yperm_stride = _p(yperm), yperm.shape[1]
     p.ycmap, p.ycmap_stride = None, 0
     if ycmap is not None:
         if ycmap.dtype != torch.int16 or tuple(ycmap.shape) != (n, cmap_stride(pad8(cout))):
@@ -412,7 +420,7 @@ def conv_fused(segs: Sequence[Seg], wimg: Tensor, cout: int, *, bias: Optional[T
     lib = _lib.load()
     if stats_mode:
         tiles = lib.mcgen_conv_m_tiles(C.byref(p), _dt(dtype))
-        stats = torch.empty((tiles, 2, pad16(cout) if ycmap is not None else cy), dtype=torch.float32, device=y.device)
+        stats = torch.empty((tiles, 2, pad16(cout) if (ycmap is not None or yperm is not None) else cy), dtype=torch.float32, device=y.device)
         p.stats = _p(stats)
     kflops = 2.0 * n * h * w * cout * sum(s.ksize * s.ksize * s.x.shape[-1] for s in segs)
 
@@ -971,6 +979,7 @@ class PrepBatch:
             w, img, transpose, row_perm, sidx, wscale = job[:6]
             kmajor = bool(job[6]) if len(job) > 6 else False          # K-major image (mode-compacted launches)
             kmap, kcount = (job[7], int(job[8])) if len(job) > 8 and job[7] is not None else (None, 0)
+            rmap = job[9] if len(job) > 9 else None                   # image row r <- weight row rmap[r] (mcgen_conv_t.yperm)
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
             if kmap is not None:                                      # a mode's compacted image: input channel k <- kmap[k], k < kcount
@@ -983,6 +992,9 @@ class PrepBatch:
             d.Cout, d.Cin, d.ksize, d.transpose, d.row_perm, d.sigma_idx = cout, cin, ks, int(transpose), row_perm, sidx
             d.wscale, d.layout = float(wscale), int(kmajor)
             d.kmap, d.kcount = _p(kmap), kcount
+            if rmap is not None:
+                assert not kmajor and not transpose and row_perm == 1 and rmap.dtype == torch.int16 and rmap.numel() >= cout and rmap.is_contiguous()
+            d.rmap = _p(rmap)
         self.key = tuple((w.data_ptr(), img.data_ptr()) for w, img, *_ in jobs)
         self.table = _struct_table(arr, jobs[0][0].device)
         self.n = len(jobs)

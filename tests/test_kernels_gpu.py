@@ -1567,6 +1567,74 @@ def test_per_mode_weight_sets_match_the_masked_convolution(two_seg, ordered):
         ops.conv_fused([ops.Seg(compact(x)[:8])], sets.view(-1), co, bias=b.cuda(), wsel=lab32[:8].contiguous())
 
 
+@pytest.mark.parametrize('two_seg', [False, True])
+def test_permuted_weight_rows_store_the_compacted_output(two_seg):
+    """mcgen_conv_t.yperm + mcgen_prep_t.rmap: the weight rows of a mode's image in the order the CONSUMER's mask keeps them
+    -- the tile's columns are the compacted order, stored with plain 16-byte stores -- against the gather pass of `ycmap`
+    on the same inputs: the active slots of every image bit for bit, the statistics rows (true channel order) bit for bit,
+    and against F.conv2d on the masked tensors."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(2203 + int(two_seg))
+    n, h, c, co, modes = 64, 32, 256, 256, 4
+    cb = (torch.rand(modes, c, generator=g) < 0.5).float()          # the mask in front of this convolution
+    cb2 = (torch.rand(modes, co, generator=g) < 0.55).float()       # its consumer's mask
+    cb2[0, co - 1] = 1.0; cb2[1, 0] = 1.0
+    cap = (int(cb.sum(1).max()) + 31) // 32 * 32
+    cap2 = (int(cb2.sum(1).max()) + 31) // 32 * 32
+    label = torch.randint(0, modes, (n,), generator=g)
+    cmaps = ops.mc_cmap(cb.cuda())
+    perm2 = torch.argsort((cb2 == 0).to(torch.int8), dim=1, stable=True).to(torch.int16).cuda().contiguous()
+
+    def compact(x):
+        out = torch.zeros(x.shape[0], x.shape[2], x.shape[3], cap)
+        for i in range(x.shape[0]):
+            idx = torch.nonzero(cb[label[i]]).flatten()
+            out[i, :, :, :idx.numel()] = x[i, idx].permute(1, 2, 0)
+        return out.to(dtype).cuda().contiguous()
+    x = _hot(_rnd(g, n, c, h, h))
+    w3, b = _rnd(g, co, c, 3, 3) * 0.03, _rnd(g, co)
+    code = cb[label]
+    ref = F.conv2d(_q(_q(x, dtype) * code[:, :, None, None], dtype), _q(w3, dtype), b, padding=1)
+    segs = [ops.Seg(compact(x))]
+    per3 = ops.weight_image_elems(co, cap, 3)
+    per = per3
+    if two_seg:
+        xl = _rnd(g, n, c, h // 2, h // 2)
+        w1 = _rnd(g, co, c, 1, 1) * 0.08
+        ref = ref + F.conv2d(_q(_q(xl, dtype) * code[:, :, None, None], dtype).repeat_interleave(2, 2).repeat_interleave(2, 3), _q(w1, dtype))
+        segs.append(ops.Seg(compact(xl), ksize=1, ups=True))
+        per += ops.weight_image_elems(co, cap, 1)
+
+    def build(rows):
+        sets = torch.empty(modes, per, dtype=dtype, device='cuda')
+        jobs = []
+        for m in range(modes):
+            r = perm2[m] if rows else None
+            jobs.append((w3.cuda(), sets[m, :per3], False, 1, -1, 1.0, False, cmaps[m, c:], cap, r))
+            if two_seg:
+                jobs.append((w1.cuda(), sets[m, per3:], False, 1, -1, 1.0, False, cmaps[m, c:], cap, r))
+        ops.PrepBatch(jobs, dtype).run()
+        return sets
+    lab32 = label.to(torch.int32).cuda()
+    ycm = ops.mc_cmap(cb2[label].cuda())
+    ya, sta = ops.conv_fused(segs, build(False).view(-1), co, bias=b.cuda(), stats_mode=1, wsel=lab32, ycmap=ycm, cy=cap2)
+    (yb, stb), tiles = _conv_logged(ops, segs, build(True).view(-1), co, bias=b.cuda(), stats_mode=1, wsel=lab32, yperm=perm2, cy=cap2)
+    assert tiles == [(256, 256)] and tuple(yb.shape) == (n, h, h, cap2)
+    assert torch.equal(sta, stb)
+    for i in range(n):
+        idx = torch.nonzero(cb2[label[i]]).flatten()
+        k = idx.numel()
+        assert torch.equal(ya[i, :, :, :k], yb[i, :, :, :k]), i
+        _assert_close(yb[i, :, :, :k].float().permute(2, 0, 1).cpu(), ref[i, idx], dtype, f'image {i}')
+        assert bool(torch.isfinite(yb[i].float()).all())
+    # refused: without wsel, with order, a pitch beyond the channels
+    with pytest.raises(Exception):
+        ops.conv_fused(segs, build(True)[0].contiguous(), co, bias=b.cuda(), yperm=perm2[:1].contiguous(), cy=cap2)
+    with pytest.raises(Exception):
+        ops.conv_fused(segs, build(True).view(-1), co, bias=b.cuda(), wsel=lab32, order=torch.arange(n, dtype=torch.int32, device='cuda'), yperm=perm2, cy=cap2)
+
+
 def test_mode_compacted_conv_rejects_what_it_cannot_run():
     from mcgen_amd import _lib
     ops = _ops()
