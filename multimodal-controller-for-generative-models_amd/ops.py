@@ -556,6 +556,7 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
                    lambda: _nbytes(gr), lambda: _nbytes(sl, bs))
 
 
+MULTI_LOG = None         # tools: receives (map side, ksize, 128-pixel steps, tiles, splits) per layer of every wgrad_multi launch
 WGRAD_LOG = None         # tests: a list that receives which weight-gradient kernel family a call with default splits takes
 _deferred = None
 _MULTI = _flag('MCGEN_WGRAD_MULTI', '1') != '0'        # eligible 3x3 weight gradients of a pass as one mcgen_wgrad_multi launch
@@ -595,6 +596,12 @@ class _PendingMulti:
                 (self.slabs[hs:], self.second[0], b1, self.second[1], self.second[2], hs) + tail]
 
 
+_WG_W1 = float(_flag('MCGEN_WG_W1', '1.6'))        # cost of a 1x1 layer's 128-pixel step relative to a 3x3 layer's (the same staging, a ninth of the MFMAs)
+_WG_W16 = float(_flag('MCGEN_WG_W16', '1.0'))      # ... of a step on 16x16 maps, on 8x8 maps (more halo per step)
+_WG_W8 = float(_flag('MCGEN_WG_W8', '1.0'))
+_WG_FIX = float(_flag('MCGEN_WG_FIX', '0'))        # fixed cost of a workgroup (setup, the accumulator flush) in steps
+
+
 def _launch_multi(pend):
     """Size the queued layers' pixel splits by their share of the pass's work (128-pixel steps x workgroup tiles), one
     workgroup per CU over the whole launch, allocate the slabs and launch mcgen_wgrad_multi (<= MCGEN_WGRAD_MULTI_MAX layers each)."""
@@ -603,28 +610,49 @@ def _launch_multi(pend):
     for base in range(0, len(pend), _lib.WGRAD_MULTI_MAX):
         grp = pend[base:base + _lib.WGRAD_MULTI_MAX]
         budget = _cu_count(dev)
-        # (a 1x1 step moves the same dy tile for a ninth of the MFMAs: memory-bound, about a third of a 3x3 step's time)
-        work = [q.m_tiles * q.blocks * (1.0 if q.seg.ksize == 3 else 0.35) for q in grp]
-        tot = float(sum(work))
-        for q, wk in zip(grp, work):
-            unit = 2 if q.second is not None else 1                     # a two-half launch needs even splits
-            cap = q.m_tiles // unit * unit
-            sp = int(budget * wk / tot / q.blocks) // unit * unit
-            q.splits = max(unit, min(cap, sp))
-        # hand the workgroups the floors left over to the layers with the most steps per workgroup
+        # Cost model of one workgroup of layer q with `sp` pixel splits: _WG_FIX + (m_tiles / sp) * w(q) in units of a 3x3
+        # layer's 128-pixel step on a 32x32 map; the launch lasts as long as its slowest workgroup, so the splits are the
+        # smallest that bring every layer under a common time T, T as small as the CU budget allows.  (The first version
+        # split in proportion to w * steps with w(1x1) = 0.35: the generator's three shortcut layers got one workgroup per
+        # tile and ran 256 steps each while the 3x3 layers' workgroups were done after 86: 518 us for a 380 us pass.)
+        def wq(q):
+            side = q.p.H
+            w = 1.0 if q.seg.ksize == 3 else _WG_W1
+            return w * (_WG_W8 if side <= 8 else (_WG_W16 if side <= 16 else 1.0))
+
+        def need(q, t):
+            unit = 2 if q.second is not None else 1
+            cap = max(unit, q.m_tiles // unit * unit)
+            if t <= _WG_FIX:
+                return cap
+            sp = int(-(-q.m_tiles * wq(q) // (t - _WG_FIX)))
+            sp = -(-sp // unit) * unit
+            return max(unit, min(cap, sp))
+        lo, hi = _WG_FIX, _WG_FIX + max(q.m_tiles * wq(q) for q in grp) + 1.0
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            if sum(need(q, mid) * q.blocks for q in grp) <= budget:
+                hi = mid
+            else:
+                lo = mid
+        for q in grp:
+            q.splits = need(q, hi)
+        # hand the workgroups left over to the layers with the most work per workgroup
         used = sum(q.splits * q.blocks for q in grp)
         while True:
             best = None
             for q in grp:
                 unit = 2 if q.second is not None else 1
                 if q.splits + unit <= q.m_tiles // unit * unit and used + unit * q.blocks <= budget:
-                    load = q.m_tiles / q.splits * (1.0 if q.seg.ksize == 3 else 0.35)
+                    load = q.m_tiles / q.splits * wq(q)
                     if best is None or load > best[0]:
                         best = (load, q, unit)
             if best is None:
                 break
             best[1].splits += best[2]
             used += best[2] * best[1].blocks
+        if MULTI_LOG is not None:
+            MULTI_LOG.append([(q.p.H, q.seg.ksize, q.m_tiles, q.blocks, q.splits) for q in grp])
         arr = (_lib.Wgrad * len(grp))()
         flops = nbytes = extra = 0.0
         for a, q in zip(arr, grp):
