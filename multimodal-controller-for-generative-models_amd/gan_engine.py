@@ -293,9 +293,6 @@ class GeneratorEngine:
             self._prep_fwd = ops.PrepBatch([(j[0].detach(),) + tuple(j[1:]) for j in jobs], dt)
         self._prep_fwd.run()
         buf('lin_bias', lin.out_features, torch.float32).view(16, c0).copy_(lin.bias.detach().view(c0, 16).t())
-        for i, b in enumerate(res):
-            torch.add(b.conv[8].module.bias.detach(), b.shortcut[2].module.bias.detach(),
-                      out=buf(f'b{i}.bias2s', b.conv[8].module.out_channels, torch.float32))
         self._img_key = key
 
     def _prep_backward_images(self):
@@ -361,6 +358,47 @@ class GeneratorEngine:
             and head_conv.in_channels % 32 == 0 and self._cap(head_mc) is not None and self._cap(head_mc) >= 64
         return head_mc if ok else None
 
+    def _pm_need(self):
+        """The MultimodalControllers whose compaction records the grouped pass reads (per-mode weight sets in use)."""
+        lin, res, head_bn, head_mc, head_conv = self._layers()
+        need = []
+        for i, b in enumerate(res):
+            if not self._gk_block(i) or self._cap(b.mc_2) is None:
+                continue
+            need.append(b.mc_2)
+            ymc = self._y_mc(i, 'headm' in self.img)
+            if ymc is not None:
+                need.append(ymc)
+        return need
+
+    def _stacked_maps(self, need):
+        """(records of all modes of all `need` controllers back to back [K * modes, stride], row offsets [K, 1] int32), or None
+        when their record strides differ.  Cached per codebook versions."""
+        tabs = [self._mode_maps(mc) for mc in need]
+        if not tabs or any(t.shape != tabs[0].shape for t in tabs):
+            return None
+        key = tuple((id(mc), mc.codebook.data_ptr(), mc.codebook._version) for mc in need)
+        if getattr(self, '_stack_key', None) != key:
+            if tabs[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                raise McgenError('compacted generator pass: a codebook changed since the last eager pass; call '
+                                 'GeneratorEngine.warm_caps() before capturing')
+            modes = tabs[0].shape[0]
+            self._stack = (torch.cat(tabs, 0).contiguous(),
+                           (torch.arange(len(tabs), dtype=torch.int32, device=tabs[0].device) * modes).view(-1, 1))
+            self._stack_key = key
+        return self._stack
+
+    def _gather_cmaps(self, need, wsel):
+        """-> {id(mc): int16 [N, stride]} the per-image compaction records of `need` (ops.mc_cmap of the one-hot samples' codes),
+        gathered from the per-mode records by label in ONE launch (+ one index add)."""
+        st = self._stacked_maps(need)
+        if st is None:
+            return {}
+        table, offs = st
+        idx = (wsel.view(1, -1) + offs).view(-1)
+        rows = table.index_select(0, idx).view(len(need), wsel.numel(), table.shape[1])
+        return {id(mc): rows[k] for k, mc in enumerate(need)}
+
     def _mode_perms(self, mc):
         """int16 [modes, C]: per codebook row, its active channels in order, then the others (mcgen_conv_t.yperm /
         mcgen_prep_t.rmap).  Cached per codebook version."""
@@ -413,6 +451,7 @@ class GeneratorEngine:
                 self._mode_maps(head_mc); self._mode_perms(head_mc)
                 for b in res:
                     self._mode_perms(b.mc_1); self._mode_perms(b.mc_2)
+                self._stacked_maps(self._pm_need())
 
     # ---- forward ---------------------------------------------------------------------------------
     def groups_supported(self, n_total: int, groups: int) -> bool:
@@ -478,6 +517,8 @@ class GeneratorEngine:
         if pm:
             wsel = hint[2] if len(hint) > 2 and hint[2] is not None else hint[0].to(torch.int32).repeat(hint[1])
         x_cm = None                                # compaction map / pitch of the block input x when it arrives compacted
+        # one-hot samples: an image's compaction record is its mode's -- one row gather for every map of the pass
+        cmaps = self._gather_cmaps(self._pm_need(), wsel) if pm else {}
         caps_h = [self._cap(b.mc_2) if (gk and self._gk_block(i)) else None for i, b in enumerate(res)]
         for i, b in enumerate(res):
             s = x.shape[1]
@@ -493,8 +534,8 @@ class GeneratorEngine:
             # image head through its own per-mode images)
             ymc = self._y_mc(i, pm and 'headm' in self.img) if cap_h is not None else None
             cap_y = self._cap(ymc) if ymc is not None else None
-            cm_h = ops.mc_cmap(code2) if cap_h else None
-            cm_y = ops.mc_cmap(codes[2 * (i + 1)]) if cap_y else None
+            cm_h = (cmaps[id(b.mc_2)] if id(b.mc_2) in cmaps else ops.mc_cmap(code2)) if cap_h else None
+            cm_y = (cmaps[id(ymc)] if id(ymc) in cmaps else ops.mc_cmap(codes[2 * (i + 1)])) if cap_y else None
             # ---- conv_a: BN -> ReLU -> Up -> MC1 -> conv3x3 (mcgan.py:15-19)
             if x_cm is not None:
                 sa, ta = ops.mc_affine(code1, x_cm[0], x_cm[1], bn1.scale, bn1.shift, group_n=gn)
@@ -528,18 +569,21 @@ class GeneratorEngine:
                 else:
                     seg_s = Seg(x, ksize=1, code=code1, ups=True)
                 if use_pm:
-                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sm'].view(-1), co, bias=self.img[f'b{i}.bias2s'],
-                                           stats_mode=st_mode, cy=cap_y, wsel=wsel,
+                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sm'].view(-1), co, bias=b.conv[8].module.bias,
+                                           bias2=b.shortcut[2].module.bias, stats_mode=st_mode, cy=cap_y, wsel=wsel,
                                            yperm=self._mode_perms(ymc) if ymc is not None else None)
                 else:
-                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co, bias=self.img[f'b{i}.bias2s'],
+                    # (the gather pass of a compacted output takes one bias vector)
+                    y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2sk'], co,
+                                           bias=b.conv[8].module.bias.detach() + b.shortcut[2].module.bias.detach(),
                                            stats_mode=st_mode, kmajor=2, ycmap=cm_y, cy=cap_y)
             else:
                 # (conv_b ++ 1x1 shortcut stays dense in the mode-compacted form: one-tap K steps cost more than they save)
                 seg_b = Seg(h, scale=bn2.scale, shift=bn2.shift, code=code2, relu=True, group_n=gn)
                 seg_s = Seg(x, ksize=1, code=code1, ups=True)
-                y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=self.img[f'b{i}.bias2s'],
-                                       stats_mode=st_mode)
+                # (the shortcut's own bias rides along as bias2: the sum is formed in fp32 in front of the accumulator)
+                y, st = ops.conv_fused([seg_b, seg_s], self.img[f'b{i}.w2s'], co, bias=b.conv[8].module.bias,
+                                       bias2=b.shortcut[2].module.bias, stats_mode=st_mode)
             blocks_ctx.append(dict(x=x, h=h, code1=code1, code2=code2, bn1=bn1, bn2=bn2))
             x = y
             x_cm = (cm_y, cap_y) if cm_y is not None else None

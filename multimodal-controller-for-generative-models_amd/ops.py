@@ -596,10 +596,10 @@ class _PendingMulti:
                 (self.slabs[hs:], self.second[0], b1, self.second[1], self.second[2], hs) + tail]
 
 
-_WG_W1 = float(_flag('MCGEN_WG_W1', '1.6'))        # cost of a 1x1 layer's 128-pixel step relative to a 3x3 layer's (the same staging, a ninth of the MFMAs)
+_WG_W1 = float(_flag('MCGEN_WG_W1', '0.55'))        # cost of a 1x1 layer's 128-pixel step relative to a 3x3 layer's (the same staging, a ninth of the MFMAs)
 _WG_W16 = float(_flag('MCGEN_WG_W16', '1.0'))      # ... of a step on 16x16 maps, on 8x8 maps (more halo per step)
 _WG_W8 = float(_flag('MCGEN_WG_W8', '1.0'))
-_WG_FIX = float(_flag('MCGEN_WG_FIX', '0'))        # fixed cost of a workgroup (setup, the accumulator flush) in steps
+_WG_FIX = float(_flag('MCGEN_WG_FIX', '5'))        # fixed cost of a workgroup (setup, the accumulator flush) in steps
 
 
 def _launch_multi(pend):
@@ -610,11 +610,14 @@ def _launch_multi(pend):
     for base in range(0, len(pend), _lib.WGRAD_MULTI_MAX):
         grp = pend[base:base + _lib.WGRAD_MULTI_MAX]
         budget = _cu_count(dev)
-        # Cost model of one workgroup of layer q with `sp` pixel splits: _WG_FIX + (m_tiles / sp) * w(q) in units of a 3x3
-        # layer's 128-pixel step on a 32x32 map; the launch lasts as long as its slowest workgroup, so the splits are the
-        # smallest that bring every layer under a common time T, T as small as the CU budget allows.  (The first version
-        # split in proportion to w * steps with w(1x1) = 0.35: the generator's three shortcut layers got one workgroup per
-        # tile and ran 256 steps each while the 3x3 layers' workgroups were done after 86: 518 us for a 380 us pass.)
+        # Cost model of one workgroup of layer q with `sp` pixel splits: fix(q) + (m_tiles / sp) * w(q) in units of a 3x3
+        # layer's 128-pixel step; the launch lasts as long as its slowest workgroup, so the splits are the smallest that
+        # bring every layer under a common time T, T as small as the CU budget allows.  Calibrated with
+        # tools/wgmulti_cost.py (one layer per launch, 16 .. 128 steps per workgroup): 3x3 4.0 us per step + 20 us fixed on
+        # every map size, 1x1 2.15 us per step + 6 us: w(1x1) = 0.55, fix = 5 steps (3x3) / 1.5 (1x1).  (The first version
+        # split in proportion to w * steps with w(1x1) = 0.35 and no fixed part: the generator's three shortcut layers got one
+        # workgroup per tile and ran 256 steps each while the 3x3 layers' workgroups were done after 86: 518 us for a pass
+        # that now takes 388; the discriminator's launches 143 -> 136 us.)
         def wq(q):
             side = q.p.H
             w = 1.0 if q.seg.ksize == 3 else _WG_W1
@@ -623,9 +626,10 @@ def _launch_multi(pend):
         def need(q, t):
             unit = 2 if q.second is not None else 1
             cap = max(unit, q.m_tiles // unit * unit)
-            if t <= _WG_FIX:
+            fix = _WG_FIX if q.seg.ksize == 3 else 0.3 * _WG_FIX
+            if t <= fix:
                 return cap
-            sp = int(-(-q.m_tiles * wq(q) // (t - _WG_FIX)))
+            sp = int(-(-q.m_tiles * wq(q) // (t - fix)))
             sp = -(-sp // unit) * unit
             return max(unit, min(cap, sp))
         lo, hi = _WG_FIX, _WG_FIX + max(q.m_tiles * wq(q) for q in grp) + 1.0

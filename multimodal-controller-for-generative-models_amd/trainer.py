@@ -453,8 +453,9 @@ class GraphedGANTrainer(GANTrainer):
         # indicator of the batch / of the paired 2N batch / of the generator pass(es): prefixes of one buffer
         self.s_lab32 = torch.empty(max(2, fg) * n, dtype=torch.int32, device=dev)
         self.s_ind, self.s_ind2, self.s_indg = self.indicators(self.s_label, fg, out=self.s_indall, lab32=self.s_lab32)
-        self.s_z = torch.randn(n, self.latent, device=dev)                  # latent of the generator update
-        self.s_zd = torch.randn(fg * n, self.latent, device=dev)            # latents of fg discriminator updates
+        # latents of the fg discriminator updates and of the generator update: one buffer, one draw per iteration
+        self.s_zall = torch.randn((fg + 1) * n, self.latent, device=dev)
+        self.s_zd, self.s_z = self.s_zall[:fg * n], self.s_zall[fg * n:]
         # real (+) generated batches of the fg discriminator updates that share a generator pass
         self.s_xbuf, self.s_x2s = self.pair_buffers(self.s_img, fg) if _NHWC_PAIR else (None, None)
         self.s_fake = None if _NHWC_PAIR else torch.empty_like(self.s_img)
@@ -510,8 +511,7 @@ class GraphedGANTrainer(GANTrainer):
                     pass
                 self.g_apply()
             with torch.cuda.graph(self.g_draw, pool=self.g_all.pool(), capture_error_mode=_CAPTURE_MODE):
-                self.s_zd.normal_()
-                self.s_z.normal_()
+                self.s_zall.normal_()
             self._graphs = True
             self._hyper_key = (self.opt_g.hyper(), self.opt_d.hyper())
             return
