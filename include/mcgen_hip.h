@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_prep_weight_batch_codes, mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -301,6 +301,12 @@ int mcgen_mc_code_batch(const float* indicator, const mcgen_code_t* descs_dev, i
  * multiply-adds per output, which is what COIL100's 100 and Omniglot's 1623 modes need. */
 int mcgen_mc_gather_batch(const int64_t* label, int n_label, const mcgen_code_t* descs_dev, int n, float* code_base, int N,
                           const float* scale, int n_half, void* stream);
+/* mcgen_prep_weight_batch + mcgen_mc_gather_batch as ONE launch: the weight images W / sigma (models/utils.py:17-21 behind
+ * mcgan.py's SpectralNorm wrappers) and the codes of a discriminator pass both wait for the power iteration and for
+ * nothing else.  Same results as the two calls. */
+int mcgen_prep_weight_batch_codes(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype,
+                                  const int64_t* label, int n_label, const mcgen_code_t* code_descs_dev, int n_code,
+                                  float* code_base, int N, const float* scale, int n_half, void* stream);
 /* y = x * code (broadcast over HW), standalone form of modules.py:75 for unfused callers;
  * x is [N, HW, C] when channels_last, else [N, C, HW] (the reference's NCHW / [N, C] inputs) */
 int mcgen_mc_apply(const void* x, const float* code, void* y, int dtype, int N, int HW, int C, int channels_last, void* stream);

@@ -176,6 +176,7 @@ SYMBOLS = {
     'mcgen_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mcgen_pool2_sum': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_mc_gather_batch': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'mcgen_prep_weight_batch_codes': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     'mcgen_mc_code': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mcgen_mc_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mcgen_bn_finalize': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -135,8 +135,7 @@ __global__ void prep_weight_ex_batch_kernel(const PrepExJobs jobs) {
 
 // all weight images of a network pass in one launch: blockIdx.y = descriptor
 template <typename T>
-__global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs, const float* __restrict__ sigma_base) {
-    const mcgen_prep_t d = descs[blockIdx.y];
+__device__ __forceinline__ void prep_weight_body(const mcgen_prep_t& d, const float* __restrict__ sigma_base) {
     const int KS = d.ksize, Cout = d.Cout, Cin = d.Cin, transpose = d.transpose, row_perm = d.row_perm;
     const float* __restrict__ w = d.w;
     T* __restrict__ img = reinterpret_cast<T*>(d.image);
@@ -194,6 +193,11 @@ __global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs,
     }
 }
 
+template <typename T>
+__global__ void prep_weight_batch_kernel(const mcgen_prep_t* __restrict__ descs, const float* __restrict__ sigma_base) {
+    prep_weight_body<T>(descs[blockIdx.y], sigma_base);
+}
+
 // K-major weight image [tap][k][co_w] with a trailing zero row per tap (single-descriptor form of the layout == 1 branch)
 template <typename T>
 __global__ void prep_weight_k_kernel(const float* __restrict__ w, T* __restrict__ img, int Cout, int Cin, int KS,
@@ -235,9 +239,8 @@ __global__ void mc_code_batch_kernel(const float* __restrict__ ind, const mcgen_
 }
 // the same for one-hot indicators given as labels: code_j[n] = codebook_j[label[n]] (one_hot(label) @ codebook exactly,
 // modules.py:73) -- a row gather per MultimodalController, all of them in one launch
-__global__ void mc_gather_batch_kernel(const int64_t* __restrict__ label, int n_label, const mcgen_code_t* __restrict__ descs,
-                                       float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
-    const mcgen_code_t d = descs[blockIdx.y];
+__device__ __forceinline__ void mc_gather_body(const int64_t* __restrict__ label, int n_label, const mcgen_code_t& d,
+                                               float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
     const float tail_scale = (scale && d.scale_idx >= 0) ? scale[d.scale_idx] : 1.f;
     const int cv = d.C >> 2;                                // (C a multiple of 4: host check)
     const size_t total = (size_t)N * cv;
@@ -249,6 +252,19 @@ __global__ void mc_gather_batch_kernel(const int64_t* __restrict__ label, int n_
         if (n >= n_half) v *= tail_scale;                   // (mc_code_batch's product order: code * scale)
         *reinterpret_cast<f32x4*>(code + (size_t)n * d.C + c) = v;
     }
+}
+__global__ void mc_gather_batch_kernel(const int64_t* __restrict__ label, int n_label, const mcgen_code_t* __restrict__ descs,
+                                       float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
+    mc_gather_body(label, n_label, descs[blockIdx.y], code_base, N, scale, n_half);
+}
+// the weight images and the MultimodalController codes of one discriminator pass in ONE launch: both follow the power
+// iteration (sigma, the sigma ratio of a paired pass) and nothing else -- rows [0, n_prep) of the grid build images, the rest gather
+template <typename T>
+__global__ void prep_codes_kernel(const mcgen_prep_t* __restrict__ pdescs, int n_prep, const float* __restrict__ sigma_base,
+                                  const int64_t* __restrict__ label, int n_label, const mcgen_code_t* __restrict__ cdescs,
+                                  float* __restrict__ code_base, int N, const float* __restrict__ scale, int n_half) {
+    if ((int)blockIdx.y < n_prep) prep_weight_body<T>(pdescs[blockIdx.y], sigma_base);
+    else mc_gather_body(label, n_label, cdescs[blockIdx.y - n_prep], code_base, N, scale, n_half);
 }
 __global__ void mc_code_kernel(const float* __restrict__ ind, const float* __restrict__ cb, float* __restrict__ code,
                                int N, int M, int C) {
@@ -1259,6 +1275,16 @@ extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, con
         hipLaunchKernelGGL(prep_weight_batch_kernel<float>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base),
         hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
     MCGEN_LAUNCH_CHECK("prep_weight_batch"); return 0;
+}
+extern "C" int mcgen_prep_weight_batch_codes(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype,
+                                             const int64_t* label, int n_label, const mcgen_code_t* code_descs_dev, int n_code,
+                                             float* code_base, int N, const float* scale, int n_half, void* stream) {
+    MCGEN_CHECK(descs_dev && n > 0 && label && code_descs_dev && code_base && n_code > 0 && N > 0 && n_label > 0 && N % n_label == 0,
+                "prep_weight_batch_codes: bad arguments (N a multiple of n_label)");
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(prep_codes_kernel<float>, dim3(64, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N),
+        hipLaunchKernelGGL(prep_codes_kernel<bf16_t>, dim3(64, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N));
+    MCGEN_LAUNCH_CHECK("prep_weight_batch_codes"); return 0;
 }
 extern "C" int64_t mcgen_weight_image_k_elems(int Cout, int Cin, int ksize) {
     return (int64_t)ksize * ksize * (round_up(Cin, 8) + 1) * round_up(Cout, 16);

@@ -103,6 +103,7 @@ _LOWRES_SC_BWD = _flag('MCGEN_LOWRES_SC_BWD', '1') != '0'
 # per-mode DENSE weight images for the launches that read compacted activations (instead of the gathered-K form's per-sample
 # row gather): needs one-hot indicators (the mode of an image is its label) and few modes (10 x 0.8 MB per layer at CIFAR-10)
 _PM = _flag('MCGEN_PM', '1') != '0'
+_PREP_CODES = _flag('MCGEN_PREP_CODES', '1') != '0'   # a discriminator pass's codes ride in its weight-image launch
 _PM_HEAD = _flag('MCGEN_PM_HEAD', '1') != '0'         # the last block stores its output compacted for the image head
 _PM_MAX_MODES = 16
 class Nhwc:
@@ -873,9 +874,14 @@ class DiscriminatorEngine:
         tail's input gradient (ops.dtail_hinge_fused); ctx['tail'] = (dlogit, d tail input) is what `backward_iter` then
         starts from -- pass ctx['tail'][0] as its dlogit."""
         sigma, uv = self._power_iter(train)
-        codes = self._codes.run_any(indicator)
-        ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'codes': codes, 'pair': None, 'train': train}
-        return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: codes[mc_i] if mc_i is not None else None, tail_loss)
+        ctx = {'n': x_nchw.shape[0], 'sigma': sigma, 'uv': uv, 'blocks': [], 'pair': None, 'train': train}
+        lab = self._codes.labels_of(indicator) if _PREP_CODES else None
+        if lab is not None:
+            # the codes ride in the weight-image launch (both wait for the power iteration only)
+            ctx['codes_job'] = (self._codes, lab[0], lab[1], None, 0, lambda outs: ctx.__setitem__('codes', outs))
+        else:
+            ctx['codes'] = self._codes.run_any(indicator)
+        return self._forward_body(x_nchw, ctx, lambda mc_i, sn_idx: ctx['codes'][mc_i] if mc_i is not None else None, tail_loss)
 
     def pair_codes(self, ind2: Tensor):
         """The UNSCALED MultimodalController codes of a paired pass ([2N, C] per MC: what the weight gradients multiply their
@@ -909,13 +915,18 @@ class DiscriminatorEngine:
             self._ones_mc = ones
             self._codes_pair = ops.CodeBatch([self._codes.mcs[u[0]] if u[0] is not None else ones for u in uses],
                                              [u[1] for u in uses])
-        outs = self._codes_pair.run_any(ind2, ratio, n)            # all scaled codes of the pass: one launch
-        scaled = dict(zip(uses, outs))
+        scaled = {}
         if codes is None:
             codes = self._codes.run_any(ind2)                      # unscaled [2N, C] codes: the weight gradients' conv inputs
         x = x2 if x2 is not None else torch.cat([real_nchw.detach(), fake_nchw.detach()])
         ctx = {'n': 2 * n, 'sigma': sigma1, 'uv': uv1, 'blocks': [], 'codes': codes,
                'pair': {'n': n, 'sigma2': sigma2, 'uv2': uv2, 'ratio': ratio}}
+        lab = self._codes_pair.labels_of(ind2) if _PREP_CODES else None
+        if lab is not None:
+            # all scaled codes of the pass ride in the weight-image launch (both wait for the power iteration only)
+            ctx['codes_job'] = (self._codes_pair, lab[0], lab[1], ratio, n, lambda outs: scaled.update(zip(uses, outs)))
+        else:
+            scaled.update(zip(uses, self._codes_pair.run_any(ind2, ratio, n)))     # all scaled codes of the pass: one launch
         return self._forward_body(x, ctx, lambda mc_i, sn_idx: scaled[(mc_i, sn_idx)], tail_loss)
 
     def _code_uses(self):
@@ -939,11 +950,15 @@ class DiscriminatorEngine:
         n = x_nchw.shape[0]
         sigma = ctx['sigma']
         self._ensure_preps()
-        if ctx.get('train', True):
-            self._prep_all.run(sigma)             # every W / sigma image of this pass, forward and transposed, in one launch
-            self._bwd_sigma = sigma
+        prep = self._prep_all if ctx.get('train', True) else self._prep_fwd
+        job = ctx.pop('codes_job', None)
+        if job is not None:
+            cb, label, reps, scale, n_half, sink = job
+            sink(ops.prep_and_codes(prep, sigma, cb, label, reps, scale, n_half))
         else:
-            self._prep_fwd.run(sigma)
+            prep.run(sigma)                       # every W / sigma image of this pass, forward and transposed, in one launch
+        if ctx.get('train', True):
+            self._bwd_sigma = sigma
         I = self.img
         img = x_nchw.t if isinstance(x_nchw, Nhwc) else ops.to_nhwc(x_nchw.detach().contiguous(), dt)
         if img.dtype != dt:

@@ -1039,6 +1039,26 @@ class PrepBatch:
               'prep_weight_batch')
 
 
+def prep_and_codes(prep: 'PrepBatch', sigma: Optional[Tensor], codes: 'CodeBatch', label: Tensor, reps: int = 1,
+                   scale: Optional[Tensor] = None, n_half: int = 0):
+    """PrepBatch.run(sigma) and CodeBatch.run_labels(label, reps, scale, n_half) as ONE launch (mcgen_prep_weight_batch_codes):
+    a discriminator pass's weight images and codes both wait for the power iteration only.  -> the code tensors."""
+    codes._ensure()
+    n = label.shape[0] * reps
+    codes._tables_for(n, label.device)
+    if label.dtype != torch.int64 or any(d.C % 4 for d in codes._arr):
+        raise _lib.McgenError('prep_and_codes: int64 labels and channel counts that are multiples of 4')
+    buf = torch.empty(codes._total, dtype=torch.float32, device=label.device)
+    check(_lib.load().mcgen_prep_weight_batch_codes(_p(prep.table), prep.n, _f32(sigma), _dt(prep.dtype), _p(label.contiguous()),
+                                                    label.shape[0], _p(codes._table), len(codes.mcs), _f32(buf), n, _f32(scale), n_half,
+                                                    _stream()), 'prep_weight_batch_codes')
+    out, off = [], 0
+    for d in codes._arr:
+        out.append(buf[off:off + n * d.C].view(n, d.C))
+        off += n * d.C
+    return out
+
+
 class CodeBatch:
     """Codes of a list of MultimodalController modules in ONE launch; rebuilt when a codebook buffer was
     re-registered (models.utils.create / transit) or moved."""
@@ -1085,6 +1105,14 @@ class CodeBatch:
             out.append(buf[off:off + n * d.C].view(n, d.C))
             off += n * d.C
         return out
+
+    def labels_of(self, indicator: Tensor):
+        """(label, reps) when `indicator` carries its labels (`onehot_hint`) and run_labels applies, else None."""
+        hint = getattr(indicator, '_mcgen_onehot', None)
+        if hint is not None and hint[0].shape[0] * hint[1] == indicator.shape[0] and hint[0].is_cuda and hint[0].dtype == torch.int64 \
+                and all(d.C % 4 == 0 for d in (self._ensure() or self._arr)):
+            return hint[0], hint[1]
+        return None
 
     def run_any(self, indicator: Tensor, scale: Optional[Tensor] = None, n_half: int = 0):
         """run(), or run_labels() when the indicator carries its labels (`onehot_hint`): the caller built it with
