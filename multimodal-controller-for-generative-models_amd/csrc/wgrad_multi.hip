@@ -285,7 +285,19 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
         __syncthreads();                                                   // the affine rows and step 0's code row(s) are in LDS
         write_x(0);
         if (cnt > 1) load_x(1);
+#ifdef WB_LATE
+        // Waves 4-7 (the second wave of every SIMD) multiply FIRST and stage step i + 1 behind their MFMAs, while their SIMD
+        // partner stages first: one wave's prologue VALU under the other's matrix work.  Their window loads of step i + 2 then
+        // leave at the END of step i and have the whole multiply phase of step i + 1 to land (they are waited for in front of
+        // the late write_x, not at the barrier); only the dy DMA -- which everyone reads behind the next barrier -- goes out early.
+        // (Not for steps of more than four images: there waves 4-7 carry code-row DMAs that the early waves read.)
+        const bool late = (wa != 0) && TI <= 4;
+#endif
         for (int i = 0; i < cnt; ++i) {
+#ifdef WB_LATE
+            if (late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIX) : "memory");   // (this wave's x loads of step i + 1 stay in flight)
+            else
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dy of step i has landed (and this thread's x of step i + 1)
             __syncthreads();                                               // step i published; the buffers of step i - 1 are free
             // Staging of step i + 1 (window prologue + LDS stores, dy DMA, register loads of step i + 2).  Waves 4-7 (the second
@@ -306,12 +318,15 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
 #endif
                 }
             };
-#ifdef WB_STAGGER
+#if defined(WB_STAGGER)
             const bool late = wa != 0;
-#else
+#elif !defined(WB_LATE)
             const bool late = false;
 #endif
             if (!late) stage_next();
+#ifdef WB_LATE
+            else if (i + 1 < cnt) dma_dy(i + 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);                             // (the staging block's temporaries die before the fragments come alive)
             const char* A = ldsA + (i & 1) * WB_ABUF + aoff;
             const char* D = ldsD + (i & 1) * WB_DBUF;
@@ -379,6 +394,15 @@ static __device__ __forceinline__ void wgrad_big_body(const mcgen_wgrad_t& p, co
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef WB_LATE
+            if (late && i + 1 < cnt) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // x of step i + 1 (loaded a step ago) and this step's dy DMA
+                write_x(i + 1);
+                if (i + 2 < cnt) load_x(i + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
         // ---- slab[z][chunk][tap][co][32]: lane holds D[co = 4 lg + r][ci = l15] of (tap j, co fragment c)
         const int nchunk = (sg.C + MCGEN_CK - 1) / MCGEN_CK;

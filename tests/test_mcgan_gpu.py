@@ -522,7 +522,7 @@ def test_compacted_grouped_pass_matches_dense(cfg_name):
     img, lab = img.cuda(), lab.cuda()
     zs = [z.cuda() for z in gu.latent_batches(6, 128, 128, seed=2)]
 
-    def run(gk):
+    def run(gk, hinted=False):
         old = GE._GK
         GE._GK = gk
         try:
@@ -532,7 +532,10 @@ def test_compacted_grouped_pass_matches_dense(cfg_name):
             assert tr.fake_groups(128) == 5
             ops.FORM_LOG = []
             ind = torch.nn.functional.one_hot(lab, modes).float()
-            fakes = tr.g_fakes(ind.repeat(5, 1), torch.cat(zs[:5]), 5)
+            # `hinted`: the indicator as the trainer builds it (one launch, carrying its labels): <= 16 modes then take the
+            # per-mode dense weight sets (wsel / yperm, compacted image head) instead of the gathered-K form
+            ind5 = tr.indicators(lab, 5)[2] if hinted else ind.repeat(5, 1)
+            fakes = tr.g_fakes(ind5, torch.cat(zs[:5]), 5)
             tiles = list(ops.FORM_LOG); ops.FORM_LOG = None
             bn = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()
                   if 'generator' in k and 'running' in k}
@@ -553,6 +556,16 @@ def test_compacted_grouped_pass_matches_dense(cfg_name):
     if cfg_name == 'cifar10':
         d = gu.load_npz('mcgan_full_digest_b128.npz')
         np.testing.assert_allclose(l_c, d['losses'][0], rtol=0, atol=5e-2)
+    # the trainer's own indicator: per-mode weight sets on CIFAR-10 (10 modes), the gathered-K form on COIL100 (100 modes)
+    f_p, bn_p, l_p, t_p = run(True, hinted=True)
+    if cfg_name == 'cifar10':
+        assert t_p.count(2) == 0, t_p                # dense K loops over the compacted pitch: no gathered-K launch left
+    else:
+        assert t_p.count(2) >= 1, t_p
+    assert float((f_p - f_d).abs().max()) < 3e-2 and float((f_p - f_d).abs().mean()) < 1e-3
+    for k, v in bn_d.items():
+        assert float((bn_p[k] - v).abs().max()) <= 2e-3 * (1 + float(v.abs().max())), k
+    np.testing.assert_allclose(l_p, l_d, rtol=0, atol=2e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
