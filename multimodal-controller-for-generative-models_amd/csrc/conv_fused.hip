@@ -2255,6 +2255,11 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, ((pp_mode & 8) && pp_fits<128, 256, 2, 4, 5>(p)) ? 20 : 5};
     if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
+    // 64-channel layers on large maps (COIL100's generator tail and discriminator head, 32x32): 128 pixels x 64 channels on FOUR
+    // waves -- small enough for several workgroups per CU, and a 128-pixel window is 4 rows + 2 of halo where the 64 x 64 tile's is
+    // 2 + 2.  tools/bench_c64.py: N = 640 128 -> 64 343 -> 148 us, 64 (+) 128 -> 64 307 -> 139; the discriminator's 84 -> 61, 70 -> 42
+    // (8 waves on the same tile: 273 / 266 / 77 / 66; 256 x 64: 205 / 194 / 59 / 49).
+    if (M >= 65536 && rows128 && p->Cout_w > 16) return {128, 64, 5};
     // 64x64 tile on 8 waves (4 x 2): ~15 % faster than 4 waves on 8x8 maps, bit-identical outputs.  (Its BatchNorm partial
     // sums round differently in the last bit, which once looked like a defect: the bf16 full-size digest run is bimodal
     // in its second-iteration G loss -- 1.81 or 1.70 -- under ANY 1e-7 nudge of the batch sums, see tools/digest_probe.py
@@ -2574,6 +2579,7 @@ static const CfgEntry* bf16_table(int* n) {
         {64, 16, 12, launch_cp<T, 64, 16, 4, 1>},     {128, 16, 12, launch_cp<T, 128, 16, 4, 1>},
         {256, 256, 20, launch_pp<T, 256, 256, 2, 4, 5, false>}, {256, 128, 20, launch_pp<T, 256, 128, MCGEN_PP128_WM, 8 / MCGEN_PP128_WM, 5, false>},
         {128, 256, 20, launch_pp<T, 128, 256, 2, 4, 5, false>},
+        {128, 64, 5, launch_dma<T, 128, 64, 2, 2>},
 #ifdef MCGEN_TUNING
         {128, 256, 4, launch_dma1<T, 128, 256, 1, 4>}, {128, 256, 14, launch_dma1<T, 128, 256, 2, 4>},
         {256, 128, 15, launch_dma<T, 256, 128, 4, 1>}, {256, 128, 16, launch_dma<T, 256, 128, 2, 2>},
@@ -2582,6 +2588,8 @@ static const CfgEntry* bf16_table(int* n) {
         {128, 16, 5, launch_dma<T, 128, 16, 4, 1>},   {64, 16, 5, launch_dma<T, 64, 16, 4, 1>},
         {64, 64, 12, launch_cp<T, 64, 64, 2, 2>},     {32, 64, 12, launch_cp<T, 32, 64, 1, 2>},
         {64, 128, 9, launch_dma<T, 64, 128, 4, 4>},   {64, 64, 9, launch_dma<T, 64, 64, 4, 4>},
+        {256, 64, 5, launch_dma<T, 256, 64, 4, 2>},   {128, 64, 15, launch_dma<T, 128, 64, 4, 2>},
+        {256, 64, 15, launch_dma<T, 256, 64, 2, 2>},  {128, 64, 16, launch_dma<T, 128, 64, 2, 1>},
 #endif
     };
     *n = (int)(sizeof(t) / sizeof(t[0]));

@@ -861,6 +861,61 @@ def test_deep_1x1_grouped_form(dtype):
     _assert_close(ops.to_nchw(y2, 96), ref2, dtype, 'deep 1x1 ragged')
 
 
+@pytest.mark.parametrize('case', ['two_seg_stats', 'pooled', 'gated', 'ups_groups'])
+def test_64_channel_layers_on_large_maps(case):
+    """COIL100's 64-channel convolutions on 32x32 / 16x16 maps (G [512, 256, 128, 64], D [64, 128, 256, 512]) take the
+    128-pixel x 64-channel four-wave tile from 65536 pixels up (pick_tile; the 64 x 64 tile below that): forward with
+    BatchNorm partial sums and a fused 1x1 shortcut, the pooled first-block form, the ReLU-gated input gradient, the
+    upsampled input with BatchNorm statistics groups -- each against F.conv2d."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(977)
+    n, h, c = 80, 32, 64
+    code = (torch.rand(n, c, generator=g) < 0.5).float()
+    b = _rnd(g, c)
+    if case == 'two_seg_stats':
+        x, xl = _hot(_rnd(g, n, c, h, h)), _rnd(g, n, 128, h // 2, h // 2)
+        sc, sh = _rnd(g, c) * 0.5 + 1, _rnd(g, c) * 0.3
+        code1 = (torch.rand(n, 128, generator=g) < 0.5).float()
+        w3, w1 = _rnd(g, c, c, 3, 3) * 0.05, _rnd(g, c, 128, 1, 1) * 0.08
+        a = _q(ref_prologue(_q(x, dtype), sc, sh, True, code, False), dtype)
+        a1 = _q(_q(xl, dtype) * code1[:, :, None, None], dtype).repeat_interleave(2, 2).repeat_interleave(2, 3)
+        ref = F.conv2d(a, _q(w3, dtype), b, padding=1) + F.conv2d(a1, _q(w1, dtype))
+        segs = [ops.Seg(_nhwc(ops, x, dtype), scale=sc.cuda(), shift=sh.cuda(), code=code.cuda(), relu=True),
+                ops.Seg(_nhwc(ops, xl, dtype), ksize=1, code=code1.cuda(), ups=True)]
+        wimg = torch.cat([ops.prep_weight(w3.cuda(), dtype), ops.prep_weight(w1.cuda(), dtype)])
+        (y, st), tiles = _conv_logged(ops, segs, wimg, c, bias=b.cuda(), stats_mode=1)
+        s = st.double().sum(0).cpu()
+        np.testing.assert_allclose(s[0, :c], ref.double().sum((0, 2, 3)), rtol=2e-2, atol=4e-3 * float(ref.abs().sum((0, 2, 3)).max()))
+    elif case == 'pooled':
+        x, img = _hot(_rnd(g, n, c, h, h)), _rnd(g, n, 3, h, h)
+        w3, w1 = _rnd(g, c, c, 3, 3) * 0.05, _rnd(g, c, 3, 1, 1) * 0.3
+        a = _q(torch.relu(_q(x, dtype)) * code[:, :, None, None], dtype)
+        ref = F.avg_pool2d(F.conv2d(a, _q(w3, dtype), None, padding=1) + F.conv2d(_q(img, dtype), _q(w1, dtype)), 2) + b.view(1, -1, 1, 1)
+        segs = [ops.Seg(_nhwc(ops, x, dtype), code=code.cuda(), relu=True), ops.Seg(_nhwc(ops, img, dtype), ksize=1)]
+        wimg = torch.cat([ops.prep_weight(w3.cuda(), dtype), ops.prep_weight(w1.cuda(), dtype)])
+        (y, _), tiles = _conv_logged(ops, segs, wimg, c, bias=b.cuda(), pool=True, alpha=0.25)
+    elif case == 'gated':
+        dy, xg = _rnd(g, n, c, h, h), _rnd(g, n, c, h, h)
+        wt = _rnd(g, c, c, 3, 3) * 0.05
+        ref = F.conv_transpose2d(_q(dy, dtype), _q(wt, dtype), padding=1) * code[:, :, None, None] * (_q(xg, dtype) > 0)
+        (y, _), tiles = _conv_logged(ops, [ops.Seg(_nhwc(ops, dy, dtype))], ops.prep_weight(wt.cuda(), dtype, transpose=True), c,
+                                     ocode=code.cuda(), gate_x=_nhwc(ops, xg, dtype))
+    else:
+        xl = _rnd(g, n, 128, h // 2, h // 2)
+        sc, sh = _rnd(g, 5, 128) * 0.5 + 1, _rnd(g, 5, 128) * 0.3
+        code1 = (torch.rand(n, 128, generator=g) < 0.5).float()
+        w3 = _rnd(g, c, 128, 3, 3) * 0.05
+        gi = torch.arange(n) // 16
+        a = torch.relu(_q(xl, dtype) * sc[gi][:, :, None, None] + sh[gi][:, :, None, None]) * code1[:, :, None, None]
+        ref = F.conv2d(_q(a, dtype).repeat_interleave(2, 2).repeat_interleave(2, 3), _q(w3, dtype), b, padding=1)
+        seg = ops.Seg(_nhwc(ops, xl, dtype), scale=sc.cuda(), shift=sh.cuda(), code=code1.cuda(), ups=True, relu=True, group_n=16)
+        (y, _), tiles = _conv_logged(ops, [seg], ops.prep_weight(w3.cuda(), dtype), c, bias=b.cuda(), stats_mode=1)
+        y = y[0] if isinstance(y, tuple) else y
+    assert tiles == [(128, 64)], tiles
+    _assert_close(ops.to_nchw(y, c), ref, dtype, case)
+
+
 BIG_WG = [
     # N, H, Cin, Cout, ksize, ups(x), dy_ups: the weight-gradient launches of the bench (default split policy)
     (128, 32, 256, 256, 3, False, False),     # G block 2 conv_b
