@@ -2254,7 +2254,8 @@ static TilePick pick_tile(const mcgen_conv_t* p, int dtype) {
     if (M >= 65536 && rows256 && p->Cout_w > 64 && (pp_mode & 2) && pp_fits<256, 128, MCGEN_PP128_WM, 8 / MCGEN_PP128_WM, 5>(p)) return {256, 128, 20};
     if (M >= 65536 && rows128 && p->Cout_w > 64) return {128, 128, 5};
     if (M >= 32768 && rows128 && p->Cout_w > 128) return {128, 256, ((pp_mode & 8) && pp_fits<128, 256, 2, 4, 5>(p)) ? 20 : 5};
-    if (M >= 32768 && p->Cout_w > 64) return {64, 128, 5};
+    // (from 16384 pixels: COIL100's 256-channel 8x8 layers at 2N = 256 -- 60.5 -> 41.7 us against the 64 x 64 tile, tools/bench_c64.py)
+    if (M >= 16384 && p->Cout_w > 64) return {64, 128, 5};
     // 64-channel layers on large maps (COIL100's generator tail and discriminator head, 32x32): 128 pixels x 64 channels on FOUR
     // waves -- small enough for several workgroups per CU, and a 128-pixel window is 4 rows + 2 of halo where the 64 x 64 tile's is
     // 2 + 2.  tools/bench_c64.py: N = 640 128 -> 64 343 -> 148 us, 64 (+) 128 -> 64 307 -> 139; the discriminator's 84 -> 61, 70 -> 42
