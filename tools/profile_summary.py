@@ -88,16 +88,49 @@ def steady_table(src, dst, tag, meta, bench):
     if iters is None:
         print('(the steady-state bench printed no JSON line)')
         return
-    # launches outside the replayed iterations (capture warm-up, one-off setup) show up as a non-integer count per iteration:
-    # per-iteration figures use calls // iters for kernels that ran at least once per iteration
+    # The replayed iterations are found in the kernel TRACE: the launch-name sequence at the end of the run is periodic (one
+    # period = one iteration: the latent draw, the input copies, the graph's kernels); everything in front of the last
+    # `use` periods (pool draws, capture warm-up, the first replays) is left out.  Launch counts are then exact integers.
     groups = collections.OrderedDict()
     tot_us = tot_launch = 0.0
-    for r in rows:
-        calls, total = int(r['Calls']), float(r['TotalDurationNs']) / 1e3
-        n = bench_name(r['Name']) or ('~ ' + re.sub(r'\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d*', '', r['Name'])[:60])
-        g = groups.setdefault(n, [0, 0.0])
-        g[0] += calls; g[1] += total
-        tot_us += total; tot_launch += calls
+    tpath = os.path.join(src, 'steady', 's_kernel_trace.csv')
+    period = None
+    if os.path.exists(tpath):
+        tr = sorted(csv.DictReader(open(tpath)), key=lambda r: int(r['Start_Timestamp']))
+        names = [r['Kernel_Name'] for r in tr]
+        # (the run ends with a few launches that belong to no iteration -- the loss trace's copy to the host -- so the periodic
+        #  stretch is looked for at every end offset up to 64 launches)
+        end = len(names)
+        for off in range(0, 64):
+            e = len(names) - off
+            for P in range(8, min(4000, e // 2)):
+                if names[e - P:e] == names[e - 2 * P:e - P]:
+                    period, end = P, e
+                    break
+            if period:
+                break
+    if period:
+        # as many whole periods back from there as repeat exactly (a periodic state reset of the bench loop ends the run of them)
+        use = 2
+        while (use + 1) * period <= end and use < b['steps'] - 1 and \
+                names[end - (use + 1) * period:end - use * period] == names[end - period:end]:
+            use += 1
+        tr = tr[:end]
+        for r in tr[-use * period:]:
+            n = bench_name(r['Kernel_Name']) or ('~ ' + re.sub(r'\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d*', '', r['Kernel_Name'])[:60])
+            g = groups.setdefault(n, [0, 0.0])
+            g[0] += 1; g[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            tot_us += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3; tot_launch += 1
+        iters = use
+        print(f'(steady iterations from the kernel trace: period {period} launches, the last {use} iterations)')
+    else:
+        # no trace / no period found: aggregate counts over the whole run (non-integer launch counts per iteration)
+        for r in rows:
+            calls, total = int(r['Calls']), float(r['TotalDurationNs']) / 1e3
+            n = bench_name(r['Name']) or ('~ ' + re.sub(r'\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d*', '', r['Name'])[:60])
+            g = groups.setdefault(n, [0, 0.0])
+            g[0] += calls; g[1] += total
+            tot_us += total; tot_launch += calls
     by = (bench or {}).get('roofline', {}) or {}
     by = by.get('by_kernel', {})
     kernels = {}
