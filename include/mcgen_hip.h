@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_prep_weight_batch_codes, mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_prep_weight_batch_codes, mcgen_wgrad_batch, mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -192,6 +192,12 @@ int64_t mcgen_wgrad_c8_slab_elems(const mcgen_wgrad_t* p);      /* floats per sp
 #define MCGEN_WGRAD_MULTI_MAX 16
 int mcgen_wgrad_multi_ok(const mcgen_wgrad_t* p, int dtype);
 int mcgen_wgrad_multi(const mcgen_wgrad_t* layers, int n, int dtype, void* stream);
+/* n <= MCGEN_WGRAD_MULTI_MAX layers of IDENTICAL shape (N, H, W, channel pitches, ksize, ups / dy_ups, splits, bias slabs present
+ * or not; no two-half launches, no image layers) as one launch of the kernel mcgen_wgrad picks for that shape: grid z = layer x
+ * split.  Same slabs per layer as n calls of mcgen_wgrad.  MCGlow's coupling networks (mcglow.py:118-160) have 16 flows per
+ * level whose first (C/2 -> 512) and zero-initialised last (512 -> C) 3x3 convolutions have skinny weight gradients: 96 launches
+ * of 12-25 us per step one by one (bf16 only). */
+int mcgen_wgrad_batch(const mcgen_wgrad_t* layers, int n, int dtype, void* stream);
 /* grad[master layout] (+)= alpha * sum_s slabs[s]; master layout = [Cout][Cin][k][k] with
  * row co stored at (co % rows_inner) * row_perm + co / rows_inner when row_perm > 1
  * (the generator's Linear(128 -> C*4*4) viewed as NHWC, mcgan.py:51,67).

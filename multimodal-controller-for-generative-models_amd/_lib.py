@@ -125,6 +125,7 @@ SYMBOLS = {
     'mcgen_wgrad_c8_ok': (_i, [_vp, _i]),
     'mcgen_wgrad_c8_slab_elems': (_i64, [_vp]),
     'mcgen_wgrad_multi': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
+    'mcgen_wgrad_batch': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
     'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),

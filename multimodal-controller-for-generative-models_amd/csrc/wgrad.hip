@@ -69,7 +69,17 @@ template <> struct KFrag<float> {
 // an L2: the linear id is re-read as (xcd, slot) -> virtual id xcd * (total / 8) + slot, and (bx, by, bz) are decoded from
 // the virtual id with bx, by fastest.  Falls back to the identity when the grid is not a multiple of 8.
 struct WgIdx { int bx, by, bz; };
-static __device__ __forceinline__ WgIdx wg_remap(int enabled) {
+// Several layers of IDENTICAL shape in one launch (mcgen_wgrad_batch): blockIdx.z = layer * splits + split.  The kernels below
+// take either one mcgen_wgrad_t or this table; everything that depends on the layer is read through wg_layer().
+struct WgBatch { mcgen_wgrad_t l[MCGEN_WGRAD_MULTI_MAX]; int splits; };
+static __device__ __forceinline__ const mcgen_wgrad_t& wg_layer(const mcgen_wgrad_t& a) { return a; }
+static __device__ __forceinline__ const mcgen_wgrad_t& wg_layer(const WgBatch& a) { return a.l[blockIdx.z / a.splits]; }
+static __device__ __forceinline__ int wg_splits(const mcgen_wgrad_t&) { return (int)gridDim.z; }
+static __device__ __forceinline__ int wg_splits(const WgBatch& a) { return a.splits; }
+static __device__ __forceinline__ WgIdx wg_remap(const WgBatch& a, int) {
+    return WgIdx{(int)blockIdx.x, (int)blockIdx.y, (int)(blockIdx.z % a.splits)};
+}
+static __device__ __forceinline__ WgIdx wg_remap(const mcgen_wgrad_t&, int enabled) {
     WgIdx r{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
     const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
     if (!enabled || (total & 7)) return r;
@@ -84,9 +94,10 @@ static __device__ __forceinline__ WgIdx wg_remap(int enabled) {
 // 32-pixel step it reads 2 dy fragments + NTAP window fragments for 2*NTAP MFMAs (small footprint:
 // 72 accumulator registers, ~35 KB LDS -> several workgroups per CU hide each other's staging latency).
 // LGW = log2(W) is a template parameter so that every tap offset is an instruction immediate.
-template <typename T, int KS, int LGW>
+template <typename T, int KS, int LGW, typename PA = mcgen_wgrad_t>
 __global__ __launch_bounds__(WG_NT, 3)
-void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
+void wgrad_kernel(const PA pa, const int a_bytes, const int m_tiles, const int xcd_map) {
+    const mcgen_wgrad_t& p = wg_layer(pa);
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
@@ -105,7 +116,7 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, N = p.N;
-    const WgIdx wi = wg_remap(xcd_map);
+    const WgIdx wi = wg_remap(pa, xcd_map);
     const int co0 = wi.bx * WG_BCO;
     const int q = wi.by;                            // input-channel chunk
     const int c0 = q * MCGEN_CK;
@@ -153,7 +164,7 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, c
     PatchStager<T, WG_NT, NI, APITCH> stager;
     stager.setup_static(KS, g0, W, tid);
     // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
-    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int zs = p.halves ? (wg_splits(pa) >> 1) : wg_splits(pa);
     const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
     const int t_lo = p.halves ? (wi.bz / zs) * mt : 0;
     for (int tile = t_lo + wi.bz % zs; tile < t_lo + mt; tile += zs) {
@@ -245,9 +256,10 @@ void wgrad_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, c
 // DDMA (bf16, whole tiles only): the dy tile goes global -> LDS by LDS-DMA instead of through producer registers: rows
 // of 128 bytes without padding, 16-byte units XOR-swizzled by ((row >> 1) & 3) << 1 (applied on the SOURCE address) so
 // that the transposing reads stay conflict-free; the producers' registers then hold only the x window.
-template <typename T, int KS, int LGW, int NCH, bool DDMA>
+template <typename T, int KS, int LGW, int NCH, bool DDMA, typename PA = mcgen_wgrad_t>
 __global__ __launch_bounds__(2 * WG_NT, 2)
-void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
+void wgrad_pc_kernel(const PA pa, const int a_bytes, const int m_tiles, const int xcd_map) {
+    const mcgen_wgrad_t& p = wg_layer(pa);
     using E = Elem<T>;
     using M = Mma<T>;
     using TR = WgTraits<T>;
@@ -275,7 +287,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H, N = p.N;
-    const WgIdx wi = wg_remap(xcd_map);
+    const WgIdx wi = wg_remap(pa, xcd_map);
     const int co0 = wi.bx * WG_BCO;
     const int q = wi.by;
     const int c0 = q * NCH * MCGEN_CK;
@@ -286,7 +298,7 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
     const Geo g0 = make_geo(WG_BM, 0, H, W);
     const int PR = g0.TH + 2 * halo;
     // tile walk of this split: all tiles with stride gridDim.z, or (p.halves) one half of the tiles with stride gridDim.z / 2
-    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int zs = p.halves ? (wg_splits(pa) >> 1) : wg_splits(pa);
     const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
     const int t_first = (p.halves ? (wi.bz / zs) * mt : 0) + wi.bz % zs;
     const int cnt = (mt - wi.bz % zs + zs - 1) / zs;                          // tiles of this workgroup
@@ -510,9 +522,10 @@ void wgrad_pc_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles
 // Measured 598 -> 641 TFLOP/s on that layer (525 -> 576, 506 -> 539 on the next two).
 constexpr int WG_DSLOT = WG_BM * WG_BCO * 2;      // one dy tile, unpadded bf16 rows
 constexpr int WG_ND = 4, WG_NR = 3;               // ring depths: dy tiles, raw windows
-template <int KS, int LGW>
+template <int KS, int LGW, typename PA = mcgen_wgrad_t>
 __global__ __launch_bounds__(3 * WG_NT, 1)
-void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_tiles, const int xcd_map) {
+void wgrad_ring_kernel(const PA pa, const int a_bytes, const int m_tiles, const int xcd_map) {
+    const mcgen_wgrad_t& p = wg_layer(pa);
     typedef bf16_t T;
     using E = Elem<T>;
     using M = Mma<T>;
@@ -542,12 +555,12 @@ void wgrad_ring_kernel(const mcgen_wgrad_t p, const int a_bytes, const int m_til
     const int lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6), wave = cw & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int H = p.H;
-    const WgIdx wi = wg_remap(xcd_map);
+    const WgIdx wi = wg_remap(pa, xcd_map);
     const int co0 = wi.bx * WG_BCO;
     const int q = wi.by;
     const int c0 = q * MCGEN_CK;
     const mcgen_seg_t sg = p.seg;
-    const int zs = p.halves ? (int)(gridDim.z >> 1) : (int)gridDim.z;
+    const int zs = p.halves ? (wg_splits(pa) >> 1) : wg_splits(pa);
     const int mt = p.halves ? (m_tiles >> 1) : m_tiles;
     const int t_first = (p.halves ? (wi.bz / zs) * mt : 0) + wi.bz % zs;
     const int cnt = (mt - wi.bz % zs + zs - 1) / zs;                   // tiles of this workgroup (>= 1)
@@ -885,15 +898,15 @@ static long wg_env(const char* name, long dflt) { const char* e = getenv(name); 
 static long wg_env(const char*, long dflt) { return dflt; }
 #endif
 
-template <typename T, int KS, int LGW>
-static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
+template <typename T, int KS, int LGW, typename PA>
+static int launch(const mcgen_wgrad_t* p, const PA& pa, int nlayers, hipStream_t st) {
     using TR = WgTraits<T>;
     const long Mtot = (long)p->N * p->H * p->W;
     const int m_tiles = (int)((Mtot + WG_BM - 1) / WG_BM);
     const int PP = mcgen_patch_pixels(WG_BM, p->H, p->W, KS);
     const int a_bytes = round_up(PP * TR::APITCH, 32);
     const int lds = a_bytes + WG_BM * TR::DPITCH;
-    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits);
+    dim3 grid((p->Cout_w + WG_BCO - 1) / WG_BCO, wgrad_chunks(p), p->splits * nlayers);
     // tuning builds (-DMCGEN_TUNING) read these once per process; the shipped library has no environment-dependent dispatch
     static const int xcd_map = (int)wg_env("MCGEN_WGRAD_XCD", 1);
     static const int mode = (int)wg_env("MCGEN_WGRAD_MODE", -1);      // 0 single role, 1 producer/consumer, -1 policy
@@ -908,14 +921,14 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
         // (upsampled reads need tiles that start on even rows: at least two rows per tile)
         const bool ups_ok = (!p->seg.ups && !p->dy_ups) || (WG_BM / (1 << LGW)) % 2 == 0;
         if (pc && ring && (long)p->H * p->W >= WG_BM && ups_ok && Mtot % WG_BM == 0 && ldsr <= 160 * 1024) {
-            auto kr = wgrad_ring_kernel<KS, LGW>;
+            auto kr = wgrad_ring_kernel<KS, LGW, PA>;
             static bool raisedr = false;
             if (!raisedr) {
                 raisedr = true;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, ldsr);
                 if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
             }
-            hipLaunchKernelGGL(kr, grid, dim3(3 * WG_NT), ldsr, st, *p, a_bytes, m_tiles, xcd_map);
+            hipLaunchKernelGGL(kr, grid, dim3(3 * WG_NT), ldsr, st, pa, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(ring)");
             return 0;
         }
@@ -926,15 +939,15 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
         static const int grp = (int)wg_env("MCGEN_WGRAD_GROUP", 1);
         const int lds4 = 2 * NCH * a_bytes + 2 * WG_BM * TR::DPITCH;     // bf16: 136 KB; fp32 does not fit -> plain path
         if (pc && wgrad_chunks(p) >= NCH && lds4 <= 160 * 1024 && grp) {
-            auto kern4 = wgrad_pc_kernel<T, 1, LGW, NCH, false>;
+            auto kern4 = wgrad_pc_kernel<T, 1, LGW, NCH, false, PA>;
             static bool raised4 = false;
             if (lds4 > 64 * 1024 && !raised4) {
                 raised4 = true;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
                 if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
             }
-            dim3 grid4((p->Cout_w + WG_BCO - 1) / WG_BCO, (wgrad_chunks(p) + NCH - 1) / NCH, p->splits);
-            hipLaunchKernelGGL(kern4, grid4, dim3(2 * WG_NT), lds4, st, *p, a_bytes, m_tiles, xcd_map);
+            dim3 grid4((p->Cout_w + WG_BCO - 1) / WG_BCO, (wgrad_chunks(p) + NCH - 1) / NCH, p->splits * nlayers);
+            hipLaunchKernelGGL(kern4, grid4, dim3(2 * WG_NT), lds4, st, pa, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(pc, chunk groups)");
             return 0;
         }
@@ -945,74 +958,67 @@ static int launch(const mcgen_wgrad_t* p, hipStream_t st) {
         static const int dy_dma = (int)wg_env("MCGEN_WGRAD_DMA", 0);
         if (pc && dy_dma && Mtot % WG_BM == 0) {
             const int ldsd = 2 * a_bytes + 2 * WG_BM * WG_BCO * 2;
-            auto kd = wgrad_pc_kernel<T, KS, LGW, 1, true>;
+            auto kd = wgrad_pc_kernel<T, KS, LGW, 1, true, PA>;
             static bool raisedd = false;
             if (ldsd > 64 * 1024 && !raisedd) {
                 raisedd = true;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, ldsd);
                 if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
             }
-            hipLaunchKernelGGL(kd, grid, dim3(2 * WG_NT), ldsd, st, *p, a_bytes, m_tiles, xcd_map);
+            hipLaunchKernelGGL(kd, grid, dim3(2 * WG_NT), ldsd, st, pa, a_bytes, m_tiles, xcd_map);
             MCGEN_LAUNCH_CHECK("wgrad(pc, dy dma)");
             return 0;
         }
     }
     if (pc) {
         const int lds2 = 2 * a_bytes + 2 * WG_BM * TR::DPITCH;
-        auto kern2 = wgrad_pc_kernel<T, KS, LGW, 1, false>;
+        auto kern2 = wgrad_pc_kernel<T, KS, LGW, 1, false, PA>;
         static bool raised2 = false;
         if (lds2 > 64 * 1024 && !raised2) {
             raised2 = true;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kern2, grid, dim3(2 * WG_NT), lds2, st, *p, a_bytes, m_tiles, xcd_map);
+        hipLaunchKernelGGL(kern2, grid, dim3(2 * WG_NT), lds2, st, pa, a_bytes, m_tiles, xcd_map);
         MCGEN_LAUNCH_CHECK("wgrad(pc)");
         return 0;
     }
-    auto kern = wgrad_kernel<T, KS, LGW>;
+    auto kern = wgrad_kernel<T, KS, LGW, PA>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         raised = true;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return mcgen_fail("wgrad: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, *p, a_bytes, m_tiles, xcd_map);
+    hipLaunchKernelGGL(kern, grid, dim3(WG_NT), lds, st, pa, a_bytes, m_tiles, xcd_map);
     MCGEN_LAUNCH_CHECK("wgrad");
     return 0;
 }
 
-template <typename T>
-static int launch_t(const mcgen_wgrad_t* p, hipStream_t st) {
+template <typename T, typename PA>
+static int launch_t(const mcgen_wgrad_t* p, const PA& pa, int nlayers, hipStream_t st) {
     const int lgw = ilog2_exact(p->W);
     if (p->seg.ksize == 3) {
         switch (lgw) {
-            case 2: return launch<T, 3, 2>(p, st);
-            case 3: return launch<T, 3, 3>(p, st);
-            case 4: return launch<T, 3, 4>(p, st);
-            case 5: return launch<T, 3, 5>(p, st);
+            case 2: return launch<T, 3, 2, PA>(p, pa, nlayers, st);
+            case 3: return launch<T, 3, 3, PA>(p, pa, nlayers, st);
+            case 4: return launch<T, 3, 4, PA>(p, pa, nlayers, st);
+            case 5: return launch<T, 3, 5, PA>(p, pa, nlayers, st);
         }
     } else {
         switch (lgw) {
-            case 0: return launch<T, 1, 0>(p, st);
-            case 1: return launch<T, 1, 1>(p, st);
-            case 2: return launch<T, 1, 2>(p, st);
-            case 3: return launch<T, 1, 3>(p, st);
-            case 4: return launch<T, 1, 4>(p, st);
-            case 5: return launch<T, 1, 5>(p, st);
+            case 0: return launch<T, 1, 0, PA>(p, pa, nlayers, st);
+            case 1: return launch<T, 1, 1, PA>(p, pa, nlayers, st);
+            case 2: return launch<T, 1, 2, PA>(p, pa, nlayers, st);
+            case 3: return launch<T, 1, 3, PA>(p, pa, nlayers, st);
+            case 4: return launch<T, 1, 4, PA>(p, pa, nlayers, st);
+            case 5: return launch<T, 1, 5, PA>(p, pa, nlayers, st);
         }
     }
     return mcgen_fail("wgrad: no instantiation for ksize %d at W = %d", p->seg.ksize, p->W);
 }
 
-}  // namespace
-
-extern "C" int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p) {
-    if (!p) return 0;
-    return (int64_t)wgrad_chunks(p) * p->seg.ksize * p->seg.ksize * p->Cout_w * MCGEN_CK;
-}
-
-extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
+static int wgrad_check(const mcgen_wgrad_t* p) {
     MCGEN_CHECK(p && p->seg.x && p->dy && p->slabs, "wgrad: null pointer");
     MCGEN_CHECK(p->N > 0 && ilog2_exact(p->H) >= 0 && ilog2_exact(p->W) >= 0 && p->W <= 64, "wgrad: H, W must be powers of two, W <= 64");
     MCGEN_CHECK(WG_BM >= 2 * p->W || p->H * p->W <= WG_BM, "wgrad: W too large for the pixel tile");
@@ -1024,11 +1030,46 @@ extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
     MCGEN_CHECK(!p->halves || (p->splits % 2 == 0 && (((long)p->N * p->H * p->W + WG_BM - 1) / WG_BM) % 2 == 0 && ((long)p->N * p->H * p->W) % (2 * WG_BM) == 0),
                 "wgrad: halves needs even splits and a whole number of pixel tiles per half");
     MCGEN_CHECK(!p->dy_ups || (p->H >= 2 && p->W >= 2), "wgrad: dy_ups needs H, W >= 2");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t mcgen_wgrad_slab_elems(const mcgen_wgrad_t* p) {
+    if (!p) return 0;
+    return (int64_t)wgrad_chunks(p) * p->seg.ksize * p->seg.ksize * p->Cout_w * MCGEN_CK;
+}
+
+extern "C" int mcgen_wgrad(const mcgen_wgrad_t* p, int dtype, void* stream) {
+    if (int rc = wgrad_check(p)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mcgen_wgrad_c8_ok(p, dtype)) return mcgen_wgrad_c8(p, st);      // the image-side layers: a stream over dy (wgrad_c8.hip)
-    if (dtype == MCGEN_F32) return launch_t<float>(p, st);
-    if (dtype == MCGEN_BF16) return launch_t<bf16_t>(p, st);
+    if (dtype == MCGEN_F32) return launch_t<float, mcgen_wgrad_t>(p, *p, 1, st);
+    if (dtype == MCGEN_BF16) return launch_t<bf16_t, mcgen_wgrad_t>(p, *p, 1, st);
     return mcgen_fail("wgrad: unknown dtype %d", dtype);
+}
+
+// n layers of identical shape (geometry, channel pitches, kernel size, splits, the same operands present) as ONE launch of the
+// kernel mcgen_wgrad would pick for each: MCGlow's 96 skinny 3x3 gradients per step (the coupling nets' first and last
+// convolutions, 16 flows per level) are launch-latency bound one by one.
+extern "C" int mcgen_wgrad_batch(const mcgen_wgrad_t* layers, int n, int dtype, void* stream) {
+    MCGEN_CHECK(layers && n >= 1 && n <= MCGEN_WGRAD_MULTI_MAX, "wgrad_batch: 1 .. %d layers per launch", MCGEN_WGRAD_MULTI_MAX);
+    MCGEN_CHECK(dtype == MCGEN_BF16, "wgrad_batch: bf16 only");
+    WgBatch a;
+    const mcgen_wgrad_t& f = layers[0];
+    for (int i = 0; i < n; ++i) {
+        const mcgen_wgrad_t& p = layers[i];
+        if (int rc = wgrad_check(&p)) return rc;
+        MCGEN_CHECK(!mcgen_wgrad_c8_ok(&p, dtype) && !p.halves, "wgrad_batch: layer %d belongs to another kernel (image layer / two-half launch)", i);
+        MCGEN_CHECK(p.N == f.N && p.H == f.H && p.W == f.W && p.Cout == f.Cout && p.Cout_w == f.Cout_w && p.Cdy == f.Cdy && p.dy_ups == f.dy_ups &&
+                    p.splits == f.splits && p.seg.C == f.seg.C && p.seg.ksize == f.seg.ksize && p.seg.ups == f.seg.ups &&
+                    (p.bias_slabs != nullptr) == (f.bias_slabs != nullptr), "wgrad_batch: layer %d differs in shape from layer 0", i);
+        a.l[i] = p;
+    }
+    for (int i = n; i < MCGEN_WGRAD_MULTI_MAX; ++i) a.l[i] = f;
+    a.splits = f.splits;
+    MCGEN_CHECK((long)f.splits * n <= 65535, "wgrad_batch: too many splits x layers for one grid");
+    return launch_t<bf16_t, WgBatch>(&f, a, n, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int mcgen_wgrad_reduce(const float* slabs, int splits, float* grad, int Cout, int Cin, int ksize,

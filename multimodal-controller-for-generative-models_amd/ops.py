@@ -514,6 +514,17 @@ def wgrad(seg: Seg, dy: Tensor, cout: int, cin: int, grad: Tensor, *, dy_ups: bo
         _deferred.append(_PendingMulti(p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm,
                                        row_scale, m_tiles, (pad16(cout) // 128) * (seg.x.shape[-1] // 64), (tap0, ntap_out)))
         return
+    if (_deferred is not None and _BATCH and dtype == torch.bfloat16 and not c8 and second is None and explicit_splits is None
+            and not _SIDE and splits * _lib.WGRAD_MULTI_MAX <= 65535):
+        # Layers the pass-wide kernel does not take (skinny channel counts, 4x4 maps ...) wait for the end of the pass too: those of
+        # IDENTICAL shape share one launch of their kernel (mcgen_wgrad_batch: MCGlow has 16 flows per level)
+        if not grad.is_contiguous():
+            raise _lib.McgenError('deferred wgrad reduce needs a contiguous gradient tensor')
+        q = _PendingMulti(p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, None, alpha, accumulate, row_perm, row_scale, m_tiles, 0,
+                          (tap0, ntap_out))
+        q.splits, q.batch = splits, True
+        _deferred.append(q)
+        return
     elems = int(lib.mcgen_wgrad_c8_slab_elems(C.byref(p)) if c8 else lib.mcgen_wgrad_slab_elems(C.byref(p)))
     # Inside a deferred_reduces() pass the split-K kernel goes to a side stream: it depends only on tensors that
     # already exist, and nothing reads its slabs before the pass's batched reduce, so it overlaps the
@@ -560,6 +571,8 @@ MULTI_LOG = None         # tools: receives (map side, ksize, 128-pixel steps, ti
 WGRAD_LOG = None         # tests: a list that receives which weight-gradient kernel family a call with default splits takes
 _deferred = None
 _MULTI = _flag('MCGEN_WGRAD_MULTI', '1') != '0'        # eligible 3x3 weight gradients of a pass as one mcgen_wgrad_multi launch
+_BATCH = _flag('MCGEN_WGRAD_BATCH', '1') != '0'        # the other layers of a pass: same-shape groups as one mcgen_wgrad_batch launch
+BATCH_LOG = None                                       # tools / tests: receives the layer count of every mcgen_wgrad_batch launch
 _CU_COUNT = {}
 
 
@@ -573,11 +586,12 @@ def _cu_count(device) -> int:
 class _PendingMulti:
     """One queued layer of a mcgen_wgrad_multi launch (see ops.wgrad)."""
     __slots__ = ('p', 'seg', 'dy', 'cout', 'cin', 'grad', 'bias_grad', 'bias_grad2', 'second', 'alpha', 'accumulate', 'row_perm',
-                 'row_scale', 'm_tiles', 'blocks', 'splits', 'slabs', 'bias_slabs', 'taps')
+                 'row_scale', 'm_tiles', 'blocks', 'splits', 'slabs', 'bias_slabs', 'taps', 'batch')
 
     def __init__(self, p, seg, dy, cout, cin, grad, bias_grad, bias_grad2, second, alpha, accumulate, row_perm, row_scale, m_tiles, blocks,
                  taps=(0, 0)):
         self.taps = taps
+        self.batch = False            # True: a layer of a same-shape batch (mcgen_wgrad_batch), splits already chosen
         self.p, self.seg, self.dy, self.cout, self.cin = p, seg, dy, cout, cin
         self.grad, self.bias_grad, self.bias_grad2, self.second = grad, bias_grad, bias_grad2, second
         self.alpha, self.accumulate, self.row_perm, self.row_scale = alpha, accumulate, row_perm, row_scale
@@ -675,6 +689,42 @@ def _launch_multi(pend):
                lambda: nbytes, lambda: extra)
 
 
+def _launch_batches(pend):
+    """Queued layers outside mcgen_wgrad_multi: groups of identical shape as one mcgen_wgrad_batch launch each (<= MCGEN_WGRAD_MULTI_MAX
+    layers), the rest one by one; slabs allocated here, the reduce jobs follow with the pass's batched reduce."""
+    lib = _lib.load()
+    groups = {}
+    for q in pend:
+        p = q.p
+        key = (p.N, p.H, p.W, p.Cout, p.Cout_w, p.Cdy, p.dy_ups, p.splits, p.seg.C, p.seg.ksize, p.seg.ups, q.bias_grad is not None)
+        groups.setdefault(key, []).append(q)
+    for grp_all in groups.values():
+        for base in range(0, len(grp_all), _lib.WGRAD_MULTI_MAX):
+            grp = grp_all[base:base + _lib.WGRAD_MULTI_MAX]
+            dev = grp[0].dy.device
+            arr = (_lib.Wgrad * len(grp))()
+            flops = nbytes = extra = 0.0
+            for a, q in zip(arr, grp):
+                elems = int(lib.mcgen_wgrad_slab_elems(C.byref(q.p)))
+                q.slabs = torch.empty((q.splits, elems), dtype=torch.float32, device=dev)
+                q.bias_slabs = (torch.empty((q.splits * 4, pad16(q.cout)), dtype=torch.float32, device=dev)
+                                if q.bias_grad is not None else None)
+                q.p.slabs, q.p.bias_slabs = _p(q.slabs), _p(q.bias_slabs)
+                C.memmove(C.byref(a), C.byref(q.p), C.sizeof(_lib.Wgrad))
+                flops += 2.0 * q.p.N * q.p.H * q.p.W * q.cout * q.seg.x.shape[-1] * q.seg.ksize ** 2
+                nbytes += _nbytes(q.seg.x, q.dy) + 4 * (q.cout * q.cin * q.seg.ksize ** 2 + (q.cout if q.bias_grad is not None else 0))
+                extra += _nbytes(q.slabs, q.bias_slabs)
+            ks = grp[0].seg.ksize
+            if BATCH_LOG is not None:
+                BATCH_LOG.append(len(grp))
+            if len(grp) == 1:
+                _timed(lambda: f'wgrad<bf16,{ks}>', flops,
+                       lambda: check(lib.mcgen_wgrad(C.byref(grp[0].p), _lib.BF16, _stream()), 'wgrad'), lambda: nbytes, lambda: extra)
+            else:
+                _timed(lambda: f'wgrad<bf16,{ks}>', flops,
+                       lambda: check(lib.mcgen_wgrad_batch(arr, len(grp), _lib.BF16, _stream()), 'wgrad_batch'), lambda: nbytes, lambda: extra)
+
+
 _SIDE = _flag('MCGEN_SIDE_STREAM', '0') == '1'     # measured slower on MI355X (16.7 vs 15.7 ms/step): opt-in only
 _side_streams = {}
 _side_keep = []
@@ -715,11 +765,15 @@ class deferred_reduces:
     def __exit__(self, et, ev, tb):
         global _deferred
         jobs, _deferred = _deferred, self._outer
-        pend = [j for j in jobs if isinstance(j, _PendingMulti)]
-        if et is None and pend:
-            _launch_multi(pend)
+        pend = [j for j in jobs if isinstance(j, _PendingMulti) and not j.batch]
+        same = [j for j in jobs if isinstance(j, _PendingMulti) and j.batch]
+        if et is None and same:
+            _launch_batches(same)
+        if et is None and (pend or same):
+            if pend:
+                _launch_multi(pend)
             jobs = [t for j in jobs for t in (j.jobs() if isinstance(j, _PendingMulti) else [j])]
-        elif pend:
+        elif pend or same:
             jobs = [j for j in jobs if not isinstance(j, _PendingMulti)]
         if _SIDE and _side_keep:
             for s in _side_streams.values():                 # join: the slabs are complete before they are reduced

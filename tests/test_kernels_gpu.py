@@ -916,6 +916,49 @@ def test_64_channel_layers_on_large_maps(case):
     _assert_close(ops.to_nchw(y, c), ref, dtype, case)
 
 
+@pytest.mark.parametrize('shape', [(64, 16, 8, 512, 3), (64, 8, 512, 16, 3), (128, 4, 8, 512, 3), (32, 16, 64, 48, 1)])
+def test_same_shape_layers_share_one_launch(shape):
+    """mcgen_wgrad_batch (ops.deferred_reduces queues the layers mcgen_wgrad_multi does not take and launches groups of identical
+    shape together): MCGlow's skinny coupling-network gradients -- 8 -> 512 and 512 -> 16 at 16x16 / 8x8 / 4x4, 16 flows per
+    level.  Five layers with their own operands in one pass: ONE batched launch, every gradient and bias gradient bit for bit
+    what the layer gives alone, and within tolerance of the fp32 reference."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    n, h, ci, co, ks = shape
+    g = torch.Generator().manual_seed(31 + h + ci)
+    layers = []
+    for _ in range(5):
+        x, dy = _rnd(g, n, ci, h, h), _rnd(g, n, co, h, h) * 0.1
+        code = (torch.rand(n, ci, generator=g) < 0.5).float()
+        layers.append((x, dy, code))
+
+    def run(batched):
+        outs = []
+        old = ops._BATCH
+        ops._BATCH = batched
+        ops.BATCH_LOG = []
+        try:
+            with ops.deferred_reduces():
+                for x, dy, code in layers:
+                    gw = torch.zeros(co, ci, ks, ks, device='cuda'); gb = torch.zeros(co, device='cuda')
+                    ops.wgrad(ops.Seg(_nhwc(ops, x, dtype), ksize=ks, code=code.cuda(), relu=True), _nhwc(ops, dy, dtype), co, ci, gw, bias_grad=gb)
+                    outs.append((gw, gb))
+            torch.cuda.synchronize()
+            return outs, list(ops.BATCH_LOG)
+        finally:
+            ops._BATCH = old
+            ops.BATCH_LOG = None
+    one, log1 = run(False)
+    many, logn = run(True)
+    assert log1 == [] and logn == [5], (log1, logn)
+    for (gw1, gb1), (gwn, gbn), (x, dy, code) in zip(one, many, layers):
+        assert torch.equal(gw1, gwn) and torch.equal(gb1, gbn)
+        a = _q(torch.relu(_q(x, dtype)) * code[:, :, None, None], dtype)
+        ref = torch.nn.grad.conv2d_weight(a, (co, ci, ks, ks), _q(dy, dtype), padding=ks // 2)
+        _assert_close(gwn, ref, dtype, 'batched wgrad')
+        np.testing.assert_allclose(gbn.cpu(), _q(dy, dtype).sum((0, 2, 3)), rtol=2e-2, atol=2e-2 * float(dy.abs().sum((0, 2, 3)).max()))
+
+
 BIG_WG = [
     # N, H, Cin, Cout, ksize, ups(x), dy_ups: the weight-gradient launches of the bench (default split policy)
     (128, 32, 256, 256, 3, False, False),     # G block 2 conv_b

@@ -6,7 +6,7 @@ TREE=$GRAFT_REPO_ROOT/${KSTAT_TREE:-.}            # (KSTAT_TREE=ab_prev: the exp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/kstat_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $TREE/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --sustain-steps 0 --real-data uniform --pool 1 > $OUT/bench.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $TREE/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --sustain-steps 0 --real-data uniform --pool 1 ${KSTAT_ARGS:-} > $OUT/bench.log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
