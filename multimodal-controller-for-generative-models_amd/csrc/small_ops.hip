@@ -635,9 +635,24 @@ void sn_c1_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer
         float s = 0.f;
         if (live) {
             // four independent partial sums per wave (rows = wave + 4 k + 16 m), combined pairwise: the rounding error of a
-            // column stays at that of the 32-slice form (one serial chain over rows / 4 terms measurably moved sigma)
+            // column stays at that of the 32-slice form (one serial chain over rows / 4 terms measurably moved sigma).  The loop
+            // is unrolled four times so that 16 loads are in flight per lane -- COIL100's 512 x 4608 layer walked 32 dependent
+            // round trips per column (36 us per launch) -- with the SAME order of additions (more chains would be more
+            // accurate still, but moves sigma's last bits away from the oracle's: the eps = 1e-6 COIL100 pin sees it)
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int i = wave;
+            for (; i + 60 < rows; i += 64) {
+                float w_[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) w_[e] = W[(size_t)(i + 4 * e) * cols + j];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    a0 = fmaf(w_[4 * m], su[i + 16 * m], a0);
+                    a1 = fmaf(w_[4 * m + 1], su[i + 16 * m + 4], a1);
+                    a2 = fmaf(w_[4 * m + 2], su[i + 16 * m + 8], a2);
+                    a3 = fmaf(w_[4 * m + 3], su[i + 16 * m + 12], a3);
+                }
+            }
             for (; i + 12 < rows; i += 16) {
                 a0 = fmaf(W[(size_t)i * cols + j], su[i], a0);
                 a1 = fmaf(W[(size_t)(i + 4) * cols + j], su[i + 4], a1);
@@ -676,9 +691,17 @@ void sn_c3_kernel(const float* __restrict__ wb, float* uvb, const mcgen_sn_layer
     const int per = (rows + SN_RS - 1) / SN_RS;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     for (int i = r0 + wave; i < r1; i += nw) {
+        // (one chain per lane in column order, as the four-kernel form; 12 loads in flight: a 4608-column row is 72 terms per lane)
         float s = 0.f;
-#pragma unroll 6
-        for (int j = lane; j < cols; j += 64) s = fmaf(W[(size_t)i * cols + j], vt[j] * inv, s);      // (v itself, as the four-kernel form)
+        int j = lane;
+        for (; j + 64 * 11 < cols; j += 64 * 12) {
+            float w_[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) w_[e] = W[(size_t)i * cols + j + 64 * e];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) s = fmaf(w_[e], vt[j + 64 * e] * inv, s);                      // (v itself)
+        }
+        for (; j < cols; j += 64) s = fmaf(W[(size_t)i * cols + j], vt[j] * inv, s);
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
         if (lane == 0) wl[t_off + i] = s;
     }
