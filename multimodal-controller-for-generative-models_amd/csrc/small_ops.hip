@@ -848,6 +848,18 @@ __global__ void sn_grad_dot2_kernel(const float* __restrict__ g0, const float* _
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     size_t i = i0 + threadIdx.x;
     const size_t st = blockDim.x;
+    // (sixteen element pairs in flight per thread, the SAME four chains in the same order: COIL100's 2.4 M-element layers walked
+    //  72 dependent round trips per thread -- 41 us per launch)
+    for (; i + 15 * st < i1; i += 16 * st) {
+        float gq[16], wq[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { gq[e] = G[i + e * st]; wq[e] = W[i + e * st]; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            d0 = fmaf(gq[4 * m], wq[4 * m], d0); d1 = fmaf(gq[4 * m + 1], wq[4 * m + 1], d1);
+            d2 = fmaf(gq[4 * m + 2], wq[4 * m + 2], d2); d3 = fmaf(gq[4 * m + 3], wq[4 * m + 3], d3);
+        }
+    }
     for (; i + 3 * st < i1; i += 4 * st) {
         d0 = fmaf(G[i], W[i], d0); d1 = fmaf(G[i + st], W[i + st], d1);
         d2 = fmaf(G[i + 2 * st], W[i + 2 * st], d2); d3 = fmaf(G[i + 3 * st], W[i + 3 * st], d3);
@@ -1169,7 +1181,33 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
         unsigned i = i0 + threadIdx.x;
         unsigned r = i / cols, c = i - r * cols;
         const unsigned dr = blockDim.x / cols, dc = blockDim.x - dr * cols;
-        for (; i < i1; i += blockDim.x) {
+        // four elements per trip, every load of the trip issued before the first update (the same arithmetic per element: the
+        // single-element loop was one dependent round trip per element -- 72 per thread on COIL100's 2.4 M-element layers, 68 us)
+        const unsigned bd = blockDim.x;
+        for (; i + 3 * bd < i1; i += 4 * bd) {
+            float av[4], bv[4], pv[4], mv[4], vv[4], ur[4], vc[4], ur2[4], vc2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned k = i + e * bd;
+                av[e] = A[k]; bv[e] = B[k]; pv[e] = P[k]; mv[e] = M[k]; vv[e] = V[k];
+                ur[e] = ua[r]; vc[e] = va[c]; ur2[e] = ub[r]; vc2[e] = vb[c];
+                c += dc; r += dr;
+                if (c >= cols) { c -= cols; ++r; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned k = i + e * bd;
+                const float oa = (av[e] - da * ur[e] * vc[e]) * ia;
+                const float ob = (bv[e] - db * ur2[e] * vc2[e]) * ib;
+                float gi = oa + ob;
+                if (wd != 0.f) gi = fmaf(wd, pv[e], gi);
+                const float mi = fmaf(b1, mv[e], (1.f - b1) * gi);
+                const float vi = fmaf(b2, vv[e], (1.f - b2) * gi * gi);
+                M[k] = mi; V[k] = vi;
+                P[k] = pv[e] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+            }
+        }
+        for (; i < i1; i += bd) {
             const float oa = (A[i] - da * ua[r] * va[c]) * ia;
             const float ob = (B[i] - db * ub[r] * vb[c]) * ib;
             adam_elem(P, M, V, i, oa + ob, b1, b2, eps, wd, step_size, bc2s);
