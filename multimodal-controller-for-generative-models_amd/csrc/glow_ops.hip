@@ -443,7 +443,17 @@ __global__ void invconv_bwd_batch_kernel(const IcbJobs jobs) {
 __global__ void sqsum_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     __shared__ float red[32];
     float s = 0.f;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
+    // (eight loads in flight per thread, the same serial order of additions: one element per trip was a dependent round trip each)
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + 7 * st < n; i += 8 * st) {
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = g[i + e * st];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(q[e], q[e], s);
+    }
+    for (; i < n; i += st) s = fmaf(g[i], g[i], s);
     s = block_sum_g(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }

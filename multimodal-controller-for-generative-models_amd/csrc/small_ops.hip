@@ -1133,8 +1133,25 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
     const float step_size = lr / bc1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        adam_elem(p, m, v, i, g[i], b1, b2, eps, wd, step_size, bc2s);
+    // four elements per trip, all loads of the trip first (the same arithmetic per element)
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * st < n; i += 4 * st) {
+        float gv[4], pv[4], mv[4], vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const size_t k = i + e * st; gv[e] = g[k]; pv[e] = p[k]; mv[e] = m[k]; vv[e] = v[k]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t k = i + e * st;
+            float gi = gv[e];
+            if (wd != 0.f) gi = fmaf(wd, pv[e], gi);
+            const float mi = fmaf(b1, mv[e], (1.f - b1) * gi);
+            const float vi = fmaf(b2, vv[e], (1.f - b2) * gi * gi);
+            m[k] = mi; v[k] = vi;
+            p[k] = pv[e] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+        }
+    }
+    for (; i < n; i += st) adam_elem(p, m, v, i, g[i], b1, b2, eps, wd, step_size, bc2s);
     adam_step_ticket(step, gridDim.x);
 }
 
