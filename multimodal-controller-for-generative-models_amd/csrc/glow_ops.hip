@@ -92,6 +92,8 @@ struct PldJobs { mcgen_pld_t j[MCGEN_GLOW_PLD_MAX]; };
 __global__ void glow_param_logdet_batch_kernel(const PldJobs jobs, int njobs, float* __restrict__ logdet, int N) {
     __shared__ float red[32];
     float s = 0.f;
+    // (unrolled: the loads of eight flows go out together -- 48 flows one after the other were 48 dependent round trips, 34 us)
+#pragma unroll 8
     for (int f = 0; f < njobs; ++f) {
         const mcgen_pld_t& j = jobs.j[f];
         float t = 0.f;
@@ -462,7 +464,15 @@ __global__ void clip_scale_kernel(float* __restrict__ g, size_t n, const float* 
     __shared__ float coef;
     if (threadIdx.x == 0) {
         double s = 0.0;
-        for (int b = 0; b < blocks; ++b) s += (double)part[b];
+        int b = 0;
+        for (; b + 16 <= blocks; b += 16) {                     // (sixteen loads in flight, the same order of additions)
+            float q[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) q[e] = part[b + e];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += (double)q[e];
+        }
+        for (; b < blocks; ++b) s += (double)part[b];
         const float nrm = (float)sqrt(s);
         if (norm_out && blockIdx.x == 0) norm_out[0] = nrm;
         const float c = max_norm / (nrm + 1e-6f);

@@ -486,7 +486,16 @@ __global__ void colsum_stage2(const float* __restrict__ ws, int blocks, int C, f
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += (double)ws[(size_t)b * C + c];
+    // (eight loads in flight, the same order of additions)
+    int b = 0;
+    for (; b + 8 <= blocks; b += 8) {
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = ws[(size_t)(b + e) * C + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (double)q[e];
+    }
+    for (; b < blocks; ++b) s += (double)ws[(size_t)b * C + c];
     int o = c;
     if (row_perm > 1) { const int Cc = C / row_perm; o = (c % Cc) * row_perm + c / Cc; }
     const float v = alpha * (float)s;
