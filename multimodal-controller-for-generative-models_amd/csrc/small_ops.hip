@@ -1164,7 +1164,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     adam_step_ticket(step, gridDim.x);
 }
 
-constexpr int SNA_CHUNKS = 128;      // blocks per layer of the fused fix + Adam launch (the dot pass keeps SNF_CHUNKS partials per layer)
+#ifndef MCGEN_SNA_CHUNKS
+#define MCGEN_SNA_CHUNKS 512
+#endif
+constexpr unsigned SNA_MIN = 1024;   // elements per block at least: a small layer uses only the blocks it needs (the others return at once)
+constexpr int SNA_CHUNKS = MCGEN_SNA_CHUNKS;      // blocks per layer of the fused fix + Adam launch (the dot pass keeps SNF_CHUNKS partials per layer)
 // sn_grad_apply2_kernel with torch.optim.Adam's update in place of the store: the discriminator update of a single-rank
 // run never materialises d/d(weight_orig) -- g = fix(g0; uv0, sigma0) + fix(g1; uv1, sigma1) goes straight into m, v, p
 // (train_gan.py:154-158: backward, optimizer['discriminator'].step()).  The step counter was advanced by the dot launch
@@ -1176,12 +1180,20 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
                                         const float* __restrict__ sigma1, const float* __restrict__ partial, int nlayers,
                                         float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd,
                                         const int64_t* __restrict__ step) {
+    const mcgen_sn_layer_t L = layers[blockIdx.x];
+    {
+        // (512 blocks per layer serve COIL100's 2.4 M-element layers -- 128 left half the chip idle, 61 us -- and a block whose
+        //  chunk lies beyond a small layer's end leaves before it computes anything)
+        const unsigned nn = L.rows == 0 ? (unsigned)L.cols : (unsigned)L.rows * (unsigned)L.cols;
+        unsigned pp = (nn + SNA_CHUNKS - 1) / SNA_CHUNKS;
+        if (L.rows != 0 && pp < SNA_MIN) pp = SNA_MIN;
+        if ((unsigned)blockIdx.y * pp >= nn) return;
+    }
     if (lr_dev) lr = lr_dev[0];
     const long t = (long)step[0];
     const float bc1 = (float)(1.0 - adam_powi((double)b1, t));
     const float bc2s = (float)sqrt(1.0 - adam_powi((double)b2, t));
     const float step_size = lr / bc1;
-    const mcgen_sn_layer_t L = layers[blockIdx.x];
     const float* A = g0 + L.w_off; const float* B = g1 + L.w_off;
     float* P = pw + L.w_off; float* M = mo + L.w_off; float* V = vo + L.w_off;
     if (L.rows == 0) {
@@ -1202,7 +1214,8 @@ __global__ void sn_fix_pair_adam_kernel(const float* __restrict__ g0, const floa
         // 32-bit indices, and (row, column) stepped instead of divided out per element (a 64-bit division per element was
         // most of this kernel: 21 us per launch for 0.5 M parameters)
         const unsigned cols = (unsigned)L.cols, n = (unsigned)L.rows * cols;
-        const unsigned per = (n + SNA_CHUNKS - 1) / SNA_CHUNKS;
+        unsigned per = (n + SNA_CHUNKS - 1) / SNA_CHUNKS;
+        if (per < SNA_MIN) per = SNA_MIN;
         const unsigned i0 = blockIdx.y * per, i1 = (i0 + per < n) ? i0 + per : n;
         unsigned i = i0 + threadIdx.x;
         unsigned r = i / cols, c = i - r * cols;
