@@ -31,7 +31,7 @@ extern "C" {
 enum { MCGEN_F32 = 0, MCGEN_BF16 = 1 };
 
 const char* mcgen_last_error(void);
-int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_prep_weight_batch_codes, mcgen_wgrad_batch, mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
+int mcgen_abi_version(void);      /* 9: mcgen_conv_t.y_group (paired output layout of the image head), mcgen_onehot_rep, MCGEN_WREDUCE_MAX 32, mcgen_dtail_hinge_fused, mcgen_wgrad_c8_ok + tapcols slabs (mcgen_wgrad_reduce gained an argument), mcgen_mc_gather_batch(n_label, scale, n_half), mcgen_conv_t.wsel / wsel_stride / order / yperm + mcgen_prep_t.kmap / rmap (per-mode dense weight sets), mcgen_prep_weight_batch_codes, mcgen_wgrad_batch, mcgen_bn_finalize_batch, mcgen_gated_fwd_batch, mcgen_wreduce_t.tap0 / ntap_out; 8: mcgen_adam / mcgen_sn_fix_pair_adam take lr_dev (learning rate read on the device at execution time); 7: + mcgen_conv_form, mcgen_sn_power_iter_rounds, the MCGlow *_batch entry points, mcgen_sn_fix_pair_adam(advance_step); 6: + mcgen_wgrad_multi (5: + mcgen_conv_t.bias2, mcgen_sn_power_iter_snap; 4: compacted activations between forward-only launches) */
 
 /* One K-segment of a fused convolution: the input tensor and the prologue that
  * is applied while the tile is staged into LDS:
@@ -343,6 +343,16 @@ int mcgen_bn_finalize_groups(const float* partials, int tiles, int pitch, int fo
                              const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
                              void* stream);
+/* several INDEPENDENT BatchNorm layers (one statistics group each) in one launch: per layer what mcgen_bn_finalize does
+ * (MCGatedPixelCNN's vertical and horizontal gate BatchNorms of a layer, mcpixelcnn.py:16-20,44-56, wait for the same two
+ * convolutions and for nothing else) */
+#define MCGEN_BN_FIN_MAX 4
+typedef struct {
+    const float* partials; int32_t tiles, pitch, fold, C; double count;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
+    float* scale; float* shift; float* mean; float* rstd;
+} mcgen_bn_fin_t;
+int mcgen_bn_finalize_batch(const mcgen_bn_fin_t* jobs, int n, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int mcgen_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
@@ -560,6 +570,10 @@ int mcgen_col2im(const void* dcol, void* dx, int dtype, int N, int H, int W, int
  * out[.., C] = code * relu(a * scale + shift) * sigmoid(b), (scale, shift) = the BatchNorm affine of this batch */
 int mcgen_gated_fwd(const void* s, const float* scale, const float* shift, const float* code, void* out, int dtype,
                     int N, int HW, int C, void* stream);
+/* the same for up to MCGEN_GATED_MAX independent gates in one launch (a layer's vertical and horizontal gate) */
+#define MCGEN_GATED_MAX 4
+typedef struct { const void* s; const float* scale; const float* shift; const float* code; void* out; int32_t N, HW, C, _pad; } mcgen_gated_t;
+int mcgen_gated_fwd_batch(const mcgen_gated_t* jobs, int n, int dtype, void* stream);
 /* its backward, pass 1: ds = [dz | db] and per-block partial sums (sum dz, sum dz * xhat) as [blocks][2][C] */
 int mcgen_gated_bwd_stats(const void* s, const float* scale, const float* shift, const float* mean, const float* rstd,
                           const float* code, const void* g, void* ds, float* partials, int blocks, int dtype,

@@ -63,6 +63,18 @@ class Prep(C.Structure):
                 ('kmap', C.c_void_p), ('kcount', C.c_int32), ('_pad', C.c_int32), ('rmap', C.c_void_p)]
 
 
+class BnFin(C.Structure):                                  # mcgen_bn_fin_t
+    _fields_ = [('partials', C.c_void_p), ('tiles', C.c_int32), ('pitch', C.c_int32), ('fold', C.c_int32), ('C', C.c_int32),
+                ('count', C.c_double), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
+                ('running_var', C.c_void_p), ('momentum', C.c_float), ('eps', C.c_float),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p)]
+
+
+class Gated(C.Structure):                                  # mcgen_gated_t
+    _fields_ = [('s', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('code', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('HW', C.c_int32), ('C', C.c_int32), ('_pad', C.c_int32)]
+
+
 class Code(C.Structure):
     _fields_ = [('codebook', C.c_void_p), ('out_off', C.c_int64), ('M', C.c_int32), ('C', C.c_int32),
                 ('scale_idx', C.c_int32), ('_pad', C.c_int32)]
@@ -126,6 +138,8 @@ SYMBOLS = {
     'mcgen_wgrad_c8_slab_elems': (_i64, [_vp]),
     'mcgen_wgrad_multi': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
     'mcgen_wgrad_batch': (_i, [C.POINTER(Wgrad), _i, _i, _vp]),
+    'mcgen_bn_finalize_batch': (_i, [C.POINTER(BnFin), _i, _vp]),
+    'mcgen_gated_fwd_batch': (_i, [C.POINTER(Gated), _i, _i, _vp]),
     'mcgen_wgrad_reduce': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mcgen_weight_image_elems': (_i64, [_i, _i, _i, _i]),
     'mcgen_prep_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),

@@ -93,8 +93,8 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, in
 
 // ---- MCGatedActivation (mcpixelcnn.py:16-20): s = [a | b] (2C channels), out = code * relu(a*sc + sh) * sigmoid(b) ----
 template <typename T>
-__global__ void gated_fwd_kernel(const T* __restrict__ s, const float* __restrict__ sc, const float* __restrict__ sh,
-                                 const float* __restrict__ code, T* __restrict__ out, size_t pixels, int HW, int C) {
+__device__ __forceinline__ void gated_fwd_body(const T* __restrict__ s, const float* __restrict__ sc, const float* __restrict__ sh,
+                                               const float* __restrict__ code, T* __restrict__ out, size_t pixels, int HW, int C) {
     const int cv = C / 8;
     const size_t total = pixels * cv;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -110,6 +110,18 @@ __global__ void gated_fwd_kernel(const T* __restrict__ s, const float* __restric
         }
         Elem<T>::store8(out + p * C + c, o);
     }
+}
+template <typename T>
+__global__ void gated_fwd_kernel(const T* __restrict__ s, const float* __restrict__ sc, const float* __restrict__ sh,
+                                 const float* __restrict__ code, T* __restrict__ out, size_t pixels, int HW, int C) {
+    gated_fwd_body<T>(s, sc, sh, code, out, pixels, HW, C);
+}
+// the vertical and the horizontal gate of a layer (independent of each other) in one launch: blockIdx.y = gate
+struct GatedJobs { mcgen_gated_t j[MCGEN_GATED_MAX]; };
+template <typename T>
+__global__ void gated_fwd_batch_kernel(const GatedJobs jobs) {
+    const mcgen_gated_t& j = jobs.j[blockIdx.y];
+    gated_fwd_body<T>(reinterpret_cast<const T*>(j.s), j.scale, j.shift, j.code, reinterpret_cast<T*>(j.out), (size_t)j.N * j.HW, j.HW, j.C);
 }
 // backward pass 1: ds[:, :C] = dz = g * code * q * [z > 0], ds[:, C:] = g * code * relu(z) * q * (1 - q), q = sigmoid(b);
 // per-block partial sums of dz and dz * xhat (xhat = (a - mean) * rstd) in the conv-epilogue layout [blocks][2][C]
@@ -391,6 +403,22 @@ extern "C" int mcgen_gated_fwd(const void* s, const float* scale, const float* s
         hipLaunchKernelGGL(gated_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const float*)s, scale, shift, code, (float*)out, pixels, HW, C),
         hipLaunchKernelGGL(gated_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, STREAM(stream), (const bf16_t*)s, scale, shift, code, (bf16_t*)out, pixels, HW, C));
     MCGEN_LAUNCH_CHECK("gated_fwd"); return 0;
+}
+extern "C" int mcgen_gated_fwd_batch(const mcgen_gated_t* jobs, int n, int dtype, void* stream) {
+    MCGEN_CHECK(jobs && n >= 1 && n <= MCGEN_GATED_MAX, "gated_fwd_batch: 1 .. %d gates", MCGEN_GATED_MAX);
+    GatedJobs t; size_t most = 1;
+    for (int i = 0; i < n; ++i) {
+        const mcgen_gated_t& j = jobs[i];
+        MCGEN_CHECK(j.s && j.scale && j.shift && j.code && j.out && j.C % 8 == 0 && j.N > 0 && j.HW > 0, "gated_fwd_batch: bad job %d", i);
+        t.j[i] = j;
+        const size_t total = (size_t)j.N * j.HW * (j.C / 8);
+        if (total > most) most = total;
+    }
+    for (int i = n; i < MCGEN_GATED_MAX; ++i) t.j[i] = jobs[0];
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gated_fwd_batch_kernel<float>, dim3(grid_for(most), n), dim3(256), 0, STREAM(stream), t),
+        hipLaunchKernelGGL(gated_fwd_batch_kernel<bf16_t>, dim3(grid_for(most), n), dim3(256), 0, STREAM(stream), t));
+    MCGEN_LAUNCH_CHECK("gated_fwd_batch"); return 0;
 }
 extern "C" int mcgen_gated_bwd_stats(const void* s, const float* scale, const float* shift, const float* mean, const float* rstd,
                                      const float* code, const void* g, void* ds, float* partials, int blocks, int dtype,

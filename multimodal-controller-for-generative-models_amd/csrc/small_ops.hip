@@ -362,11 +362,11 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
     if (threadIdx.x < RED_CPB)
         for (int w = 0; w < RED_SLOTS; ++w) { s1 += sh[w][0][ch]; s2 += sh[w][1][ch]; }
 }
-__global__ __launch_bounds__(64 * RED_WAVES)
-void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count, int groups,
-                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                        float* rmean, float* rvar, float momentum, float eps,
-                        float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
+__device__ __forceinline__
+void bn_finalize_body(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count, int groups,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      float* rmean, float* rvar, float momentum, float eps,
+                      float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
     __shared__ double sh[RED_SLOTS][2][RED_CPB];
     const int c = blockIdx.x * RED_CPB + (threadIdx.x % RED_CPB);
     const bool owner = threadIdx.x < RED_CPB && c < C;
@@ -391,6 +391,23 @@ void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, in
         rv = (1.f - momentum) * rv + momentum * (float)unb;
     }
     if (owner && rmean) { rmean[c] = rm; rvar[c] = rv; }
+}
+__global__ __launch_bounds__(64 * RED_WAVES)
+void bn_finalize_kernel(const float* __restrict__ part, int tiles, int pitch, int fold, int C, double count, int groups,
+                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                        float* rmean, float* rvar, float momentum, float eps,
+                        float* scale, float* shift, float* mean_o, float* rstd_o, double perturb1, double perturb2) {
+    bn_finalize_body(part, tiles, pitch, fold, C, count, groups, gamma, beta, rmean, rvar, momentum, eps, scale, shift, mean_o, rstd_o,
+                     perturb1, perturb2);
+}
+// several independent BatchNorm layers in one launch (blockIdx.y = layer): MCGatedPixelCNN's vertical and horizontal gates
+struct BnFinJobs { mcgen_bn_fin_t j[MCGEN_BN_FIN_MAX]; };
+__global__ __launch_bounds__(64 * RED_WAVES)
+void bn_finalize_batch_kernel(const BnFinJobs jobs, double perturb1, double perturb2) {
+    const mcgen_bn_fin_t& j = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x * RED_CPB >= j.C) return;                       // (workgroup-uniform: no barrier is skipped by part of a block)
+    bn_finalize_body(j.partials, j.tiles, j.pitch, j.fold, j.C, j.count, 1, j.gamma, j.beta, j.running_mean, j.running_var, j.momentum, j.eps,
+                     j.scale, j.shift, j.mean, j.rstd, perturb1, perturb2);
 }
 // The statistics groups of a grouped pass in PARALLEL (blockIdx.y = group): the serial form above walks 5 groups x 512
 // tiles on 16 workgroups (14 us for a 256-channel 32x32 layer).  The running statistics take the groups' momentum
@@ -1461,6 +1478,21 @@ extern "C" int mcgen_bn_finalize_groups(const float* partials, int tiles, int pi
                        groups, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd,
                        1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
     MCGEN_LAUNCH_CHECK("bn_finalize"); return 0;
+}
+extern "C" int mcgen_bn_finalize_batch(const mcgen_bn_fin_t* jobs, int n, void* stream) {
+    MCGEN_CHECK(jobs && n >= 1 && n <= MCGEN_BN_FIN_MAX, "bn_finalize_batch: 1 .. %d layers", MCGEN_BN_FIN_MAX);
+    BnFinJobs t; int cmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const mcgen_bn_fin_t& j = jobs[i];
+        MCGEN_CHECK(j.partials && j.gamma && j.beta && j.scale && j.shift && j.mean && j.rstd && j.tiles > 0 && j.fold >= 1 && j.pitch >= j.fold * j.C && j.C > 0,
+                    "bn_finalize_batch: bad job %d", i);
+        MCGEN_CHECK((j.running_mean == nullptr) == (j.running_var == nullptr), "bn_finalize_batch: running_mean and running_var go together");
+        t.j[i] = j; if (j.C > cmax) cmax = j.C;
+    }
+    for (int i = n; i < MCGEN_BN_FIN_MAX; ++i) t.j[i] = jobs[0];
+    hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3((cmax + RED_CPB - 1) / RED_CPB, n), dim3(64 * RED_WAVES), 0, STREAM(stream), t,
+                       1.0 + bn_perturb(), 1.0 - 0.5 * bn_perturb());
+    MCGEN_LAUNCH_CHECK("bn_finalize_batch"); return 0;
 }
 extern "C" int mcgen_bn_finalize_par(const float* partials, int tiles, int pitch, int fold, int C, double count, int groups,
                                      const float* gamma, const float* beta, float eps,

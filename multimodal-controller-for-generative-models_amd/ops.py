@@ -811,6 +811,24 @@ def bn_finalize(partials: Tensor, count: int, gamma: Tensor, beta: Tensor,
     return out[0], out[1], out[2], out[3]
 
 
+def bn_finalize_batch(items):
+    """items = [(partials, count, gamma, beta, running_mean, running_var, momentum, eps)]: several independent BatchNorm layers
+    finalized in ONE launch (mcgen_bn_finalize_batch, <= 4) -> [(scale, shift, mean, rstd)] as bn_finalize gives per layer."""
+    arr = (_lib.BnFin * len(items))()
+    outs = []
+    for d, (partials, count, gamma, beta, rm, rv, momentum, eps) in zip(arr, items):
+        tiles, _, pitch = partials.shape
+        c = gamma.numel()
+        out = torch.empty((4, c), dtype=torch.float32, device=partials.device)
+        d.partials, d.tiles, d.pitch, d.fold, d.C, d.count = _f32(partials), tiles, pitch, 1, c, float(count)
+        d.gamma, d.beta, d.running_mean, d.running_var = _f32(gamma), _f32(beta), _f32(rm), _f32(rv)
+        d.momentum, d.eps = float(momentum), float(eps)
+        d.scale, d.shift, d.mean, d.rstd = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr()
+        outs.append((out[0], out[1], out[2], out[3]))
+    check(_lib.load().mcgen_bn_finalize_batch(arr, len(items), _stream()), 'bn_finalize_batch')
+    return outs
+
+
 def bn_finalize_par(partials: Tensor, count: int, gamma: Tensor, beta: Tensor, eps: float = 1e-5, fold: int = 1, groups: int = 1):
     """bn_finalize with the statistics groups in parallel and the running statistics left alone
     -> (scale, shift, mean, rstd, unbiased var), each [groups, C]; pair with bn_running_batch at the end of the pass."""
@@ -1468,6 +1486,20 @@ def gated_fwd(s: Tensor, scale: Tensor, shift: Tensor, code: Tensor) -> Tensor:
     check(_lib.load().mcgen_gated_fwd(_p(s), _f32(scale), _f32(shift), _f32(code), _p(out), _dt(s.dtype), n, h * w, c, _stream()),
           'gated_fwd')
     return out
+
+
+def gated_fwd_batch(items):
+    """items = [(s, scale, shift, code)]: independent gated activations in ONE launch (mcgen_gated_fwd_batch, <= 4) -> [out]."""
+    arr = (_lib.Gated * len(items))()
+    outs = []
+    for d, (s, scale, shift, code) in zip(arr, items):
+        n, h, w, c2 = s.shape
+        out = torch.empty((n, h, w, c2 // 2), dtype=s.dtype, device=s.device)
+        d.s, d.scale, d.shift, d.code, d.out = _p(s), _f32(scale), _f32(shift), _f32(code), _p(out)
+        d.N, d.HW, d.C = n, h * w, c2 // 2
+        outs.append(out)
+    check(_lib.load().mcgen_gated_fwd_batch(arr, len(items), _dt(items[0][0].dtype), _stream()), 'gated_fwd_batch')
+    return outs
 
 
 def _bwd_sums(partials: Tensor, c: int, dgamma: Optional[Tensor], dbeta: Optional[Tensor]) -> Tensor:

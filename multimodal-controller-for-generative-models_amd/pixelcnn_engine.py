@@ -20,7 +20,10 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from ._tuning import flag as _flag
 from .ops import Seg, pad8
+
+_PAIR_GATES = _flag('MCGEN_PAIR_GATES', '1') != '0'      # a layer's two gates: BatchNorm statistics / activations as one launch each
 
 Tensor = torch.Tensor
 
@@ -131,10 +134,20 @@ class PixelCNNEngine:
         s, st_s = ops.conv_fused([Seg(h_vert, ksize=1), in_h], wimg, 2 * c,
                                  bias=L.vert_to_horiz.bias.detach(), bias2=L.horiz_stack.bias.detach(), stats_mode=sm)
         code_v, code_h = self._code(L.gate_v.mc, label), self._code(L.gate_h.mc, label)
-        bn_v = self._bn(L.gate_v.bn, st_v, count, train)
-        bn_h = self._bn(L.gate_h.bn, st_s, count, train)
-        out_v = ops.gated_fwd(h_vert, bn_v[0], bn_v[1], code_v)
-        out_h = ops.gated_fwd(s, bn_h[0], bn_h[1], code_h)
+        if train and _PAIR_GATES:
+            # the two gates of a layer wait for the same two convolutions and for nothing else: their BatchNorm statistics in
+            # one launch, their activations in another (4 launches -> 2 per layer)
+            bv, bh = L.gate_v.bn, L.gate_h.bn
+            bn_v, bn_h = ops.bn_finalize_batch([
+                (st_v, count, bv.weight.detach(), bv.bias.detach(), bv.running_mean, bv.running_var, bv.momentum, bv.eps),
+                (st_s, count, bh.weight.detach(), bh.bias.detach(), bh.running_mean, bh.running_var, bh.momentum, bh.eps)])
+            self._nbt += [bv.num_batches_tracked, bh.num_batches_tracked]
+            out_v, out_h = ops.gated_fwd_batch([(h_vert, bn_v[0], bn_v[1], code_v), (s, bn_h[0], bn_h[1], code_h)])
+        else:
+            bn_v = self._bn(L.gate_v.bn, st_v, count, train)
+            bn_h = self._bn(L.gate_h.bn, st_s, count, train)
+            out_v = ops.gated_fwd(h_vert, bn_v[0], bn_v[1], code_v)
+            out_h = ops.gated_fwd(s, bn_h[0], bn_h[1], code_h)
         conv_r, bn_rm, mc_r = L.horiz_resid[0].module, L.horiz_resid[1].module, L.horiz_resid[2]
         r, st_r = ops.conv_fused([Seg(out_h, ksize=1)], I[(li, 'r')], c,
                                  bias=conv_r.bias.detach(), stats_mode=sm)

@@ -83,6 +83,40 @@ def test_pixelcnn_kernels():
     assert _rel(ops.to_nchw(dl, 20), logits.grad) < 1e-5
 
 
+def test_paired_gate_launches_equal_the_single_ones():
+    """mcgen_bn_finalize_batch / mcgen_gated_fwd_batch (a layer's vertical and horizontal gate in one launch each,
+    mcpixelcnn.py:16-20,44-56): bit for bit what mcgen_bn_finalize / mcgen_gated_fwd give per gate -- statistics, affine,
+    running statistics, activations -- for two layers of different width in one call."""
+    from mcgen_amd import ops
+    g = torch.Generator().manual_seed(99)
+    dt = torch.bfloat16
+    items, singles = [], []
+    for c, tiles in ((128, 128), (64, 96)):
+        part = (torch.rand(tiles, 2, 2 * c, generator=g) * 50).cuda()
+        part[:, 1] += 100.0                                                      # sums of squares above the squared sums
+        gamma, beta = (1 + 0.1 * torch.randn(2 * c, generator=g)).cuda(), (0.1 * torch.randn(2 * c, generator=g)).cuda()
+        rm, rv = torch.randn(2 * c, generator=g).cuda(), (torch.rand(2 * c, generator=g) + 0.5).cuda()
+        count = tiles * 64
+        rm1, rv1 = rm.clone(), rv.clone()
+        singles.append(ops.bn_finalize(part, count, gamma, beta, rm1, rv1, 0.1, 1e-5) + (rm1, rv1))
+        rm2, rv2 = rm.clone(), rv.clone()
+        items.append((part, count, gamma, beta, rm2, rv2, 0.1, 1e-5))
+    outs = ops.bn_finalize_batch(items)
+    for one, many, it in zip(singles, outs, items):
+        for a, b in zip(one[:4], many):
+            assert torch.equal(a, b)
+        assert torch.equal(one[4], it[4]) and torch.equal(one[5], it[5])          # running statistics
+    gates = []
+    for (n, c, hw) in ((8, 128, 8), (8, 64, 4)):
+        s = torch.randn(n, hw, hw, 2 * c, generator=g).to(dt).cuda()
+        sc, sh = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+        code = (torch.rand(n, c, generator=g) < 0.5).float().cuda()
+        gates.append((s, sc, sh, code))
+    many = ops.gated_fwd_batch(gates)
+    for (s, sc, sh, code), o in zip(gates, many):
+        assert torch.equal(ops.gated_fwd(s, sc, sh, code), o)
+
+
 def test_pixelcnn_forward_vs_reference():
     d = gu.load_npz('mcpixelcnn_small.npz')
     codes, lab = torch.from_numpy(d['codes']).cuda(), torch.from_numpy(d['label']).cuda()
