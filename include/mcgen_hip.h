@@ -235,7 +235,7 @@ int mcgen_prep_weight_ex(const float* w, int64_t s_co, int64_t s_ci, int64_t s_k
                          int KH, int KW, int kh0, int kw0, int ksize, int transpose, int rows_img, int k_img,
                          const float* row_scale, const float* col_scale, float wscale, void* image, int dtype, void* stream);
 /* many generalised images in a few launches (jobs travel by value in the kernel arguments, 16 per launch) */
-#define MCGEN_PREPEX_MAX 16
+#define MCGEN_PREPEX_MAX 32
 typedef struct {
     const float* w; int64_t s_co, s_ci, s_kh, s_kw;
     int32_t Cout, Cin, KH, KW, kh0, kw0, ksize, transpose, rows_img, k_img;

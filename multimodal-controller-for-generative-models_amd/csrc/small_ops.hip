@@ -1386,11 +1386,18 @@ extern "C" int mcgen_prep_weight(const float* w, void* image, int dtype, int Cou
     MCGEN_LAUNCH_CHECK("prep_weight"); return 0;
 }
 
+// blocks per image of the batched weight-image launches: a block walks 8-row x 32-column groups with stride gridDim.x, and a
+// 512 x 512 x 9 image (COIL100's discriminator) has 1024 of them -- 64 blocks per image left that launch on a quarter of the
+// chip (42 us); blocks beyond an image's group count return at once
+#ifndef MCGEN_PREP_BLOCKS
+#define MCGEN_PREP_BLOCKS 256
+#endif
+constexpr int PREP_BLOCKS = MCGEN_PREP_BLOCKS;
 extern "C" int mcgen_prep_weight_batch(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype, void* stream) {
     MCGEN_CHECK(descs_dev && n > 0, "prep_weight_batch: bad arguments");
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(prep_weight_batch_kernel<float>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base),
-        hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(64, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
+        hipLaunchKernelGGL(prep_weight_batch_kernel<float>, dim3(PREP_BLOCKS, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base),
+        hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, dim3(PREP_BLOCKS, n), dim3(256), 0, STREAM(stream), descs_dev, sigma_base));
     MCGEN_LAUNCH_CHECK("prep_weight_batch"); return 0;
 }
 extern "C" int mcgen_prep_weight_batch_codes(const mcgen_prep_t* descs_dev, int n, const float* sigma_base, int dtype,
@@ -1399,8 +1406,8 @@ extern "C" int mcgen_prep_weight_batch_codes(const mcgen_prep_t* descs_dev, int 
     MCGEN_CHECK(descs_dev && n > 0 && label && code_descs_dev && code_base && n_code > 0 && N > 0 && n_label > 0 && N % n_label == 0,
                 "prep_weight_batch_codes: bad arguments (N a multiple of n_label)");
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(prep_codes_kernel<float>, dim3(64, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N),
-        hipLaunchKernelGGL(prep_codes_kernel<bf16_t>, dim3(64, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N));
+        hipLaunchKernelGGL(prep_codes_kernel<float>, dim3(PREP_BLOCKS, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N),
+        hipLaunchKernelGGL(prep_codes_kernel<bf16_t>, dim3(PREP_BLOCKS, n + n_code), dim3(256), 0, STREAM(stream), descs_dev, n, sigma_base, label, n_label, code_descs_dev, code_base, N, scale, scale ? n_half : N));
     MCGEN_LAUNCH_CHECK("prep_weight_batch_codes"); return 0;
 }
 extern "C" int64_t mcgen_weight_image_k_elems(int Cout, int Cin, int ksize) {
